@@ -1,0 +1,175 @@
+"""``CrossAttentionRenderer`` — the drop-in module boundary (reference models.py:42-626).
+
+Same constructor signature, same parameter names/shapes (so a reference checkpoint loads with
+``load_state_dict``), same ``get_z`` / ``forward(input, z=None, val=False, debug=False) -> dict`` contract and
+the same output-dict keys.  Underneath, ``forward`` runs hand-written HIP kernels for gfx950 through the
+C-ABI library ``libcar_hip.so`` (``include/car_hip.h``); there is **no** PyTorch or CPU fallback on the render
+path: if the library is missing or the tensors are not on a ROCm device, ``forward`` raises.
+
+What stays stock PyTorch here is only what the reference also leaves to the framework outside the hot loop:
+parameter storage, ``get_z`` (image encoder + ``conv_map``, once per stereo pair) and output-dict assembly.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+class ResnetBlockFC(nn.Module):
+    """Parameter holder mirroring resnet_block_fc.py:10-62 (fc_0, fc_1; fc_1.weight zero-initialised)."""
+
+    def __init__(self, size: int):
+        super().__init__()
+        self.fc_0 = nn.Linear(size, size)
+        self.fc_1 = nn.Linear(size, size)
+        nn.init.constant_(self.fc_0.bias, 0.0)
+        nn.init.kaiming_normal_(self.fc_0.weight, a=0, mode="fan_in")
+        nn.init.constant_(self.fc_1.bias, 0.0)
+        nn.init.zeros_(self.fc_1.weight)
+
+
+class ResnetFC(nn.Module):
+    """Parameter holder mirroring resnet_block_fc.py:65-130 (lin_in, lin_out, blocks.i, lin_z.i)."""
+
+    def __init__(self, d_in: int, d_out: int, n_blocks: int, d_latent: int, d_hidden: int):
+        super().__init__()
+        self.d_in, self.d_out, self.n_blocks, self.d_latent, self.d_hidden = d_in, d_out, n_blocks, d_latent, d_hidden
+        self.lin_in = nn.Linear(d_in, d_hidden)
+        self.lin_out = nn.Linear(d_hidden, d_out)
+        self.blocks = nn.ModuleList([ResnetBlockFC(d_hidden) for _ in range(n_blocks)])
+        self.lin_z = nn.ModuleList([nn.Linear(d_latent, d_hidden) for _ in range(n_blocks)])
+        for lin in [self.lin_in, self.lin_out, *self.lin_z]:
+            nn.init.constant_(lin.bias, 0.0)
+            nn.init.kaiming_normal_(lin.weight, a=0, mode="fan_in")
+
+
+class EncoderNotBuilt(nn.Module):
+    """Placeholder for the multi-view DPT-hybrid image encoder (reference midas/, vit_models.py).
+
+    The encoder runs once per stereo pair outside the hot loop and is out of scope for this round
+    (SURVEY.md §8f row 2).  Assign any module with ``forward(rgb, rel_pose16, n_view) -> [path_2, path_1]``
+    to ``renderer.encoder`` to make ``get_z`` work; ``forward(input, z=z)`` never touches it.
+    """
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(
+            "image encoder not built: pass precomputed feature maps via forward(input, z=z) or assign "
+            "renderer.encoder = <module returning [path_2 (256@H/4), path_1 (256@H/2)]>")
+
+
+def _feature_dim(model: str) -> int:
+    """Channel count of the concatenated feature pyramid (models.py:63-99)."""
+    if model in ("resnet", "midas"):
+        return 512
+    if model == "midas_vit":
+        return 512 + 64
+    return 32
+
+
+class CrossAttentionRenderer(nn.Module):
+    def __init__(self, no_sample=False, no_latent_concat=False, no_multiview=False, no_high_freq=False,
+                 model="midas_vit", uv=None, repeat_attention=True, n_view=1, npoints=64,
+                 num_hidden_units_phi=128, encoder: Optional[nn.Module] = None):
+        super().__init__()
+        self.n_view = n_view
+        self.npoints = 64 if n_view in (1, 2) else 48
+        if npoints:
+            self.npoints = npoints                          # models.py:53-54 (default 64 overrides 48)
+        self.repeat_attention = repeat_attention
+        self.no_sample = no_sample
+        self.no_latent_concat = no_latent_concat
+        self.no_multiview = no_multiview
+        self.no_high_freq = no_high_freq
+        self.model = model
+        self.num_hidden_units_phi = num_hidden_units_phi
+
+        self.encoder = encoder if encoder is not None else EncoderNotBuilt()
+        self.latent_dim = _feature_dim(model)
+        self.feature_dim = self.latent_dim
+        if model == "midas_vit":
+            self.conv_map = nn.Conv2d(3, 64, kernel_size=7, stride=1, padding=3)
+
+        if self.n_view > 1 and not self.no_latent_concat:
+            self.query_encode_latent = nn.Conv2d(self.latent_dim + 3, self.latent_dim, 1)
+            self.query_encode_latent_2 = nn.Conv2d(self.latent_dim, self.latent_dim // 2, 1)
+            self.latent_dim = self.latent_dim // 2
+            self.update_val_merge = nn.Conv2d(self.latent_dim * 2 + 6, self.latent_dim, 1)
+        elif self.no_latent_concat:
+            self.feature_map = nn.Conv2d(self.latent_dim, self.latent_dim // 2, 1)
+        else:
+            self.update_val_merge = nn.Conv2d(self.latent_dim + 6, self.latent_dim, 1)
+
+        hidden_dim = 128
+        self.hidden_dim = hidden_dim
+        if not self.no_latent_concat:
+            self.latent_value = nn.Conv2d(self.latent_dim * self.n_view, self.latent_dim, 1)
+            self.key_map = nn.Conv2d(self.latent_dim * self.n_view, hidden_dim, 1)
+        else:
+            self.latent_value = nn.Conv2d(self.latent_dim, self.latent_dim, 1)
+            self.key_map = nn.Conv2d(self.latent_dim, hidden_dim, 1)
+        self.key_map_2 = nn.Conv2d(hidden_dim, hidden_dim, 1)
+
+        self.query_embed = nn.Conv2d(16, hidden_dim, 1)
+        self.query_embed_2 = nn.Conv2d(hidden_dim, hidden_dim, 1)
+        # declared by the reference but unused in forward; kept so checkpoints load
+        self.latent_avg_query = nn.Conv2d(9 + 16, hidden_dim, 1)
+        self.latent_avg_query_2 = nn.Conv2d(hidden_dim, hidden_dim, 1)
+        self.latent_avg_key = nn.Conv2d(self.latent_dim, hidden_dim, 1)
+        self.latent_avg_key_2 = nn.Conv2d(hidden_dim, hidden_dim, 1)
+        self.query_repeat_embed = nn.Conv2d(16 + 128, hidden_dim, 1)
+        self.query_repeat_embed_2 = nn.Conv2d(hidden_dim, hidden_dim, 1)
+        self.latent_avg_repeat_query = nn.Conv2d(9 + 16 + 128, hidden_dim, 1)
+        self.latent_avg_repeat_query_2 = nn.Conv2d(hidden_dim, hidden_dim, 1)
+        self.encode_latent = nn.Conv1d(self.latent_dim, 128, 1)
+
+        self.phi = ResnetFC(self.n_view * 9, n_blocks=3, d_out=3, d_latent=self.latent_dim * self.n_view,
+                            d_hidden=self.num_hidden_units_phi)
+        self._engine = None
+
+    # ------------------------------------------------------------------------------------------
+    def get_z(self, input, val=False) -> List[Tensor]:
+        """Feature pyramid of the context views, NCHW (models.py:148-188).  Stock PyTorch by design."""
+        rgb = input["context"]["rgb"]
+        cam2world = input["context"]["cam2world"]
+        rel_cam2world = torch.matmul(torch.inverse(cam2world[:, :1]), cam2world)
+        rgb = torch.flatten(rgb, 0, 1).permute(0, -1, 1, 2)
+        self.H, self.W = rgb.shape[-2], rgb.shape[-1]
+        if self.model in ("resnet", "midas", "midas_vit"):
+            rgb = (rgb + 1) / 2.0
+            mean = rgb.new_tensor([0.485, 0.456, 0.406])[None, :, None, None]
+            std = rgb.new_tensor([0.229, 0.224, 0.225])[None, :, None, None]
+            rgb = (rgb - mean) / std
+        pose16 = rel_cam2world.reshape(-1, 16)
+        if self.no_multiview:
+            pose16 = torch.zeros_like(pose16)
+        z = list(self.encoder.forward(rgb, pose16, self.n_view))
+        if self.model in ("midas", "midas_vit"):
+            z_conv = self.conv_map(rgb)
+            if self.no_high_freq:
+                z_conv = torch.zeros_like(z_conv)
+            z = z + [z_conv]
+        return z
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, input, z=None, val=False, debug=False) -> Dict[str, Tensor]:
+        """Render the query rays (models.py:190-626) on the HIP engine.  ``input`` is not mutated."""
+        from .engine import RenderEngine          # deferred: importing the package must work without the .so
+        if z is None:
+            z = self.get_z(input)
+        elif not hasattr(self, "H"):
+            # the reference requires get_z to have run (models.py:162); recover H, W from the RGB shape
+            self.H, self.W = input["context"]["rgb"].shape[2:4]
+        if self._engine is None:
+            self._engine = RenderEngine(self)
+        return self._engine.render(input, z, debug=debug)
+
+
+def renderer_param_shapes(model="midas_vit", n_view=2, no_latent_concat=False) -> Dict[str, tuple]:
+    """name -> shape of every renderer parameter except the image encoder's."""
+    m = CrossAttentionRenderer(model=model, n_view=n_view, no_latent_concat=no_latent_concat)
+    return {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.startswith("encoder.")}

@@ -1,0 +1,493 @@
+"""CPU oracle for the epipolar cross-attention render forward.  TEST INFRASTRUCTURE ONLY.
+
+This module is a from-scratch CPU (PyTorch, fp32 + fp64 where the reference uses fp64) restatement of
+``CrossAttentionRenderer.forward(input, z=z)`` of yilundu/cross_attention_renderer
+(reference models.py:190-626 with epipolar.py:175-253 and geometry.py:98-162, 236-245, 313-433).
+It exists to *check* the HIP path; it is never the thing shipped or measured:
+
+  * only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it;
+  * the product package ``cross_attention_renderer_amd`` must never import it (a test enforces this).
+
+Parity pinning: the reference ships no tests or golden vectors for this path, so the
+oracle is pinned against the *reference itself*, imported read-only in the build container by
+``tests/golden/make_golden.py``; the resulting vectors are committed as ``tests/golden/*.npz`` and
+``tests/test_oracle_golden.py`` replays them everywhere (including the GPU box, where the reference
+does not exist).
+
+Conventions (all reference quirks are reproduced on purpose, see SURVEY.md §7 "Hard parts"):
+  b scenes, V context views, R rays, P samples per view; C = sum of feature-map channels.
+  ``z`` is the list of NCHW feature maps returned by ``get_z``; all of them are sampled at every point.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Mapping, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class RenderConfig:
+    """Constructor knobs of the reference module that reach the hot path (models.py:43-61)."""
+    n_view: int = 2
+    npoints: int = 64
+    no_sample: bool = False
+    no_latent_concat: bool = False
+    repeat_attention: bool = True
+    H: int = 256
+    W: int = 256
+
+
+# --------------------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------------------
+
+def _fma(a: Tensor, b: Tensor, c: Tensor) -> Tensor:
+    """fp32 fused multiply-add, emulated exactly in fp64 (a*b is exact in fp64; the one extra rounding
+    of the fp64 sum is a ~2^-29-probability event).  The reference's small einsum/bmm call sites run as
+    MKL FMA chains in k order (checked bitwise in the build container), and the HIP kernels use ``fmaf``
+    at the same places, so the oracle does too."""
+    return (a.double() * b.double() + c.double()).float()
+
+
+def _scrub(x: Tensor, value: float) -> Tensor:
+    """NaN/Inf -> value (the reference does ``x[isnan(x)] = v; x[isinf(x)] = v``)."""
+    return torch.where(torch.isfinite(x), x, torch.full_like(x, value))
+
+
+def _conv1x1(x: Tensor, w: Tensor, bias: Tensor) -> Tensor:
+    """1x1 Conv2d / Conv1d on channel-last data: x (..., Cin) -> (..., Cout)."""
+    return F.linear(x, w.reshape(w.shape[0], -1), bias)
+
+
+def _apply_4x4(T: Tensor, p: Tensor) -> Tensor:
+    """T (...,4,4) applied to points p (...,N...,3) broadcast over the sample dims: T[:3,:3] p + T[:3,3].
+
+    Mirrors ``encode_relative_point`` (models.py:30-39): homogeneous multiply, first three rows kept.
+    Summation order over j = 0..3 matches a left-to-right reduction.
+    """
+    x, y, zc = p[..., 0], p[..., 1], p[..., 2]
+    out = []
+    for i in range(3):
+        out.append(((x * T[..., i, 0] + y * T[..., i, 1]) + zc * T[..., i, 2]) + T[..., i, 3])
+    return torch.stack(out, dim=-1)
+
+
+def parse_intrinsics(K: Tensor):
+    """fx, fy, cx, cy of a (...,4,4) or (...,3,3) intrinsic matrix (geometry.py:335-340)."""
+    return K[..., 0, 0], K[..., 1, 1], K[..., 0, 2], K[..., 1, 2]
+
+
+# --------------------------------------------------------------------------------------
+# a4: query rays as Pluecker lines in each context camera frame  (geometry.py:236-245, 409-433)
+# --------------------------------------------------------------------------------------
+
+def pluecker_rays(cam2world: Tensor, uv: Tensor, K: Tensor) -> Tensor:
+    """cam2world (n,4,4), uv (n,R,2) pixel units (x=col, y=row), K (n,4,4) -> (n,R,6) = [d, o x d].
+
+    d = normalize(cam2world @ [(u-cx)/fx, (v-cy)/fy, 1, 1] - o), o = cam2world[:3,3].
+    """
+    fx, fy, cx, cy = (t[:, None] for t in parse_intrinsics(K))
+    x = (uv[..., 0] - cx) / fx
+    y = (uv[..., 1] - cy) / fy
+    one = torch.ones_like(x)
+    M = cam2world[:, None]                                    # (n,1,4,4)
+    world = []
+    for i in range(3):   # einsum('b...ij,b...kj->b...ki') == FMA chain over j = 0..3 (geometry.py:417)
+        acc = x * M[..., i, 0]
+        acc = _fma(y, M[..., i, 1], acc)
+        acc = _fma(one, M[..., i, 2], acc)
+        world.append(_fma(one, M[..., i, 3], acc))
+    world = torch.stack(world, dim=-1)
+    o = cam2world[:, None, :3, 3].expand_as(world)
+    d = F.normalize(world - o, dim=-1)                        # eps = 1e-12
+    m = torch.cross(o, d, dim=-1)
+    return torch.cat([d, m], dim=-1)
+
+
+# --------------------------------------------------------------------------------------
+# a5: clip the projected query ray to the unit image square  (epipolar.py:74-253)
+# --------------------------------------------------------------------------------------
+
+def _in_bounds(xy: Tensor, eps: float = 1e-6) -> Tensor:
+    return (xy >= -eps).all(dim=-1) & (xy <= 1 + eps).all(dim=-1)
+
+
+def _frame_line_hit(K: Tensor, o: Tensor, d: Tensor, dim: int, value: float):
+    """Intersection of the projected ray with the image-frame line ``xy[dim] == value``.
+
+    K (n,1,3,3) normalised intrinsics, o/d (n,R,3).  Returns t (n,R), xy (n,R,2), valid (n,R).
+    Divisions by zero are allowed to produce inf/nan (epipolar.py:101-111).
+    """
+    od = 1 - dim
+    fs, fo = K[..., dim, dim], K[..., od, od]
+    cs, co = K[..., dim, 2], K[..., od, 2]
+    o_s, o_o, o_z = o[..., dim], o[..., od], o[..., 2]
+    d_s, d_o, d_z = d[..., dim], d[..., od], d[..., 2]
+    c = (value - cs) / fs
+    t = (c * o_z - o_s) / (d_s - c * d_z)
+    num = fo * (o_o * (c * d_z - d_s) + d_o * (o_s - c * o_z))
+    den = d_z * o_s - d_s * o_z
+    other = co + num / den
+    same = torch.ones_like(other) * value
+    xy = torch.stack([same, other] if dim == 0 else [other, same], dim=-1)
+    xyz_z = o_z + t * d_z
+    valid = _in_bounds(xy) & (xyz_z > -1e-6)
+    return t, xy, valid
+
+
+def _pinhole01(p: Tensor, K: Tensor, eps: float = 1e-8) -> Tensor:
+    """epipolar.project: p/(p_z+eps) then K (n,1,3,3) applied, first two coordinates."""
+    q = p / (p[..., -1:] + eps)
+    x = _fma(K[..., 0, 2], q[..., 2], _fma(K[..., 0, 1], q[..., 1], K[..., 0, 0] * q[..., 0]))
+    y = _fma(K[..., 1, 2], q[..., 2], _fma(K[..., 1, 1], q[..., 1], K[..., 1, 0] * q[..., 0]))
+    return torch.stack([x, y], dim=-1)
+
+
+def project_rays(o: Tensor, d: Tensor, K01: Tensor, eps: float = 1e-6) -> Dict[str, Tensor]:
+    """o,d (n,R,3) in the context camera frame, K01 (n,3,3) intrinsics normalised to a 0..1 image.
+
+    Restates epipolar.project_rays with identity extrinsics (the only way models.py:232-238 calls it).
+    Returns xy_min, xy_max (n,R,2), t_min, t_max (n,R), overlaps_image (n,R) bool.
+    """
+    K = K01[:, None]
+    hits = [_frame_line_hit(K, o, d, 0, 0.0), _frame_line_hit(K, o, d, 0, 1.0),
+            _frame_line_hit(K, o, d, 1, 0.0), _frame_line_hit(K, o, d, 1, 1.0)]
+    t = torch.stack([h[0] for h in hits])                      # (4,n,R)
+    xy = torch.stack([h[1] for h in hits])                     # (4,n,R,2)
+    ok = torch.stack([h[2] for h in hits])                     # (4,n,R)
+
+    def pick(reduction: str):
+        tt = torch.where(ok, t, torch.full_like(t, math.inf if reduction == "min" else -math.inf))
+        red, sel = getattr(tt, reduction)(dim=0)
+        xy_sel = xy.gather(0, sel[None, ..., None].expand(1, *sel.shape, 2))[0]
+        ok_sel = ok.gather(0, sel[None])[0]
+        return red, xy_sel, ok_sel
+
+    fmin_t, fmin_xy, fmin_ok = pick("min")
+    fmax_t, fmax_xy, fmax_ok = pick("max")
+
+    depth_zero = o[..., 2] < eps
+    at_camera = o.norm(dim=-1) < eps
+    p0 = torch.where(at_camera[..., None], d, o)
+    xy0 = _pinhole01(p0, K)
+    ok0 = _in_bounds(xy0) & (p0[..., 2] > -1e-6)
+    ok0 = ok0 & ~(depth_zero & ~at_camera)
+    xyi = _pinhole01(d, K)
+    oki = _in_bounds(xyi) & (d[..., 2] > -1e-6)
+
+    xy_min = torch.where(ok0[..., None], xy0, fmin_xy)
+    xy_max = torch.where(oki[..., None], xyi, fmax_xy)
+    t_min = torch.where(ok0, torch.zeros_like(fmin_t), fmin_t)
+    t_max = torch.where(oki, torch.full_like(fmax_t, math.inf), fmax_t)
+    overlaps = torch.where(ok0, ok0, fmin_ok) & torch.where(oki, oki, fmax_ok)
+    return {"xy_min": xy_min, "xy_max": xy_max, "t_min": t_min, "t_max": t_max,
+            "overlaps_image": overlaps}
+
+
+# --------------------------------------------------------------------------------------
+# no_sample variant: uniform depth samples on the query ray (geometry.py:165-187)
+# --------------------------------------------------------------------------------------
+
+def _project_pixels(p: Tensor, K: Tensor) -> Tensor:
+    """geometry.project: p (...,3) with K broadcastable (...,4,4) -> (..., 2) pixel coords; NaN/Inf -> 1e10."""
+    fx, fy, cx, cy = parse_intrinsics(K)
+    x = fx * p[..., 0] / (p[..., 2] + 1e-12) + cx
+    y = fy * p[..., 1] / (p[..., 2] + 1e-12) + cy
+    return _scrub(torch.stack([x, y], dim=-1), 1e10)
+
+
+def _norm_for_grid(px: Tensor, H: int, W: int) -> Tensor:
+    """utils/util.py:16-19: pixel -> [-1,1] with the (W-1) convention."""
+    return torch.stack([px[..., 0] / (W - 1) * 2 - 1, px[..., 1] / (H - 1) * 2 - 1], dim=-1)
+
+
+def volumetric_samples(lf: Tensor, q_c2w: Tensor, K_ctx: Tensor, H: int, W: int, P: int):
+    """lf (b,V,R,6), q_c2w (b,V,4,4), K_ctx (b,V,4,4) -> pixel_val (b,V,R,P,2), valid (b,V,R) bool."""
+    o = q_c2w[..., :3, 3][:, :, None, None, :]
+    s = torch.linspace(0.1, 10.0, P, device=lf.device)
+    pts = o + s[None, None, None, :, None] * lf[..., None, :3]
+    px = _project_pixels(pts, K_ctx[:, :, None, None])
+    pv = _norm_for_grid(px, H, W)
+    valid = ((pv < 1) & (pv > -1)).all(dim=-1).any(dim=-1)
+    return pv, valid
+
+
+# --------------------------------------------------------------------------------------
+# a7 / a10: bilinear gathers from the feature pyramid
+# --------------------------------------------------------------------------------------
+
+def gather_pyramid(z: List[Tensor], grid: Tensor, padding_mode: str) -> Tensor:
+    """z: list of (n,C_l,H_l,W_l); grid (n,R,P,2) in [-1,1] -> (n,R,P,sum C_l) channel-last.
+
+    ``F.grid_sample(bilinear, align_corners=False)`` per level, concatenated on channels in list order
+    (models.py:278, 317).
+    """
+    outs = [F.grid_sample(lat, grid, mode="bilinear", padding_mode=padding_mode, align_corners=False)
+            for lat in z]
+    return torch.cat(outs, dim=1).permute(0, 2, 3, 1)
+
+
+def bilinear_explicit(feat: Tensor, grid: Tensor, padding_mode: str) -> Tensor:
+    """Explicit 4-tap restatement of grid_sample (align_corners=False) for one NCHW map.
+
+    This is the formula the HIP gather implements; kept here so a CPU test can pin it
+    against ``F.grid_sample`` itself.  feat (n,C,Hl,Wl), grid (n,R,P,2) -> (n,R,P,C).
+    """
+    n, C, Hl, Wl = feat.shape
+    ix = ((grid[..., 0] + 1) * Wl - 1) / 2
+    iy = ((grid[..., 1] + 1) * Hl - 1) / 2
+    if padding_mode == "border":
+        ix = ix.clamp(0, Wl - 1)
+        iy = iy.clamp(0, Hl - 1)
+    # coordinates can be ~1e10 (geometry.project scrubbing): clamp before the integer conversion
+    ix = ix.clamp(-4.0, Wl + 4.0)
+    iy = iy.clamp(-4.0, Hl + 4.0)
+    x0 = torch.floor(ix)
+    y0 = torch.floor(iy)
+    wx1 = ix - x0
+    wy1 = iy - y0
+    wx0 = 1 - wx1
+    wy0 = 1 - wy1
+    fl = feat.permute(0, 2, 3, 1).reshape(n, Hl * Wl, C)
+    out = torch.zeros(*grid.shape[:-1], C, dtype=feat.dtype)
+    for dy, wy in ((0, wy0), (1, wy1)):
+        for dx, wx in ((0, wx0), (1, wx1)):
+            xi = (x0 + dx).long()
+            yi = (y0 + dy).long()
+            inside = (xi >= 0) & (xi < Wl) & (yi >= 0) & (yi < Hl)
+            idx = (yi.clamp(0, Hl - 1) * Wl + xi.clamp(0, Wl - 1)).reshape(n, -1)
+            tap = torch.gather(fl, 1, idx[..., None].expand(-1, -1, C)).reshape(*grid.shape[:-1], C)
+            w = (wx * wy) * inside.to(feat.dtype)
+            out = out + tap * w[..., None]
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# a8: closest point on the query line to each sample's pixel ray, in fp64 (geometry.py:98-162)
+# --------------------------------------------------------------------------------------
+
+def epipolar_points(lf: Tensor, pixel_val: Tensor, ctx_c2w: Tensor, K_ctx: Tensor, H: int, W: int) -> Tensor:
+    """lf (n,R,6), pixel_val (n,R,P,2), ctx_c2w (n,4,4) (~identity), K_ctx (n,4,4) -> pt (n,R,P,3) fp32."""
+    n, R, P, _ = pixel_val.shape
+    px = (pixel_val[..., 0] + 1) / 2 * (W - 1)
+    py = (pixel_val[..., 1] + 1) / 2 * (H - 1)
+    pix = torch.stack([px, py], dim=-1).reshape(n, R * P, 2)
+    ctx_line = pluecker_rays(ctx_c2w, pix, K_ctx).reshape(n, R, P, 6).double()
+    q_line = lf[:, :, None, :].double().expand(n, R, P, 6)
+    l1, m1 = q_line[..., :3], q_line[..., 3:]
+    l2, m2 = ctx_line[..., :3], ctx_line[..., 3:]
+    n12 = torch.cross(l1, l2, dim=-1)
+    l2xn = torch.cross(l2, n12, dim=-1)
+    first = -torch.cross(m1, l2xn, dim=-1)
+    second = (m2 * n12).sum(dim=-1, keepdim=True) * l1
+    den = n12.norm(p=2, dim=-1, keepdim=True).pow(2) + 1e-12
+    p1 = (first + second) / den
+    return _scrub(p1, 0.0).float()
+
+
+def camera_ray_dirs(pixel_val: Tensor, K: Tensor, H: int, W: int) -> Tensor:
+    """geometry.get_ray_directions_cam: unit direction of each sample's pixel ray in its own camera."""
+    fx, fy, cx, cy = (t[:, None, None] for t in parse_intrinsics(K))
+    y = (pixel_val[..., 1] + 1) / 2 * (H - 1)
+    x = (pixel_val[..., 0] + 1) / 2 * (W - 1)
+    v = torch.stack([(x - cx) / fx, (y - cy) / fy, torch.ones_like(x)], dim=-1)
+    return F.normalize(v, dim=-1)
+
+
+# --------------------------------------------------------------------------------------
+# a17: light-field decoder (resnet_block_fc.py:53-62, 132-168)
+# --------------------------------------------------------------------------------------
+
+def resnet_fc(params: Mapping[str, Tensor], zx: Tensor, d_latent: int, prefix: str = "phi.",
+              n_blocks: int = 3) -> Tensor:
+    zlat, x = zx[..., :d_latent], zx[..., d_latent:]
+    x = F.linear(x, params[prefix + "lin_in.weight"], params[prefix + "lin_in.bias"])
+    for i in range(n_blocks):
+        x = x + F.linear(zlat, params[f"{prefix}lin_z.{i}.weight"], params[f"{prefix}lin_z.{i}.bias"])
+        net = F.linear(F.relu(x), params[f"{prefix}blocks.{i}.fc_0.weight"], params[f"{prefix}blocks.{i}.fc_0.bias"])
+        dx = F.linear(F.relu(net), params[f"{prefix}blocks.{i}.fc_1.weight"], params[f"{prefix}blocks.{i}.fc_1.bias"])
+        x = x + dx
+    return F.linear(F.relu(x), params[prefix + "lin_out.weight"], params[prefix + "lin_out.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# the forward pass
+# --------------------------------------------------------------------------------------
+
+def render_forward(params: Mapping[str, Tensor], inp: Mapping, z: List[Tensor], cfg: RenderConfig,
+                   debug: bool = False) -> Dict[str, Tensor]:
+    """Restates ``CrossAttentionRenderer.forward(input, z=z)`` (models.py:190-626) on CPU.
+
+    ``params``: the module's state_dict (names of SURVEY.md §8b).  ``inp``: the reference input dict
+    (``context``: rgb (b,V,H,W,3) [shape only], cam2world (b,V,4,4), intrinsics (b,V,4,4);
+    ``query``: cam2world (b,1,4,4), intrinsics (b,1,4,4), uv (b,1,R,2)).  Returns the reference's output
+    dict; with ``debug`` also the per-stage intermediates under ``"stages"``.
+    """
+    ctx, qry = inp["context"], inp["query"]
+    c2w_ctx, K_ctx = ctx["cam2world"].float(), ctx["intrinsics"].float()
+    c2w_q, K_q, uv = qry["cam2world"].float(), qry["intrinsics"].float(), qry["uv"].float()
+    b, V = c2w_ctx.shape[:2]
+    n_qry, R = uv.shape[1:3]
+    assert n_qry == 1, "the reference forward only works with one query view (models.py:213, 619)"
+    assert V == cfg.n_view
+    P, H, W = cfg.npoints, cfg.H, cfg.W
+    st: Dict[str, Tensor] = {}
+
+    # a3 pose algebra (models.py:207-211)
+    inv_ctx = torch.inverse(c2w_ctx)
+    ctx_rel = torch.matmul(inv_ctx, c2w_ctx)                  # ~identity, (b,V,4,4)
+    q_rel = torch.matmul(inv_ctx, c2w_q)                      # (b,V,4,4)
+
+    # a4 query rays in every context frame (models.py:213-214)
+    lf = pluecker_rays(q_rel.flatten(0, 1), uv.expand(-1, V, -1, -1).flatten(0, 1),
+                       K_q.expand(-1, V, -1, -1).flatten(0, 1))             # (bV,R,6)
+    o_q = q_rel[..., :3, 3].flatten(0, 1)                     # (bV,3)
+
+    # a5/a6 epipolar segment and sample positions (models.py:221-275)
+    if cfg.no_sample:
+        pv, valid = volumetric_samples(lf.reshape(b, V, R, 6), q_rel, K_ctx, H, W, P)
+        pixel_val = pv.flatten(0, 1)
+        valid_mask = valid.float()
+    else:
+        K01 = K_ctx.clone()
+        K01[:, :, :2, :] = K01[:, :, :2, :] / H
+        seg = project_rays(o_q[:, None, :].expand(-1, R, -1), lf[..., :3], K01.flatten(0, 1)[:, :3, :3])
+        start = _scrub((seg["xy_min"] - 0.5) * 2, 0.0)
+        end = _scrub((seg["xy_max"] - 0.5) * 2, 0.0)
+        interval = torch.linspace(0, 1, P)
+        pixel_val = start[:, :, None, :] + (end - start)[:, :, None, :] * interval[None, None, :, None]
+        valid_mask = seg["overlaps_image"].reshape(b, V, R).float()
+        st.update(xy_min=seg["xy_min"], xy_max=seg["xy_max"], overlaps=seg["overlaps_image"])
+    st.update(lf=lf, pixel_val=pixel_val)
+
+    # a7 gather #1: own features along the line (models.py:278)
+    feat_own = gather_pyramid(z, pixel_val, "border")         # (bV,R,P,C)
+    C = feat_own.shape[-1]
+
+    # a8 3-D point per sample (models.py:283 / 503)
+    Kf = K_ctx.flatten(0, 1)
+    pt = epipolar_points(lf, pixel_val, ctx_rel.flatten(0, 1), Kf, H, W)     # (bV,R,P,3)
+    st.update(pt=pt)
+
+    if cfg.no_latent_concat:
+        e = feat_own                                          # models.py:476-477
+    elif V == 1:
+        # models.py:478-485
+        ptn = torch.where(torch.isnan(pt), torch.zeros_like(pt), pt)
+        pt_ctx = torch.cat([torch.tanh(ptn / 5.0), torch.tanh(ptn / 100.0)], dim=-1)
+        e = _conv1x1(torch.cat([feat_own, pt_ctx], dim=-1),
+                     params["update_val_merge.weight"], params["update_val_merge.bias"])
+    elif V == 2:
+        # a9-a11 cross-view exchange (models.py:285-344)
+        ptv = pt.reshape(b, V, R, P, 3)
+        # T_s[c] maps a point from context frame c into context frame s
+        T = [torch.matmul(torch.inverse(c2w_ctx[:, s:s + 1]), c2w_ctx) for s in range(V)]   # each (b,V,4,4)
+        pts_in = [_apply_4x4(T[s][:, :, None, None], ptv) for s in range(V)]                # [s] -> (b,V,R,P,3)
+        # where the points of the *other* line land in each view: index v = map that is sampled
+        other = [1, 0]
+        grid_other = torch.stack(
+            [_norm_for_grid(_project_pixels(pts_in[v][:, other[v]], K_ctx[:, v, None, None]), H, W)
+             for v in range(V)], dim=1).flatten(0, 1)          # (bV,R,P,2)
+        st.update(pixel_val_stack=grid_other)
+        feat_oth = gather_pyramid(z, grid_other, "zeros").reshape(b, V, R, P, C)
+        feat_ownv = feat_own.reshape(b, V, R, P, C)
+        st.update(feat_own=feat_own, feat_other=feat_oth.flatten(0, 1))
+
+        def enc(x: Tensor) -> Tensor:
+            h = F.relu(_conv1x1(x, params["query_encode_latent.weight"], params["query_encode_latent.bias"]))
+            return _conv1x1(h, params["query_encode_latent_2.weight"], params["query_encode_latent_2.bias"])
+
+        per_ctx = []
+        for c in range(V):
+            halves = []
+            for s in range(V):                                 # view-1-sourced half first (models.py:335, 342)
+                f = feat_ownv[:, c] if s == c else feat_oth[:, s]
+                p3 = torch.nan_to_num(pts_in[s][:, c], 0.0)
+                halves.append(enc(torch.cat([f, torch.tanh(p3 / 5.0)], dim=-1)))
+            per_ctx.append(torch.cat(halves, dim=-1))
+        e = torch.stack(per_ctx, dim=1).flatten(0, 1)         # (bV,R,P,2*C/2)
+    else:
+        raise NotImplementedError("n_view=3 is restated in oracle/car_oracle_nview3.py")
+    st.update(interp_val=e)
+
+    # a12 values and keys (models.py:487-491)
+    val = _conv1x1(e, params["latent_value.weight"], params["latent_value.bias"])
+    key = _conv1x1(F.relu(_conv1x1(e, params["key_map.weight"], params["key_map.bias"])),
+                   params["key_map_2.weight"], params["key_map_2.bias"])
+
+    # a13 geometric query per sample (models.py:494-529)
+    cam_rays = camera_ray_dirs(pixel_val, Kf, H, W)
+    ray_dir = lf[:, :, None, :3].expand(-1, -1, P, -1)
+    o_ex = o_q[:, None, None, :].expand(-1, R, P, -1)
+    depth = _scrub((pt - o_ex).norm(p=2, dim=-1, keepdim=True), 1e6)
+    depth_enc = torch.cat([torch.tanh(depth), torch.tanh(depth / 10.0), torch.tanh(depth / 100.0),
+                           torch.tanh(depth / 1000.0)], dim=-1)
+    g = torch.cat([cam_rays, torch.zeros_like(o_ex), ray_dir, depth_enc, o_ex], dim=-1)    # (bV,R,P,16)
+    q = _conv1x1(F.relu(_conv1x1(g, params["query_embed.weight"], params["query_embed.bias"])),
+                 params["query_embed_2.weight"], params["query_embed_2.bias"])
+    st.update(local_coords=g, depth=depth)
+
+    def ray_softmax(logit: Tensor) -> Tensor:
+        """(bV,R,P) logits -> softmax over the ray's V*P samples ordered [view 1's P, view 2's P]."""
+        lg = logit.reshape(b, V, R, P).permute(0, 2, 1, 3).reshape(b, R, V * P)
+        w = F.softmax(lg, dim=-1)
+        return w.reshape(b, R, V, P).permute(0, 2, 1, 3).flatten(0, 1)
+
+    def view_sum(x: Tensor) -> Tensor:
+        """(bV,R,D) -> sum over views, replicated back to every view."""
+        s = x.reshape(b, V, *x.shape[1:]).sum(dim=1, keepdim=True)
+        return s.expand(-1, V, *([-1] * (x.dim() - 1))).flatten(0, 1)
+
+    # a14 attention round 1 (models.py:532-544)
+    at_wt = ray_softmax((key * q).sum(dim=-1) / 16.0)
+    z_local = view_sum((val * at_wt[..., None]).sum(dim=2))    # (bV,R,D)
+    st.update(at_wt1=at_wt, z1=z_local)
+
+    # a15 attention round 2 (models.py:547-565)
+    if cfg.repeat_attention:
+        h = _conv1x1(z_local, params["encode_latent.weight"], params["encode_latent.bias"])   # (bV,R,128)
+        q2_in = torch.cat([h[:, :, None, :].expand(-1, -1, P, -1), g], dim=-1)
+        q2 = _conv1x1(F.relu(_conv1x1(q2_in, params["query_repeat_embed.weight"], params["query_repeat_embed.bias"])),
+                      params["query_repeat_embed_2.weight"], params["query_repeat_embed_2.bias"])
+        at_wt2 = ray_softmax((q2 * q).sum(dim=-1) / 16.0)
+        z_local = view_sum((val * at_wt2[..., None]).sum(dim=2) + z_local)
+        st.update(at_wt2=at_wt2)
+    st.update(z_final=z_local)
+
+    # a16 depth read-out from the round-1 weights (models.py:573-594)
+    pt_mean = (at_wt[..., None] * pt.clamp(-100, 100)).sum(dim=-2)          # (bV,R,3)
+    pt_mean = pt_mean.reshape(b, V, R, 3).sum(dim=1)
+    inv_q = torch.inverse(c2w_q[:, 0])
+    depth_ray = _apply_4x4(inv_q[:, None], pt_mean)[..., 2].clamp(0, 10)[..., None]
+    at_wt_max = at_wt.argmax(dim=-1)[..., None]
+
+    # a17 decode (models.py:597-612)
+    coords9 = torch.cat([lf, o_q[:, None, :].expand(-1, R, -1)], dim=-1)    # (bV,R,9)
+    coords = coords9.reshape(b, V, R, 9).permute(0, 2, 1, 3).flatten(-2, -1)
+    D = z_local.shape[-1]
+    z_flat = z_local.reshape(b, V, R, D).permute(0, 2, 1, 3).flatten(-2, -1)
+    rgb = resnet_fc(params, torch.cat([z_flat, coords], dim=-1), d_latent=D * V)[..., :3]
+
+    # a18 valid mask and output dict (models.py:614-626)
+    valid = valid_mask.reshape(b, V, R).bool().any(dim=1).float()
+    rgb = rgb * valid[:, :, None] + (1 - valid[:, :, None])
+    out = {
+        "rgb": rgb.reshape(b, n_qry, R, 3),
+        "valid_mask": valid[..., None],
+        "depth_ray": depth_ray,
+        "at_wt": at_wt,
+        "at_wts": [at_wt],
+        "at_wt_max": at_wt_max,
+        "coords": coords9,
+        "uv": qry["uv"],
+        "pixel_val": pixel_val,
+        "z": z,
+    }
+    if debug:
+        out["stages"] = st
+    return out

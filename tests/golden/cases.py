@@ -1,0 +1,100 @@
+"""Golden-vector case table shared by ``make_golden.py`` (writer, build container only) and the tests
+(readers, everywhere).  A case is fully described by small numbers: shapes, seeds and pose knobs.  The
+bulky inputs (feature maps, weights) are regenerated from the seeds by
+``cross_attention_renderer_amd.synthetic``; every fixture stores checksums of them so that RNG drift is
+detected instead of silently invalidating the vectors.
+
+Tiers:
+  T0  tiny widths (latent 32 -> 16), every intermediate stored, plus the constructor variants (a19);
+  T1  real widths (C=576) at the C1 shape (64x64, 32 samples), 256 rays;
+  T2  real widths at the C2/C4/C5 shapes (256x256x64, x128, 384x384x64), 48-64 rays, outputs only.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from cross_attention_renderer_amd import synthetic as S
+
+GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
+
+TINY = dict(model="tiny", channels=(16, 16), strides=(2, 1))
+REAL = dict(model="midas_vit", channels=(256, 256, 64), strides=(4, 2, 1))
+
+CASES: Dict[str, dict] = {
+    # ---- T0: tiny widths, full intermediates -------------------------------------------------
+    "t0_default": dict(tier=0, H=16, P=8, b=2, rays=64, **TINY),
+    "t0_query_at_ctx0": dict(tier=0, H=16, P=8, b=1, rays=64, query_at_context=0, **TINY),
+    "t0_query_at_ctx1": dict(tier=0, H=16, P=8, b=1, rays=64, query_at_context=1, **TINY),
+    "t0_diverging": dict(tier=0, H=16, P=8, b=2, rays=96, yaw_deg=38.0, baseline=0.9, **TINY),
+    "t0_no_repeat": dict(tier=0, H=16, P=8, b=1, rays=64, repeat_attention=False, **TINY),
+    "t0_no_sample": dict(tier=0, H=16, P=8, b=1, rays=64, no_sample=True, **TINY),
+    "t0_no_latent_concat": dict(tier=0, H=16, P=8, b=1, rays=64, no_latent_concat=True, **TINY),
+    "t0_nview1": dict(tier=0, H=16, P=8, b=2, rays=64, n_view=1, **TINY),
+    "t0_p5": dict(tier=0, H=16, P=5, b=1, rays=37, **TINY),            # ragged sizes
+    # ---- T1: real widths, C1 shape -----------------------------------------------------------
+    "t1_c1": dict(tier=1, H=64, P=32, b=1, rays=256, **REAL),
+    "t1_c1_diverging": dict(tier=1, H=64, P=32, b=1, rays=128, yaw_deg=38.0, baseline=0.9, **REAL),
+    # ---- T2: real widths, bench shapes -------------------------------------------------------
+    "t2_c2": dict(tier=2, H=256, P=64, b=1, rays=64, **REAL),
+    "t2_c3": dict(tier=2, H=256, P=64, b=2, rays=48, alpha=0.3, **REAL),
+    "t2_c4": dict(tier=2, H=256, P=128, b=1, rays=48, **REAL),
+    "t2_c5": dict(tier=2, H=384, P=64, b=1, rays=48, alpha=0.7, **REAL),
+}
+
+DEFAULTS = dict(n_view=2, no_sample=False, no_latent_concat=False, repeat_attention=True,
+                alpha=0.5, baseline=0.6, yaw_deg=-12.0, query_at_context=None,
+                scene_seed=5, z_seed=1, w_seed=3)
+
+# outputs stored for every case / only for tier 0
+OUT_KEYS = ["rgb", "valid_mask", "depth_ray", "at_wt", "at_wt_max", "coords", "pixel_val"]
+STAGE_KEYS_T0 = ["interp_val", "pt", "z_final"]
+
+
+def case_config(name: str) -> dict:
+    c = dict(DEFAULTS)
+    c.update(CASES[name])
+    c["name"] = name
+    return c
+
+
+def select_rays(H: int, n: int) -> torch.Tensor:
+    """``n`` pixel coordinates spread over the HxH grid (corners included), x fastest."""
+    grid = S.pixel_grid(H, H)
+    idx = torch.linspace(0, H * H - 1, n).round().long()
+    # make sure the four corners are present
+    corners = torch.tensor([0, H - 1, H * (H - 1), H * H - 1])
+    idx[: min(4, n)] = corners[: min(4, n)]
+    return grid[idx].contiguous()
+
+
+def param_shapes(c: dict) -> Dict[str, tuple]:
+    """Parameter name -> shape table of the renderer (without the image encoder) for a case; the same
+    table the product module declares."""
+    from cross_attention_renderer_amd.models import renderer_param_shapes
+    return renderer_param_shapes(model=c["model"], n_view=c["n_view"], no_latent_concat=c["no_latent_concat"])
+
+
+def build_inputs(c: dict):
+    """(input dict, z list, uv) for a case, regenerated from seeds."""
+    uv = select_rays(c["H"], c["rays"])
+    inp = S.stereo_scene(c["H"], b=c["b"], alpha=c["alpha"], baseline=c["baseline"], yaw_deg=c["yaw_deg"],
+                         uv=uv, seed=c["scene_seed"], n_view=c["n_view"], query_at_context=c["query_at_context"])
+    z = S.feature_maps(c["b"], c["n_view"], c["H"], seed=c["z_seed"], channels=c["channels"], strides=c["strides"])
+    return inp, z
+
+
+def checksum(tensors: List[torch.Tensor]) -> np.ndarray:
+    """Order-sensitive fp64 checksum of a list of tensors (sum, sum of |x|, a strided probe)."""
+    acc = []
+    for t in tensors:
+        f = t.detach().double().flatten()
+        acc += [f.sum().item(), f.abs().sum().item(), f[:: max(1, f.numel() // 7)][:7].sum().item()]
+    return np.asarray(acc, dtype=np.float64)
+
+
+def fixture_path(name: str) -> str:
+    return os.path.join(GOLDEN_DIR, name + ".npz")
