@@ -1,0 +1,192 @@
+"""Headline benchmark: rendered rays/s of the epipolar cross-attention render forward (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A *step* renders one full 256x256 query frame (65 536 rays, 64 samples per view, 2 context views = config
+"RealEstate10K pair 256x256, 64 samples") as 8 chunks of 8192 rays — the chunking of the reference's render script
+(render_realestate10k_traj.py:96).  Inputs are synthetic (seeded stereo pair, N(0,1) feature pyramid, perturbed
+default-init weights), resident in HBM before the timed region; ``get_z`` (the image encoder) is excluded on both
+sides, as in BASELINE.md.  With N GPUs every rank renders its own frame of the trajectory (weak scaling, rays are
+independent) and the rendered tiles [rgb, depth, valid] are exchanged with one RCCL all-gather per step.
+
+The JSON line also carries
+  roofline     : the dominant kernel (fp32-MFMA 1x1-conv ``linear_kernel``, the 579->576 layer) timed live with HIP
+                 events on the launch stream: algorithmic FLOP per launch / mean launch time vs the 157.3 TFLOP/s fp32
+                 matrix peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md);
+  cpu_baseline : the CPU oracle (a port of the reference forward, validated against it) timed on this host's cores
+                 over a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, P, V, CHUNK = 256, 64, 2, 8192
+FP32_MFMA_PEAK = 157.3e12
+
+
+def build_model(device):
+    from cross_attention_renderer_amd import synthetic as S
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    torch.manual_seed(0)
+    m = CrossAttentionRenderer(model="midas_vit", n_view=V, npoints=P).eval()
+    S.perturb_parameters(m, seed=0, scale=0.02)
+    m.H = m.W = H
+    return m.to(device)
+
+
+def make_frame(alpha: float, device):
+    """Input dict + feature pyramid for one query frame (the same stereo pair, query pose at ``alpha``)."""
+    from cross_attention_renderer_amd import synthetic as S
+    inp = S.stereo_scene(H, b=1, alpha=alpha, seed=5)
+    z = S.feature_maps(1, V, H, seed=1)
+    if device is not None:
+        inp = {k: {kk: vv.to(device) for kk, vv in v.items()} for k, v in inp.items()}
+        z = [t.to(device) for t in z]
+    return inp, z
+
+
+def render_frame(model, inp, z, tile):
+    """One step: 8 forward calls of 8192 rays, results packed as [rgb(3), depth, valid] per ray."""
+    uv_all = inp["query"]["uv"]
+    R = uv_all.shape[2]
+    for c0 in range(0, R, CHUNK):
+        chunk = {"context": inp["context"], "query": dict(inp["query"], uv=uv_all[:, :, c0:c0 + CHUNK])}
+        out = model(chunk, z=z)
+        tile[c0:c0 + CHUNK, 0:3] = out["rgb"][0, 0]
+        tile[c0:c0 + CHUNK, 3:4] = out["depth_ray"][0]
+        tile[c0:c0 + CHUNK, 4:5] = out["valid_mask"][0]
+    return tile
+
+
+def cpu_baseline(rays: int):
+    """The CPU oracle on a bounded sample of the same workload (same pair, weights, feature maps)."""
+    from oracle import car_oracle as O
+    model = build_model(torch.device("cpu"))
+    inp, z = make_frame(0.5, None)
+    sd = {k: v for k, v in model.state_dict().items()}
+    uv = inp["query"]["uv"][:, :, 96 * H: 96 * H + rays].contiguous()
+    inp = {"context": inp["context"], "query": dict(inp["query"], uv=uv)}
+    cfg = O.RenderConfig(n_view=V, npoints=P, H=H, W=H)
+    best = float("inf")
+    with torch.no_grad():
+        O.render_forward(sd, inp, z, cfg)                      # warm-up
+        for _ in range(2):
+            t0 = time.perf_counter()
+            O.render_forward(sd, inp, z, cfg)
+            best = min(best, time.perf_counter() - t0)
+    cores = torch.get_num_threads()
+    model_name = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": rays / best, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{rays} rays of the same 256x256x64 frame, best of 2 after warm-up, oracle/car_oracle.py on {model_name}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-rays", type=int, default=4096, help="rays in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a ROCm device: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)      # nccl == RCCL on ROCm
+
+    import __graft_entry__ as ge
+    ge.build()
+    from cross_attention_renderer_amd.engine import RenderEngine
+    from cross_attention_renderer_amd.sharding import TileGather
+
+    model = build_model(dev)
+    model._engine = RenderEngine(model)
+    # rank r renders frame r of the trajectory between the two context cameras
+    alpha = (rank + 0.5) / world
+    inp, z = make_frame(alpha, dev)
+    R = inp["query"]["uv"].shape[2]
+    tile = torch.empty(R, 5, device=dev)
+    gather = TileGather(world, R, 5, dev) if world > 1 else None
+
+    def step():
+        render_frame(model, inp, z, tile)
+        if gather is not None:
+            gather(tile)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        model._engine.timing = {}                               # per-layer HIP-event pairs from here on
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        if gather is not None:
+            gather.wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        rays_total = world * R * args.steps
+        # dominant kernel: the 579->576 layer, launched once per chunk on M = 2*V*P*8192 rows
+        ev = model._engine.timing.get("query_encode_latent", [])
+        lat = [a.elapsed_time(b_) * 1e-3 for a, b_ in ev]
+        M = CHUNK * V * P * V
+        flop = 2.0 * M * (579 + 1) * 576
+        roof = None
+        if lat:
+            mean = sum(lat) / len(lat)
+            roof = {"bound": "mfma", "kernel": "linear_kernel<9> 579->576 (query_encode_latent)", "achieved": flop / mean / 1e12,
+                    "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": flop / mean / FP32_MFMA_PEAK,
+                    "traffic": None, "launches": len(lat), "ms_per_launch": mean * 1e3}
+        line = {
+            "metric": "rendered_rays_per_sec", "value": rays_total / elapsed, "unit": "rays/s",
+            "frames_per_sec": world * args.steps / elapsed,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "256x256 query frame, 64 samples/view, 2 context views (config 2), 8 chunks x 8192 rays",
+                       "rays_per_step_per_gpu": R, "parallelism": f"ray-sharded frames x{world}, RCCL all-gather of tiles"},
+            "roofline": roof,
+            "cpu_baseline": cpu_baseline(args.cpu_rays) if args.cpu_rays > 0 else None,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""ctypes binding of ``libcar_hip.so`` (C ABI declared in ``include/car_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()``.  There is no fallback: if it cannot be loaded,
+``load()`` raises, and every wrapper turns a negative return code into ``RuntimeError(car_last_error())``.
+ctypes releases the GIL around each call; all work is enqueued on the stream the caller passes.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcar_hip.so")
+
+_P = c_void_p
+# name -> (restype, argtypes); mirrors include/car_hip.h line by line
+SIGNATURES = {
+    "car_version": (c_int, []),
+    "car_last_error": (c_char_p, []),
+    "car_device_cu_count": (c_int, []),
+    "car_pose_setup": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "car_ray_setup": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "car_sample_setup": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P,
+                                 c_int, c_int, _P]),
+    "car_gather_bilinear": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_long, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "car_linear_packed_floats": (c_size_t, [c_int, c_int]),
+    "car_linear_pack": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
+    "car_linear": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_long, c_int, _P]),
+    "car_attend": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P, c_int, c_int,
+                           _P, _P, _P, _P, _P]),
+    "car_add_ray_bias_relu": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "car_finalize": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """Loads the HIP library (once) and sets the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+            "The render path has no CPU/PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check_exports() -> None:
+    """Every symbol the header declares must be exported (used by build() and the CPU test-suite)."""
+    lib = load()
+    missing = [n for n in SIGNATURES if not hasattr(lib, n)]
+    if missing:
+        raise RuntimeError(f"libcar_hip.so lacks symbols: {missing}")
+    if lib.car_version() < 100:
+        raise RuntimeError("libcar_hip.so is older than the Python package")
+
+
+def check(code: int, what: str = "") -> None:
+    if code < 0:
+        msg = load().car_last_error()
+        raise RuntimeError(f"{what or 'libcar_hip'} failed ({code}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,149 @@
+// car_attention.hip — stage kernels for the per-ray softmax attention over the V*P epipolar samples
+// (reference models.py:532-594).
+//
+// One 256-thread workgroup per (scene, ray).  The ray's S = V*P logits (S <= 384) live in LDS; the softmax
+// is a wavefront-shuffle max/sum reduction; the value reduction sum_s w_s val[s][:] reads each value row
+// once, coalesced across the D channels.  HBM-bound: (2*dq + D)*4 bytes per sample.
+#include "car_common.h"
+#include "car_geom.h"
+
+namespace {
+
+constexpr int kMaxSamples = CAR_MAX_VIEWS * 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ qa, const float* __restrict__ qb, int dq,
+                                                     const float* __restrict__ val, int D, int b, int V, int R, int P,
+                                                     const float* __restrict__ zprev, float zprev_scale,
+                                                     float* __restrict__ w_out, float* __restrict__ z_out, int ld_z, int reps,
+                                                     const float* __restrict__ pt, const CarPose* __restrict__ poses,
+                                                     float* __restrict__ depth, int32_t* __restrict__ w_argmax) {
+    __shared__ float s_w[kMaxSamples];
+    __shared__ float s_red[8];
+    const int sc = blockIdx.x / R, r = blockIdx.x % R;
+    const int S = V * P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // sample s = v*P + p of this ray lives at row ((sc*V+v)*R + r)*P + p
+    auto row_of = [&](int s) -> long { return ((long)(sc * V + s / P) * R + r) * P + (s % P); };
+
+    // 1. logits: 16 lanes per sample, float4 per lane per step
+    const int sub = tid & 15, grp = tid >> 4;            // 16 groups of 16 lanes
+    for (int s = grp; s < S; s += 16) {
+        const long row = row_of(s);
+        const float* a = qa + row * dq;
+        const float* c = qb + row * dq;
+        float acc = 0.0f;
+        for (int k = 4 * sub; k < dq; k += 64) {
+            const float4 x = *reinterpret_cast<const float4*>(a + k);
+            const float4 y = *reinterpret_cast<const float4*>(c + k);
+            acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
+        if (sub == 0) s_w[s] = acc / 16.0f;
+    }
+    __syncthreads();
+    // 2. softmax over the S samples
+    float m = -INFINITY;
+    for (int s = tid; s < S; s += 256) m = fmaxf(m, s_w[s]);
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sum = 0.0f;
+    for (int s = tid; s < S; s += 256) { const float e = expf(s_w[s] - m); s_w[s] = e; sum += e; }
+    sum = wave_sum(sum);
+    if (lane == 0) s_red[4 + wave] = sum;
+    __syncthreads();
+    sum = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    for (int s = tid; s < S; s += 256) {
+        const float w = s_w[s] / sum;
+        s_w[s] = w;
+        w_out[row_of(s)] = w;
+    }
+    __syncthreads();
+    // 3. z = sum_s w_s val[s] (+ scale * zprev), replicated `reps` times
+    for (int d = tid; d < D; d += 256) {
+        float acc = 0.0f;
+        for (int s = 0; s < S; ++s) acc += s_w[s] * val[row_of(s) * D + d];
+        if (zprev) acc += zprev_scale * zprev[((long)sc * R + r) * D + d];
+        for (int k = 0; k < reps; ++k) z_out[((long)sc * R + r) * ld_z + (long)k * D + d] = acc;
+    }
+    // 4. depth read-out and per-view argmax (wave 0 / wave 1)
+    if (pt && wave == 0) {
+        float acc[3] = {0.0f, 0.0f, 0.0f};
+        for (int s = lane; s < S; s += 64) {
+            const float* q = pt + row_of(s) * 3;
+            for (int k = 0; k < 3; ++k) acc[k] += s_w[s] * fminf(fmaxf(q[k], -100.0f), 100.0f);
+        }
+        for (int k = 0; k < 3; ++k) acc[k] = wave_sum(acc[k]);
+        if (lane == 0) {
+            const float* Mi = poses[sc * V].inv_q;
+            const float zc = ((acc[0] * Mi[8] + acc[1] * Mi[9]) + acc[2] * Mi[10]) + Mi[11];
+            depth[(long)sc * R + r] = fminf(fmaxf(zc, 0.0f), 10.0f);
+        }
+    }
+    if (w_argmax && wave == 1) {
+        for (int v = 0; v < V; ++v) {
+            float best = -1.0f;
+            int bi = 0x7fffffff;
+            for (int p = lane; p < P; p += 64) { const float w = s_w[v * P + p]; if (w > best) { best = w; bi = p; } }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (lane == 0) w_argmax[(long)(sc * V + v) * R + r] = bi;
+        }
+    }
+}
+
+__global__ void add_ray_bias_relu_kernel(float* __restrict__ r, const float* __restrict__ u, int b, int V, int R, int P,
+                                         int C, long total4) {
+    const int c4 = C / 4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % c4);
+        const long row = idx / c4;                  // ((sc*V+v)*R + ray)*P + p
+        const long nr = row / P;
+        const int ray = (int)(nr % R);
+        const int sc = (int)(nr / R) / V;
+        float4 x = *reinterpret_cast<float4*>(r + row * C + 4 * q);
+        const float4 y = *reinterpret_cast<const float4*>(u + ((long)sc * R + ray) * C + 4 * q);
+        x.x = fmaxf(x.x + y.x, 0.0f); x.y = fmaxf(x.y + y.y, 0.0f);
+        x.z = fmaxf(x.z + y.z, 0.0f); x.w = fmaxf(x.w + y.w, 0.0f);
+        *reinterpret_cast<float4*>(r + row * C + 4 * q) = x;
+    }
+}
+
+}  // namespace
+
+extern "C" int car_attend(const float* qa, const float* qb, int dq, const float* val, int D, int b, int V, int R,
+                          int P, const float* zprev, float zprev_scale, float* w_out, float* z_out, int ld_z, int reps,
+                          const float* pt, const float* poses, float* depth, int32_t* w_argmax, void* stream) {
+    CAR_REQUIRE(qa && qb && val && w_out && z_out, "car_attend: null pointer");
+    CAR_REQUIRE(b > 0 && V > 0 && V <= CAR_MAX_VIEWS && R > 0 && P > 0 && V * P <= kMaxSamples, "car_attend: bad sizes");
+    CAR_REQUIRE(dq > 0 && dq % 4 == 0 && D > 0 && reps >= 1 && ld_z >= reps * D, "car_attend: bad widths dq=%d D=%d", dq, D);
+    CAR_REQUIRE(!pt || (poses && depth), "car_attend: pt needs poses and depth");
+    hipLaunchKernelGGL(attend_kernel, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, qa, qb, dq, val,
+                       D, b, V, R, P, zprev, zprev_scale, w_out, z_out, ld_z, reps, pt, (const CarPose*)poses, depth,
+                       w_argmax);
+    CAR_CHECK_LAUNCH("car_attend");
+    return CAR_OK;
+}
+
+extern "C" int car_add_ray_bias_relu(float* r, const float* u, int b, int V, int R, int P, int C, void* stream) {
+    CAR_REQUIRE(r && u, "car_add_ray_bias_relu: null pointer");
+    CAR_REQUIRE(b > 0 && V > 0 && R > 0 && P > 0 && C > 0 && C % 4 == 0, "car_add_ray_bias_relu: bad sizes");
+    const long total4 = (long)b * V * R * P * (C / 4);
+    const unsigned blocks = (unsigned)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(add_ray_bias_relu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, r, u, b, V, R, P, C, total4);
+    CAR_CHECK_LAUNCH("car_add_ray_bias_relu");
+    return CAR_OK;
+}

@@ -1,0 +1,28 @@
+// car_common.h — error plumbing shared by the translation units of libcar_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/car_hip.h"
+
+void car_set_error(const char* fmt, ...);
+
+#define CAR_REQUIRE(cond, ...)                         \
+    do {                                               \
+        if (!(cond)) {                                 \
+            car_set_error(__VA_ARGS__);                \
+            return CAR_E_ARG;                          \
+        }                                              \
+    } while (0)
+
+// Checks the launch itself (configuration / missing code object); never synchronises.
+#define CAR_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            car_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return CAR_E_LAUNCH;                                                      \
+        }                                                                             \
+    } while (0)
+
+static inline unsigned car_div_up(long a, long b) { return (unsigned)((a + b - 1) / b); }

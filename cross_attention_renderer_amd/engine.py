@@ -1,0 +1,292 @@
+"""Host side of the render forward: sequences the HIP stage kernels of ``libcar_hip.so`` on the current stream.
+
+``RenderEngine.render(input, z)`` is what ``CrossAttentionRenderer.forward`` runs.  Every arithmetic step of the
+reference forward (models.py:206-621) is a HIP kernel launched through the C ABI (``include/car_hip.h``); PyTorch
+is used for device memory, the stream handle and the (reference-identical) 4x4 pose algebra on the host.
+There is no CPU or eager-PyTorch fallback: tensors must live on a ROCm device and the library must load.
+
+Stage map:
+  a3 poses.pack_poses (host, torch.inverse like the reference)          a11-a13, a15, a17  car_linear (fp32 MFMA)
+  a4-a6 car_ray_setup / car_sample_setup                                  a14-a16            car_attend
+  a7/a10 car_gather_bilinear                                              a18                car_finalize
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .poses import pack_poses
+
+Tensor = torch.Tensor
+
+RELU_IN, RELU_OUT, ACCUM, NO_GLDS = 1, 2, 4, 8
+PLACE_PLAIN, PLACE_OWN, PLACE_OTHER2 = 0, 1, 2
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class PackedLinear:
+    """A linear / 1x1-conv layer re-laid out for the MFMA kernel (``car_linear_pack``)."""
+
+    def __init__(self, weight: Tensor, bias: Optional[Tensor], device, name: str = ""):
+        self.name = name
+        lib = _lib.load()
+        w = weight.detach().reshape(weight.shape[0], -1).to(device=device, dtype=torch.float32).contiguous()
+        self.N, self.K = int(w.shape[0]), int(w.shape[1])
+        bdev = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        n = lib.car_linear_packed_floats(self.K, self.N)
+        self.packed = torch.empty(n, device=device, dtype=torch.float32)
+        _lib.check(lib.car_linear_pack(_ptr(w), self.K, _ptr(bdev), self.K, self.N, _ptr(self.packed), _stream()),
+                   "car_linear_pack")
+
+
+class RenderEngine:
+    """Per-module state of the HIP path: packed weights (re-packed when the parameters change) and the
+    channel-last copies of the last feature pyramid."""
+
+    def __init__(self, module):
+        self.m = module
+        self.lib = _lib.load()
+        self._packed: Dict[str, PackedLinear] = {}
+        self._packed_key = None
+        self._maps_key = None
+        self._maps: List[Tensor] = []
+        self._steps: Dict[tuple, Tensor] = {}
+        self.linear_flags = 0          # tests may set NO_GLDS for A/B
+        self.timing = None             # bench: dict layer name -> [(start, end) HIP events on the launch stream]
+
+    # ------------------------------------------------------------------ weights
+    def _weights(self, device) -> Dict[str, PackedLinear]:
+        m = self.m
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in m.parameters())
+        if key == self._packed_key:
+            return self._packed
+        sd = {k: v for k, v in m.named_parameters()}
+        pk: Dict[str, PackedLinear] = {}
+
+        def add(name, w=None, b=None, use_bias=True):
+            W = sd[name + ".weight"] if w is None else w
+            B = (sd[name + ".bias"] if b is None else b) if use_bias else None
+            pk[name] = PackedLinear(W, B, device, name)
+
+        if m.n_view > 1 and not m.no_latent_concat:
+            add("query_encode_latent")
+            add("query_encode_latent_2")
+        elif not m.no_latent_concat:
+            add("update_val_merge")
+        for n in ("latent_value", "key_map", "key_map_2", "query_embed", "query_embed_2", "encode_latent",
+                  "query_repeat_embed_2", "phi.lin_in", "phi.lin_out"):
+            add(n)
+        wr = sd["query_repeat_embed.weight"].reshape(128, -1)
+        pk["query_repeat_embed.h"] = PackedLinear(wr[:, :128], None, device, "query_repeat_embed.h")           # z_embed half, per ray
+        pk["query_repeat_embed.g"] = PackedLinear(wr[:, 128:], sd["query_repeat_embed.bias"], device, "query_repeat_embed.g")  # local_coords half
+        for i in range(m.phi.n_blocks):
+            add(f"phi.lin_z.{i}")
+            add(f"phi.blocks.{i}.fc_0")
+            add(f"phi.blocks.{i}.fc_1")
+        self._packed, self._packed_key = pk, key
+        return pk
+
+    # ------------------------------------------------------------------ feature maps
+    def _channel_last(self, z: List[Tensor]) -> List[Tensor]:
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in z)
+        if key != self._maps_key:
+            self._maps = [t.detach().float().permute(0, 2, 3, 1).contiguous() for t in z]
+            self._maps_key = key
+        return self._maps
+
+    def _linspace(self, a: float, b_: float, P: int, device) -> Tensor:
+        k = (a, b_, P, str(device))
+        if k not in self._steps:
+            self._steps[k] = torch.linspace(a, b_, P).to(device)      # CPU linspace, like the reference's values
+        return self._steps[k]
+
+    # ------------------------------------------------------------------ kernels
+    def linear(self, x: Tensor, ldx: int, layer: PackedLinear, y: Tensor, ldy: int, M: int, flags: int = 0):
+        ev = None
+        if self.timing is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        _lib.check(self.lib.car_linear(_ptr(x), ldx, _ptr(layer.packed), layer.K, layer.N, _ptr(y), ldy, M,
+                                       flags | self.linear_flags, _stream()), "car_linear")
+        if ev is not None:
+            ev[1].record()
+            self.timing.setdefault(layer.name, []).append(ev)
+
+    def gather(self, maps: List[Tensor], grid: Tensor, pts: int, mode: int, place: int, V: int, out: Tensor,
+               ld_out: int, col_out: int):
+        L = len(maps)
+        ptrs = (ctypes.c_void_p * L)(*[m.data_ptr() for m in maps])
+        cs = (ctypes.c_int * L)(*[m.shape[3] for m in maps])
+        hs = (ctypes.c_int * L)(*[m.shape[1] for m in maps])
+        ws = (ctypes.c_int * L)(*[m.shape[2] for m in maps])
+        _lib.check(self.lib.car_gather_bilinear(ptrs, cs, hs, ws, L, maps[0].shape[0], _ptr(grid), pts, mode, place, V,
+                                                _ptr(out), ld_out, col_out, _stream()), "car_gather_bilinear")
+
+    # ------------------------------------------------------------------ the forward pass
+    @torch.no_grad()
+    def render(self, inp, z: List[Tensor], debug: bool = False) -> Dict[str, Tensor]:
+        m, lib = self.m, self.lib
+        ctx, qry = inp["context"], inp["query"]
+        uv_in = qry["uv"]
+        dev = uv_in.device
+        if dev.type != "cuda":
+            raise RuntimeError("CrossAttentionRenderer.forward runs on the HIP engine only: move the model, the input "
+                               "dict and z to a ROCm device (there is no CPU fallback)")
+        b, V = ctx["rgb"].shape[:2]
+        n_qry, R = uv_in.shape[1:3]
+        if n_qry != 1:
+            raise ValueError("forward supports one query view per scene (reference models.py:213, 619)")
+        if V != m.n_view:
+            raise ValueError(f"input has {V} context views, module was built with n_view={m.n_view}")
+        if V == 3 and not m.no_latent_concat:
+            raise NotImplementedError("n_view=3 with latent concat is not built yet on the HIP engine")
+        P, H, W = m.npoints, m.H, m.W
+        n, S = b * V, b * V * R * P
+        st = _stream()
+        f32 = dict(device=dev, dtype=torch.float32)
+        pk = self._weights(dev)
+        maps = self._channel_last(z)
+        C = sum(t.shape[3] for t in maps)
+        Dl = m.latent_dim
+
+        # a3: pose algebra on the host, exactly the reference's torch calls
+        poses = pack_poses(inp, H).to(dev, non_blocking=True)
+        uv = uv_in.detach().reshape(b, R, 2).float().contiguous()
+        steps = self._linspace(0.1, 10.0, P, dev) if m.no_sample else self._linspace(0.0, 1.0, P, dev)
+
+        # a4-a6: rays
+        rays = torch.empty(n, R, 12, **f32)
+        coords9 = torch.empty(n, R, 9, **f32)
+        ld_phi = _round_up(9 * V, 4)
+        phi_x = torch.zeros(b * R, ld_phi, **f32)
+        _lib.check(lib.car_ray_setup(_ptr(poses), _ptr(uv), b, V, R, H, W, P, int(m.no_sample), _ptr(steps),
+                                     _ptr(rays), _ptr(coords9), _ptr(phi_x), ld_phi, st), "car_ray_setup")
+
+        # a6, a8, a9, a13: samples
+        pixel_val = torch.empty(n, R, P, 2, **f32)
+        pt = torch.empty(n, R, P, 3, **f32)
+        g = torch.empty(S, 16, **f32)
+        concat2 = (V == 2 and not m.no_latent_concat)
+        single = (V == 1 and not m.no_latent_concat)
+        grid_in = torch.empty(n, R, P, V, 2, **f32) if concat2 else None
+        x1 = None
+        if concat2:
+            ld1 = _round_up(C + 3, 32)
+            x1 = torch.empty(S * V, ld1, **f32)
+        elif single:
+            ld1 = _round_up(C + 6, 32)
+            x1 = torch.empty(S, ld1, **f32)
+        _lib.check(lib.car_sample_setup(_ptr(poses), _ptr(rays), _ptr(steps), b, V, R, P, H, W, int(m.no_sample),
+                                        _ptr(pixel_val), _ptr(pt), _ptr(g), _ptr(grid_in), _ptr(x1),
+                                        ld1 if x1 is not None else 0, C, st), "car_sample_setup")
+
+        # a7, a9-a11: per-sample features e
+        if concat2:
+            self.gather(maps, pixel_val, R * P, 0, PLACE_OWN, V, x1, ld1, 0)
+            gi = grid_in.view(b, V, R, P, V, 2)
+            # pixel_val_stack (models.py:316): map (b, s) is sampled where the *other* line's points land in view s
+            grid_other = torch.stack([gi[:, 1, :, :, 0], gi[:, 0, :, :, 1]], dim=1).contiguous()
+            self.gather(maps, grid_other, R * P, 1, PLACE_OTHER2, V, x1, ld1, 0)
+            h1 = torch.empty(S * V, C, **f32)
+            self.linear(x1, ld1, pk["query_encode_latent"], h1, C, S * V, RELU_OUT)
+            e = torch.empty(S, V * (C // 2), **f32)
+            self.linear(h1, C, pk["query_encode_latent_2"], e, C // 2, S * V)
+            del h1
+            Ce = V * (C // 2)
+        elif single:
+            self.gather(maps, pixel_val, R * P, 0, PLACE_PLAIN, V, x1, ld1, 0)
+            e = torch.empty(S, C, **f32)
+            self.linear(x1, ld1, pk["update_val_merge"], e, C, S)
+            Ce = C
+        else:
+            e = torch.empty(S, C, **f32)
+            self.gather(maps, pixel_val, R * P, 0, PLACE_PLAIN, V, e, C, 0)
+            Ce = C
+        del x1
+
+        # a12: values and keys;  a13: geometric query
+        val = torch.empty(S, Dl, **f32)
+        self.linear(e, Ce, pk["latent_value"], val, Dl, S)
+        k1 = torch.empty(S, 128, **f32)
+        self.linear(e, Ce, pk["key_map"], k1, 128, S, RELU_OUT)
+        key = torch.empty(S, 128, **f32)
+        self.linear(k1, 128, pk["key_map_2"], key, 128, S)
+        self.linear(g, 16, pk["query_embed"], k1, 128, S, RELU_OUT)
+        q = torch.empty(S, 128, **f32)
+        self.linear(k1, 128, pk["query_embed_2"], q, 128, S)
+
+        # a14 + a16: attention round 1, depth read-out
+        at_wt = torch.empty(n, R, P, **f32)
+        depth = torch.empty(b, R, **f32)
+        amax = torch.empty(n, R, dtype=torch.int32, device=dev)
+        rep = m.repeat_attention
+        z1 = torch.empty(b * R, Dl if rep else V * Dl, **f32)
+        _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(val), Dl, b, V, R, P, None, 0.0, _ptr(at_wt), _ptr(z1),
+                                  z1.shape[1], 1 if rep else V, _ptr(pt), _ptr(poses), _ptr(depth), _ptr(amax), st),
+                   "car_attend")
+        at_wt2 = None
+        if rep:
+            # a15: second round; the z_embed half of query_repeat_embed is per ray, the local_coords half per sample
+            hb = torch.empty(b * R, 128, **f32)
+            self.linear(z1, Dl, pk["encode_latent"], hb, 128, b * R)
+            uh = torch.empty(b * R, 128, **f32)
+            self.linear(hb, 128, pk["query_repeat_embed.h"], uh, 128, b * R)
+            self.linear(g, 16, pk["query_repeat_embed.g"], k1, 128, S)
+            _lib.check(lib.car_add_ray_bias_relu(_ptr(k1), _ptr(uh), b, V, R, P, 128, st), "car_add_ray_bias_relu")
+            self.linear(k1, 128, pk["query_repeat_embed_2"], key, 128, S)
+            at_wt2 = torch.empty(n, R, P, **f32)
+            zrep = torch.empty(b * R, V * Dl, **f32)
+            _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(val), Dl, b, V, R, P, _ptr(z1), float(V), _ptr(at_wt2),
+                                      _ptr(zrep), V * Dl, V, None, None, None, None, st), "car_attend")
+        else:
+            zrep = z1
+
+        # a17: light-field decoder
+        hid = m.phi.d_hidden
+        x = torch.empty(b * R, hid, **f32)
+        net = torch.empty(b * R, hid, **f32)
+        self.linear(phi_x, ld_phi, pk["phi.lin_in"], x, hid, b * R)
+        for i in range(m.phi.n_blocks):
+            self.linear(zrep, V * Dl, pk[f"phi.lin_z.{i}"], x, hid, b * R, ACCUM)
+            self.linear(x, hid, pk[f"phi.blocks.{i}.fc_0"], net, hid, b * R, RELU_IN)
+            self.linear(net, hid, pk[f"phi.blocks.{i}.fc_1"], x, hid, b * R, RELU_IN | ACCUM)
+        out3 = torch.empty(b * R, 4, **f32)
+        self.linear(x, hid, pk["phi.lin_out"], out3, 4, b * R, RELU_IN)
+
+        # a18: valid mask, white background, output dict
+        rgb = torch.empty(b, R, 3, **f32)
+        valid = torch.empty(b, R, **f32)
+        _lib.check(lib.car_finalize(_ptr(rays), _ptr(out3), 4, b, V, R, _ptr(rgb), _ptr(valid), st), "car_finalize")
+
+        out = {
+            "rgb": rgb.view(b, n_qry, R, 3),
+            "valid_mask": valid[..., None],
+            "depth_ray": depth[..., None],
+            "at_wt": at_wt,
+            "at_wts": [at_wt],
+            "at_wt_max": amax.long()[..., None],
+            "coords": coords9,
+            "uv": qry["uv"],
+            # the reference returns pixel_val on the CPU (models.py:570), forcing a device sync on every call; here it
+            # stays on the device unless debug is set
+            "pixel_val": pixel_val.cpu() if debug else pixel_val,
+            "z": z,
+        }
+        if debug:
+            out["stages"] = {"rays": rays, "pt": pt, "local_coords": g.view(n, R, P, 16), "interp_val": e.view(n, R, P, Ce),
+                             "z_final": zrep[:, :Dl].reshape(b, R, Dl), "at_wt2": at_wt2, "poses": poses}
+        return out

@@ -1,0 +1,131 @@
+/* car_hip.h — C ABI of libcar_hip.so, the MI355X (gfx950) implementation of the epipolar cross-attention
+ * render forward of yilundu/cross_attention_renderer.
+ *
+ * What it replaces.  The reference has NO native/FFI boundary on this path: the whole of
+ * `CrossAttentionRenderer.forward(input, z=z)` (reference models.py:190-626) is Python calling stock torch
+ * ops.  This header therefore does not mirror an existing FFI; it is the boundary this repo introduces
+ * underneath the Python class.  Each entry point names the reference code it stands for.
+ *
+ * Conventions
+ *  - Every pointer is a caller-owned DEVICE pointer (e.g. torch.Tensor.data_ptr()) unless marked host;
+ *    fp32, contiguous, 16-byte aligned.  The library allocates nothing, frees nothing and keeps no
+ *    reference after the call returns.
+ *  - All work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = default
+ *    stream).  No call synchronises the device.
+ *  - Return value: 0 on success, a negative CAR_E_* code on failure; `car_last_error()` then returns a
+ *    thread-local human-readable message.  Nothing throws or aborts.
+ *  - Index conventions: b scenes, V context views, n = b*V + v "scene-views", R rays per scene,
+ *    P samples per ray and view.  Feature maps are channel-last (NHWC) per pyramid level.
+ */
+#ifndef CAR_HIP_H
+#define CAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAR_VERSION 100           /* 0.1.0 */
+
+#define CAR_OK            0
+#define CAR_E_ARG        (-1)     /* invalid argument (null pointer, bad size, unsupported shape) */
+#define CAR_E_LAUNCH     (-2)     /* HIP launch / runtime error */
+#define CAR_E_NODEVICE   (-3)     /* no gfx950 device visible */
+
+#define CAR_POSE_FLOATS   96      /* sizeof(struct CarPose)/4, see csrc/car_geom.h */
+#define CAR_RAY_FLOATS    12      /* sizeof(struct CarRay)/4 */
+#define CAR_G_DIM         16      /* channels of the geometric query (models.py:528) */
+#define CAR_MAX_VIEWS     3
+#define CAR_MAX_LEVELS    4
+
+/* flags of car_linear */
+#define CAR_LIN_RELU_IN   1       /* apply ReLU to the input rows on load            (F.relu(x) feeding a conv) */
+#define CAR_LIN_RELU_OUT  2       /* apply ReLU to the result                                                     */
+#define CAR_LIN_ACCUM     4       /* Y += result instead of Y = result                 (x = x + lin_z(z), x + dx) */
+#define CAR_LIN_NO_GLDS   8       /* stage weights through registers instead of global_load_lds (debug/A-B)       */
+
+/* gather placement patterns (which output row a sampled point lands in), see car_gather_bilinear */
+#define CAR_PLACE_PLAIN   0
+#define CAR_PLACE_OWN     1
+#define CAR_PLACE_OTHER2  2
+
+int car_version(void);
+const char* car_last_error(void);
+
+/* Number of compute units of the current device (host query; used by tests/bench to size launches). */
+int car_device_cu_count(void);
+
+/* ---- a3: pose algebra (models.py:207-211, 226-228, 285-286; geometry.py:404) ---------------------------
+ * c2w_ctx [b,V,4,4], c2w_q [b,4,4], K_ctx [b,V,4,4], K_q [b,4,4]  ->  poses [b*V, CAR_POSE_FLOATS].
+ * Inverses are computed by partial-pivot Gauss-Jordan in fp64 (the reference uses LAPACK in fp32; results
+ * agree to a few ulp).  Hosts that want the reference's exact matrices may fill `poses` themselves. */
+int car_pose_setup(const float* c2w_ctx, const float* c2w_q, const float* K_ctx, const float* K_q,
+                   int b, int V, int H, float* poses, void* stream);
+
+/* ---- a4-a6: query rays and their epipolar segments (geometry.py:236-245; epipolar.py:175-253; models.py:213-258)
+ * uv [b,R,2] pixel coords (x=col, y=row).  rays [b*V,R,CAR_RAY_FLOATS] (struct CarRay).
+ * no_sample != 0 selects the uniform-depth variant (geometry.py:165-187): `depth_steps` [P] = linspace(0.1,10,P).
+ * Optional outputs (may be NULL): coords9 [b*V,R,9] = [d, o x d, o]; phi_x [b,R,ld_phi] whose first V*9 columns are
+ * the decoder's ray input (models.py:597-602), ld_phi >= 9*V. */
+int car_ray_setup(const float* poses, const float* uv, int b, int V, int R, int H, int W, int P,
+                  int no_sample, const float* depth_steps, float* rays, float* coords9, float* phi_x, int ld_phi,
+                  void* stream);
+
+/* ---- a6, a8, a9, a13: per-sample geometry (models.py:261-331, 494-528; geometry.py:98-162, 313-324, 374-393)
+ * steps [P]: linspace(0,1,P) (or the depth steps when no_sample).  Outputs, each optional (NULL to skip):
+ *   pixel_val [b*V,R,P,2]   grid_sample coordinates of the sample in its own view
+ *   pt        [b*V,R,P,3]   closest point on the query ray (fp64 Pluecker intersection, stored fp32)
+ *   g         [b*V,R,P,16]  local_coords
+ *   grid_in   [b*V,R,P,V,2] where the point lands in every context view s
+ *   xenc/ld_xenc/col_xenc   tanh(nan_to_num(T_s pt)/5) written to xenc[((n*R+r)*P+p)*V + s][col..col+3)
+ *                           (the 3 point channels of models.py:330-338); with V == 1: tanh(pt/5), tanh(pt/100)
+ *                           at [col..col+6) (models.py:483). */
+int car_sample_setup(const float* poses, const float* rays, const float* steps, int b, int V, int R, int P,
+                     int H, int W, int no_sample, float* pixel_val, float* pt, float* g, float* grid_in,
+                     float* xenc, int ld_xenc, int col_xenc, void* stream);
+
+/* ---- a7/a10: F.grid_sample(bilinear, align_corners=False) over a channel-last pyramid (models.py:278, 317)
+ * maps[l] : device pointer to level l, [n_maps, Hl, Wl, Cl] (NHWC); level_c/h/w host arrays of n_levels ints.
+ * grid [n_maps, pts, 2].  mode 0 = border, 1 = zeros.  Point i of map m writes sum(Cl) channels to row
+ *   PLAIN : m*pts + i
+ *   OWN   : (m*pts + i)*V + (m % V)                              (own-view features, source slot = own view)
+ *   OTHER2: ((b*2 + (1-s))*pts + i)*2 + s  with m = b*2+s         (V == 2: features of view s for the other line)
+ * of `out` (row stride ld_out floats) starting at column col_out. */
+int car_gather_bilinear(const float* const* maps, const int* level_c, const int* level_h, const int* level_w,
+                        int n_levels, int n_maps, const float* grid, long pts, int mode, int place, int V,
+                        float* out, int ld_out, int col_out, void* stream);
+
+/* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
+ *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).
+ * Weights are re-laid out once into the MFMA operand order by car_linear_pack (bias folded in as column K). */
+size_t car_linear_packed_floats(int K, int N);
+int car_linear_pack(const float* W, int ldw, const float* bias, int K, int N, float* packed, void* stream);
+int car_linear(const float* X, int ldx, const float* packed, int K, int N, float* Y, int ldy, long M, int flags,
+               void* stream);
+
+/* ---- a14-a16: per-ray softmax attention over the V*P samples (models.py:532-594)
+ * qa, qb [b*V,R,P,dq] (row stride dq): logit = <qa,qb>/16.  val [b*V,R,P,D].
+ * w_out [b*V,R,P] softmax weights (ordered [view 1's P, view 2's P] per ray).
+ * z_out [b,R,ld_z]: sum_s w_s val_s (+ zprev_scale * zprev[b,R,D] if zprev != NULL), written `reps` times
+ *   side by side (the per-view replication of models.py:541, 565, 605-606).
+ * If pt != NULL also: depth [b,R] = clamp((inv_q . sum_s w_s clamp(pt_s,+-100)).z, 0, 10) and
+ *   w_argmax [b*V,R] (int32) = argmax_p w. */
+int car_attend(const float* qa, const float* qb, int dq, const float* val, int D, int b, int V, int R, int P,
+               const float* zprev, float zprev_scale, float* w_out, float* z_out, int ld_z, int reps,
+               const float* pt, const float* poses, float* depth, int32_t* w_argmax, void* stream);
+
+/* r[row, c] = relu(r[row, c] + u[ray(row), c]) with ray(row) = scene b, ray r of the sample row (models.py:549-553:
+ * the z_embed half of query_repeat_embed is constant along the samples of a ray). r [b*V,R,P,C], u [b,R,C]. */
+int car_add_ray_bias_relu(float* r, const float* u, int b, int V, int R, int P, int C, void* stream);
+
+/* ---- a18: valid mask and white background (models.py:614-617).
+ * rays [b*V,R,CAR_RAY_FLOATS]; rgb_in [b,R,ld_in] (first 3 columns used) -> rgb [b,R,3], valid [b,R]. */
+int car_finalize(const float* rays, const float* rgb_in, int ld_in, int b, int V, int R, float* rgb, float* valid,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAR_HIP_H */

@@ -1,0 +1,76 @@
+"""Shared helpers of the ``-m gpu`` parity tests: run the HIP path (through the module / C ABI) and the CPU oracle on
+the same seeded inputs and return both.  Test infrastructure; the oracle is only ever the checker."""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict
+
+import numpy as np
+import torch
+
+import cases as C
+from golden_util import load_case, rel_err
+from oracle import car_oracle as O
+
+
+def oracle_cfg(c) -> O.RenderConfig:
+    return O.RenderConfig(n_view=c["n_view"], npoints=c["P"], no_sample=c["no_sample"],
+                          no_latent_concat=c["no_latent_concat"], repeat_attention=c["repeat_attention"],
+                          H=c["H"], W=c["H"])
+
+
+def build_module(c, sd, device):
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    m = CrossAttentionRenderer(model=c["model"], n_view=c["n_view"], npoints=c["P"], no_sample=c["no_sample"],
+                               no_latent_concat=c["no_latent_concat"], repeat_attention=c["repeat_attention"]).eval()
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and not missing.missing_keys, missing
+    m.H = m.W = c["H"]
+    return m.to(device)
+
+
+def to_device(inp, device):
+    return {k: {kk: vv.to(device) for kk, vv in v.items()} for k, v in inp.items()}
+
+
+def run_case(name: str, device="cuda:0", debug=True, linear_flags=0):
+    """Returns (config, fixture, oracle output dict (CPU), HIP output dict (tensors moved to CPU))."""
+    c, inp, z, sd, fx = load_case(name)
+    with torch.no_grad():
+        ora = O.render_forward(sd, inp, z, oracle_cfg(c), debug=True)
+    m = build_module(c, sd, device)
+    if linear_flags:
+        from cross_attention_renderer_amd.engine import RenderEngine
+        m._engine = RenderEngine(m)
+        m._engine.linear_flags = linear_flags
+    with torch.no_grad():
+        out = m(to_device(inp, device), z=[t.to(device) for t in z], debug=debug)
+    torch.cuda.synchronize()
+
+    def cpu(v):
+        if isinstance(v, torch.Tensor):
+            return v.detach().cpu()
+        if isinstance(v, dict):
+            return {k: cpu(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [cpu(x) for x in v]
+        return v
+    return c, fx, ora, cpu(out)
+
+
+def err_stats(a, b) -> Dict[str, float]:
+    """Relative error |a-b|/max(1,|b|): max, and the fraction of elements above 1e-4 / 1e-3."""
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    e = (a - b).abs() / b.abs().clamp_min(1.0)
+    e = torch.where(torch.isfinite(e), e, torch.full_like(e, float("inf")))
+    return {"max": e.max().item(), "f1e-4": (e > 1e-4).double().mean().item(), "f1e-3": (e > 1e-3).double().mean().item()}
+
+
+def ray_err(a, b, ray_dim: int):
+    """Per-ray max relative error (reduces every dim except ``ray_dim`` and the leading batch dims before it)."""
+    a = torch.as_tensor(np.asarray(a)).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    e = (a - b).abs() / b.abs().clamp_min(1.0)
+    dims = [d for d in range(e.dim()) if d > ray_dim]
+    return e.amax(dim=dims) if dims else e

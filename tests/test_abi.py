@@ -1,0 +1,78 @@
+"""CPU checks of the C-ABI boundary: the library builds, loads and exports every symbol of include/car_hip.h,
+argument validation returns error codes (never aborts), and the product package never touches the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from cross_attention_renderer_amd import _lib
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from cross_attention_renderer_amd import _lib
+    header = open(os.path.join(ROOT, "include", "car_hip.h")).read()
+    declared = set(re.findall(r"\b(car_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.car_version() == 100
+
+
+def test_bad_arguments_return_codes_not_crashes(lib):
+    from cross_attention_renderer_amd import _lib
+    assert lib.car_linear(None, 4, None, 4, 4, None, 4, 1, 0, None) == -1
+    assert b"null pointer" in lib.car_last_error()
+    assert lib.car_ray_setup(None, None, 1, 2, 1, 8, 8, 4, 0, None, None, None, None, 0, None) == -1
+    assert lib.car_linear_packed_floats(0, 4) == 0
+    # K=579 (+1 bias column) -> 19 chunks of 32; N=576 -> 18 tiles; 1024 floats per (chunk, tile)
+    assert lib.car_linear_packed_floats(579, 576) == 19 * 18 * 1024
+    with pytest.raises(RuntimeError):
+        _lib.check(-1, "probe")
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "cross_attention_renderer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S), f"{f} mentions the oracle"
+
+
+def test_forward_refuses_cpu_tensors():
+    """No CPU fallback: the render path fails loudly off-device."""
+    import torch
+    from cross_attention_renderer_amd import synthetic as S
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    m = CrossAttentionRenderer(model="tiny", n_view=2, npoints=4).eval()
+    inp = S.stereo_scene(16, b=1, uv=S.pixel_grid(16, 16)[:8].contiguous())
+    z = S.feature_maps(1, 2, 16, channels=(16, 16), strides=(2, 1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(inp, z=z)
+
+
+def test_module_state_dict_matches_reference_table():
+    """Parameter names/shapes of SURVEY.md §8b (checked against the real reference in make_golden.py)."""
+    from cross_attention_renderer_amd.models import renderer_param_shapes
+    t = renderer_param_shapes("midas_vit", n_view=2)
+    assert t["query_encode_latent.weight"] == (576, 579, 1, 1)
+    assert t["query_encode_latent_2.weight"] == (288, 576, 1, 1)
+    assert t["update_val_merge.weight"] == (288, 582, 1, 1)
+    assert t["latent_value.weight"] == (288, 576, 1, 1)
+    assert t["key_map.weight"] == (128, 576, 1, 1)
+    assert t["query_repeat_embed.weight"] == (128, 144, 1, 1)
+    assert t["latent_avg_repeat_query.weight"] == (128, 153, 1, 1)
+    assert t["encode_latent.weight"] == (128, 288, 1)
+    assert t["phi.lin_in.weight"] == (128, 18) and t["phi.lin_z.2.weight"] == (128, 576)
+    assert t["conv_map.weight"] == (64, 3, 7, 7)
+    assert sum(int(__import__("math").prod(s)) for s in t.values()) == 1457955

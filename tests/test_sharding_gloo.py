@@ -1,0 +1,72 @@
+"""world_size-2 ``gloo`` tests (CPU) of the multi-GPU ray-sharding path: band partitioning, the padded all-gather that
+reassembles a frame, and the overlapped tile gather used by bench.py.  The render itself is replaced by a deterministic
+per-ray function so the test needs no GPU; rays are independent, so this is exactly what sharding relies on."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cross_attention_renderer_amd import sharding as Sh
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fake_render(uv):
+    """(b,1,R,2) -> forward()-shaped dict whose values depend only on the ray itself."""
+    x, y = uv[:, 0, :, 0], uv[:, 0, :, 1]
+    rgb = torch.stack([x * 0.01, y * 0.02, x + y], dim=-1)[:, None]
+    return {"rgb": rgb, "depth_ray": (x - y)[..., None], "valid_mask": ((x + y) % 2)[..., None]}
+
+
+def _worker(rank, world, port, n_rays, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(0)
+        uv = torch.rand(2, 1, n_rays, 2, generator=g) * 100
+        inp = {"context": {"rgb": torch.zeros(2, 2, 4, 4, 3)}, "query": {"uv": uv, "cam2world": torch.eye(4)}}
+        shard, (s, e) = Sh.shard_query(inp, rank, world)
+        assert inp["query"]["uv"].shape[2] == n_rays, "caller's dict was mutated"
+        tile = Sh.pack_tile(_fake_render(shard["query"]["uv"]))
+        full = Sh.gather_rays(tile, n_rays)
+        want = Sh.pack_tile(_fake_render(uv))
+        assert torch.equal(full, want), "sharded render differs from the unsharded one"
+        # overlapped equal-size gather (bench path), twice to exercise buffer reuse
+        tg = Sh.TileGather(world, 16, 5, "cpu")
+        for it in range(2):
+            t = torch.full((16, 5), float(rank * 10 + it))
+            tg(t)
+            t.zero_()                                   # the caller may overwrite its tile right away
+            out = tg.wait()
+            for r in range(world):
+                assert (out[r] == r * 10 + it).all()
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rays", [64, 65, 7])
+def test_ray_sharding_world2(n_rays):
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, port, n_rays, ret), nprocs=world, join=True)
+        assert dict(ret) == {0: 1, 1: 1}
+
+
+def test_ray_bands_partition_exactly():
+    for n in (1, 7, 64, 65536, 147456):
+        for w in (1, 2, 3, 4, 8):
+            bands = [Sh.ray_band(n, r, w) for r in range(w)]
+            assert bands[0][0] == 0 and bands[-1][1] == n
+            assert all(bands[i][1] == bands[i + 1][0] for i in range(w - 1))
+            sizes = [e - s for s, e in bands]
+            assert max(sizes) - min(sizes) <= 1
