@@ -67,6 +67,7 @@ class RenderEngine:
         self._steps: Dict[tuple, Tensor] = {}
         self.linear_flags = 0          # tests may set NO_GLDS for A/B
         self.timing = None             # bench: dict layer name -> [(start, end) HIP events on the launch stream]
+        self.pose_records = None       # tests: (b*V, 96) CarPose records to use instead of the host pose algebra
 
     # ------------------------------------------------------------------ weights
     def _weights(self, device) -> Dict[str, PackedLinear]:
@@ -164,7 +165,10 @@ class RenderEngine:
         Dl = m.latent_dim
 
         # a3: pose algebra on the host, exactly the reference's torch calls
-        poses = pack_poses(inp, H).to(dev, non_blocking=True)
+        poses = (pack_poses(inp, H) if self.pose_records is None else self.pose_records.float().contiguous())
+        if tuple(poses.shape) != (n, 96):
+            raise ValueError(f"pose records must have shape ({n}, 96)")
+        poses = poses.to(dev, non_blocking=True)
         uv = uv_in.detach().reshape(b, R, 2).float().contiguous()
         steps = self._linspace(0.1, 10.0, P, dev) if m.no_sample else self._linspace(0.0, 1.0, P, dev)
 

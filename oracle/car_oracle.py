@@ -319,14 +319,27 @@ def resnet_fc(params: Mapping[str, Tensor], zx: Tensor, d_latent: int, prefix: s
 # the forward pass
 # --------------------------------------------------------------------------------------
 
+def _rows_to_4x4(rows12: Tensor) -> Tensor:
+    """(...,12) top three rows of a rigid/affine 4x4 -> (...,4,4)."""
+    top = rows12.reshape(*rows12.shape[:-1], 3, 4)
+    last = torch.tensor([0.0, 0.0, 0.0, 1.0]).expand(*top.shape[:-2], 1, 4)
+    return torch.cat([top, last], dim=-2)
+
+
 def render_forward(params: Mapping[str, Tensor], inp: Mapping, z: List[Tensor], cfg: RenderConfig,
-                   debug: bool = False) -> Dict[str, Tensor]:
+                   debug: bool = False, poses96: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """Restates ``CrossAttentionRenderer.forward(input, z=z)`` (models.py:190-626) on CPU.
 
     ``params``: the module's state_dict (names of SURVEY.md §8b).  ``inp``: the reference input dict
     (``context``: rgb (b,V,H,W,3) [shape only], cam2world (b,V,4,4), intrinsics (b,V,4,4);
     ``query``: cam2world (b,1,4,4), intrinsics (b,1,4,4), uv (b,1,R,2)).  Returns the reference's output
     dict; with ``debug`` also the per-stage intermediates under ``"stages"``.
+
+    ``poses96`` (b*V, 96), optional: the relative-pose matrices (``struct CarPose`` layout, see
+    ``cross_attention_renderer_amd/poses.py``) to use instead of recomputing them with ``torch.inverse``.
+    ``torch.inverse`` is LAPACK, whose last-ulp results depend on the host CPU; the fp64 intersection
+    downstream amplifies such differences on ill-conditioned samples, so the golden fixtures carry the
+    matrices the reference itself computed and the replay tests pass them in here.
     """
     ctx, qry = inp["context"], inp["query"]
     c2w_ctx, K_ctx = ctx["cam2world"].float(), ctx["intrinsics"].float()
@@ -339,9 +352,18 @@ def render_forward(params: Mapping[str, Tensor], inp: Mapping, z: List[Tensor], 
     st: Dict[str, Tensor] = {}
 
     # a3 pose algebra (models.py:207-211)
-    inv_ctx = torch.inverse(c2w_ctx)
-    ctx_rel = torch.matmul(inv_ctx, c2w_ctx)                  # ~identity, (b,V,4,4)
-    q_rel = torch.matmul(inv_ctx, c2w_q)                      # (b,V,4,4)
+    if poses96 is None:
+        inv_ctx = torch.inverse(c2w_ctx)
+        ctx_rel = torch.matmul(inv_ctx, c2w_ctx)              # ~identity, (b,V,4,4)
+        q_rel = torch.matmul(inv_ctx, c2w_q)                  # (b,V,4,4)
+        T_rel = [torch.matmul(torch.inverse(c2w_ctx[:, s:s + 1]), c2w_ctx) for s in range(V)]
+        inv_q = torch.inverse(c2w_q[:, 0])
+    else:
+        pz = poses96.reshape(b, V, 96).float()
+        q_rel = _rows_to_4x4(pz[..., 0:12])
+        ctx_rel = _rows_to_4x4(pz[..., 12:24])
+        T_rel = [_rows_to_4x4(pz[..., 24 + 12 * s:36 + 12 * s]) for s in range(V)]
+        inv_q = _rows_to_4x4(pz[:, 0, 77:89])
 
     # a4 query rays in every context frame (models.py:213-214)
     lf = pluecker_rays(q_rel.flatten(0, 1), uv.expand(-1, V, -1, -1).flatten(0, 1),
@@ -386,7 +408,7 @@ def render_forward(params: Mapping[str, Tensor], inp: Mapping, z: List[Tensor], 
         # a9-a11 cross-view exchange (models.py:285-344)
         ptv = pt.reshape(b, V, R, P, 3)
         # T_s[c] maps a point from context frame c into context frame s
-        T = [torch.matmul(torch.inverse(c2w_ctx[:, s:s + 1]), c2w_ctx) for s in range(V)]   # each (b,V,4,4)
+        T = T_rel                                                                            # each (b,V,4,4)
         pts_in = [_apply_4x4(T[s][:, :, None, None], ptv) for s in range(V)]                # [s] -> (b,V,R,P,3)
         # where the points of the *other* line land in each view: index v = map that is sampled
         other = [1, 0]
@@ -462,7 +484,6 @@ def render_forward(params: Mapping[str, Tensor], inp: Mapping, z: List[Tensor], 
     # a16 depth read-out from the round-1 weights (models.py:573-594)
     pt_mean = (at_wt[..., None] * pt.clamp(-100, 100)).sum(dim=-2)          # (bV,R,3)
     pt_mean = pt_mean.reshape(b, V, R, 3).sum(dim=1)
-    inv_q = torch.inverse(c2w_q[:, 0])
     depth_ray = _apply_4x4(inv_q[:, None], pt_mean)[..., 2].clamp(0, 10)[..., None]
     at_wt_max = at_wt.argmax(dim=-1)[..., None]
 

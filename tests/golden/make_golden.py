@@ -121,7 +121,13 @@ def run_case(name: str) -> None:
     assert worst["valid_mask"] == 0.0 and worst["at_wt_max"] == 0.0, "discrete outputs differ"
     assert max(worst.values()) < 2e-5, "oracle does not reproduce the reference"
 
+    from cross_attention_renderer_amd.poses import pack_poses
+    poses = pack_poses(inp, c["H"])
+    with torch.no_grad():   # the pose records must reproduce the reference run they are stored beside
+        chk = O.render_forward(sd, inp, z, cfg, poses96=poses)
+    assert torch.equal(chk["pixel_val"], ref_out["pixel_val"]) and torch.equal(chk["coords"], ref_out["coords"])
     payload = {
+        "poses": poses.numpy(),
         "ctx_cam2world": inp["context"]["cam2world"].numpy(),
         "ctx_intrinsics": inp["context"]["intrinsics"].numpy(),
         "qry_cam2world": inp["query"]["cam2world"].numpy(),

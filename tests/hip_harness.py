@@ -33,16 +33,20 @@ def to_device(inp, device):
     return {k: {kk: vv.to(device) for kk, vv in v.items()} for k, v in inp.items()}
 
 
-def run_case(name: str, device="cuda:0", debug=True, linear_flags=0):
-    """Returns (config, fixture, oracle output dict (CPU), HIP output dict (tensors moved to CPU))."""
+def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_poses=False):
+    """Returns (config, fixture, oracle output dict (CPU), HIP output dict (tensors moved to CPU)).
+
+    fixture_poses=True: both sides use the relative-pose matrices stored in the fixture (the ones the reference
+    computed in the build container) instead of running torch.inverse on this host."""
+    from cross_attention_renderer_amd.engine import RenderEngine
     c, inp, z, sd, fx = load_case(name)
+    poses = torch.as_tensor(fx["poses"]) if fixture_poses else None
     with torch.no_grad():
-        ora = O.render_forward(sd, inp, z, oracle_cfg(c), debug=True)
+        ora = O.render_forward(sd, inp, z, oracle_cfg(c), debug=True, poses96=poses)
     m = build_module(c, sd, device)
-    if linear_flags:
-        from cross_attention_renderer_amd.engine import RenderEngine
-        m._engine = RenderEngine(m)
-        m._engine.linear_flags = linear_flags
+    m._engine = RenderEngine(m)
+    m._engine.linear_flags = linear_flags
+    m._engine.pose_records = poses
     with torch.no_grad():
         out = m(to_device(inp, device), z=[t.to(device) for t in z], debug=debug)
     torch.cuda.synchronize()

@@ -19,9 +19,11 @@ from oracle import car_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4
-OUTLIER_FRAC = 2e-3          # at most 0.2 % of the elements of an output may exceed TOL ...
-OUTLIER_MAX = 5e-2           # ... and none may be off by more than this
+TOL = 1e-4                   # the contract: |a-b| <= 1e-4 * max(1,|b|)
+# Only for the comparison that runs torch.inverse on *this* host against vectors made on another CPU (see
+# test_forward_host_poses_vs_reference): at most 2 % of an output's elements may exceed TOL, none by more than 5e-2.
+OUTLIER_FRAC = 2e-2
+OUTLIER_MAX = 5e-2
 
 HIP_CASES = [n for n, c in C.CASES.items() if c.get("n_view", 2) != 3]
 
@@ -116,8 +118,7 @@ def test_geometry_stages_match_oracle(name):
     if "overlaps" in st:
         assert (rays[..., 10] != st["overlaps"].float()).float().mean() == 0.0
     assert rel_err(out["pixel_val"], st["pixel_val"]) < 1e-5
-    e = err_stats(hs["pt"], st["pt"])
-    assert e["f1e-4"] < 1e-3 and e["max"] < 1e-1, e
+    assert rel_err(hs["pt"], st["pt"]) < 1e-6
     assert rel_err(hs["local_coords"][..., :9], st["local_coords"][..., :9]) < 1e-5
     assert (out["valid_mask"] == ora["valid_mask"]).all()
 
@@ -125,25 +126,47 @@ def test_geometry_stages_match_oracle(name):
 # ----------------------------------------------------------------------------------------------------------
 # the whole forward: HIP vs oracle and HIP vs the committed reference outputs
 # ----------------------------------------------------------------------------------------------------------
-def _check_outputs(got, want_of, what):
+def _check_outputs(got, want_of, what, frac=0.0, worst=TOL):
     for k in ("rgb", "depth_ray", "at_wt"):
         e = err_stats(got[k], want_of(k))
-        assert e["f1e-4"] <= OUTLIER_FRAC and e["max"] <= OUTLIER_MAX, f"{what} {k}: {e}"
+        assert e["f1e-4"] <= frac and e["max"] <= worst, f"{what} {k}: {e}"
     assert (np.asarray(got["valid_mask"]) == np.asarray(want_of("valid_mask"))).all(), what
     same = (np.asarray(got["at_wt_max"]) == np.asarray(want_of("at_wt_max"))).mean()
-    assert same > 0.99, f"{what} at_wt_max agreement {same}"
+    assert same > 0.995, f"{what} at_wt_max agreement {same}"
 
 
 @pytest.mark.parametrize("name", HIP_CASES)
-def test_forward_matches_oracle_and_reference(name):
+def test_forward_matches_oracle(name):
+    """HIP vs the CPU oracle on this host, both running the reference's pose algebra here: strict 1e-4."""
     c, fx, ora, out = run_case(name)
     assert tuple(out["rgb"].shape) == fx["out_rgb"].shape
     assert tuple(out["at_wt_max"].shape) == fx["out_at_wt_max"].shape and out["at_wt_max"].dtype == torch.int64
     assert tuple(out["coords"].shape) == fx["out_coords"].shape
     _check_outputs(out, lambda k: ora[k], "vs oracle")
+    assert err_stats(out["stages"]["interp_val"], ora["stages"]["interp_val"])["max"] <= TOL
+    assert err_stats(out["stages"]["pt"], ora["stages"]["pt"])["max"] <= TOL
+
+
+@pytest.mark.parametrize("name", HIP_CASES)
+def test_forward_matches_reference_fixture(name):
+    """HIP vs the outputs of the reference itself (committed fixture), using the pose matrices the reference computed:
+    strict 1e-4, every element."""
+    c, fx, ora, out = run_case(name, fixture_poses=True)
     _check_outputs(out, lambda k: fx["out_" + k], "vs reference fixture")
-    e = err_stats(out["stages"]["interp_val"], ora["stages"]["interp_val"])
-    assert e["f1e-4"] <= OUTLIER_FRAC, e
+    assert rel_err(out["pixel_val"], fx["out_pixel_val"]) < 1e-6
+    assert rel_err(out["coords"], fx["out_coords"]) < 1e-6
+    if c["tier"] == 0:
+        assert rel_err(out["stages"]["pt"], fx["stage_pt"]) < 1e-6
+        assert err_stats(out["stages"]["interp_val"], fx["stage_interp_val"])["max"] <= TOL
+
+
+@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c4", "t2_c5"])
+def test_forward_host_poses_vs_reference(name):
+    """The production path (torch.inverse on this host's CPU) against vectors made on another CPU: LAPACK's last-ulp
+    results are host dependent and the fp64 intersection amplifies them on a few ill-conditioned samples, so this
+    comparison — and only this one — carries an outlier budget."""
+    c, fx, ora, out = run_case(name)
+    _check_outputs(out, lambda k: fx["out_" + k], "host poses vs reference fixture", frac=OUTLIER_FRAC, worst=OUTLIER_MAX)
 
 
 def test_register_staged_weights_agree_with_lds_dma():
@@ -194,4 +217,4 @@ def test_full_size_properties():
     with torch.no_grad():
         ora = O.render_forward(sd, cpu_inp, [t.cpu() for t in z], O.RenderConfig(n_view=2, npoints=P, H=H, W=H))
     e = err_stats(full["rgb"][:, :, idx].cpu(), ora["rgb"])
-    assert e["f1e-4"] <= 5e-3 and e["max"] < OUTLIER_MAX, e
+    assert e["max"] <= TOL, e
