@@ -131,6 +131,7 @@ extern "C" int car_attend(const float* qa, const float* qb, int dq, const float*
     CAR_REQUIRE(b > 0 && V > 0 && V <= CAR_MAX_VIEWS && R > 0 && P > 0 && V * P <= kMaxSamples, "car_attend: bad sizes");
     CAR_REQUIRE(dq > 0 && dq % 4 == 0 && D > 0 && reps >= 1 && ld_z >= reps * D, "car_attend: bad widths dq=%d D=%d", dq, D);
     CAR_REQUIRE(!pt || (poses && depth), "car_attend: pt needs poses and depth");
+    (void)hipGetLastError();
     hipLaunchKernelGGL(attend_kernel, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, qa, qb, dq, val,
                        D, b, V, R, P, zprev, zprev_scale, w_out, z_out, ld_z, reps, pt, (const CarPose*)poses, depth,
                        w_argmax);
@@ -143,6 +144,7 @@ extern "C" int car_add_ray_bias_relu(float* r, const float* u, int b, int V, int
     CAR_REQUIRE(b > 0 && V > 0 && R > 0 && P > 0 && C > 0 && C % 4 == 0, "car_add_ray_bias_relu: bad sizes");
     const long total4 = (long)b * V * R * P * (C / 4);
     const unsigned blocks = (unsigned)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(add_ray_bias_relu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, r, u, b, V, R, P, C, total4);
     CAR_CHECK_LAUNCH("car_add_ray_bias_relu");
     return CAR_OK;

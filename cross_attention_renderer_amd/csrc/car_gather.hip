@@ -79,6 +79,7 @@ extern "C" int car_gather_bilinear(const float* const* maps, const int* level_c,
                 "car_gather_bilinear: output window [%d,%d) must be float4-aligned inside a row of %d", col_out, col_out + 4 * q, ld_out);
     const long total = (long)n_maps * pts * q;
     const unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L, n_maps, grid, pts, mode,
                        place, V, out, ld_out, col_out);
     CAR_CHECK_LAUNCH("car_gather_bilinear");

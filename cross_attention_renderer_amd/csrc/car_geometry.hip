@@ -117,6 +117,7 @@ extern "C" int car_pose_setup(const float* c2w_ctx, const float* c2w_q, const fl
                               int b, int V, int H, float* poses, void* stream) {
     CAR_REQUIRE(c2w_ctx && c2w_q && K_ctx && K_q && poses, "car_pose_setup: null pointer");
     CAR_REQUIRE(b > 0 && V > 0 && V <= CAR_MAX_VIEWS && H > 0, "car_pose_setup: bad sizes b=%d V=%d H=%d", b, V, H);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(pose_kernel, dim3(car_div_up(b, 64)), dim3(64), 0, (hipStream_t)stream, c2w_ctx, c2w_q, K_ctx,
                        K_q, b, V, H, (CarPose*)poses);
     CAR_CHECK_LAUNCH("car_pose_setup");
@@ -131,6 +132,7 @@ extern "C" int car_ray_setup(const float* poses, const float* uv, int b, int V, 
     CAR_REQUIRE(!no_sample || depth_steps, "car_ray_setup: no_sample needs depth_steps");
     CAR_REQUIRE(!phi_x || ld_phi >= 9 * V, "car_ray_setup: ld_phi (%d) < 9*V", ld_phi);
     const long n = (long)b * V * R;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(ray_kernel, dim3(car_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, (const CarPose*)poses,
                        uv, b, V, R, H, W, P, no_sample, depth_steps, (CarRay*)rays, coords9, phi_x, ld_phi);
     CAR_CHECK_LAUNCH("car_ray_setup");
@@ -144,6 +146,7 @@ extern "C" int car_sample_setup(const float* poses, const float* rays, const flo
     CAR_REQUIRE(b > 0 && V > 0 && V <= CAR_MAX_VIEWS && R > 0 && P > 0 && H > 1 && W > 1, "car_sample_setup: bad sizes");
     CAR_REQUIRE(!xenc || (ld_xenc >= col_xenc + (V == 1 ? 6 : 3) && col_xenc >= 0), "car_sample_setup: xenc window out of row");
     const long n = (long)b * V * R * P;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(sample_kernel, dim3(car_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const CarPose*)poses, (const CarRay*)rays, steps, b, V, R, P, H, W, no_sample, pixel_val, pt, g,
                        grid_in, xenc, ld_xenc, col_xenc);
@@ -156,6 +159,7 @@ extern "C" int car_finalize(const float* rays, const float* rgb_in, int ld_in, i
     CAR_REQUIRE(rays && rgb_in && rgb && valid, "car_finalize: null pointer");
     CAR_REQUIRE(b > 0 && V > 0 && R > 0 && ld_in >= 3, "car_finalize: bad sizes");
     const long n = (long)b * R;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(finalize_kernel, dim3(car_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, (const CarRay*)rays,
                        rgb_in, ld_in, b, V, R, rgb, valid);
     CAR_CHECK_LAUNCH("car_finalize");

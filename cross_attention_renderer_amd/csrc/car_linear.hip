@@ -223,9 +223,11 @@ int launch_linear(const float* X, int ldx, const float* packed, int K, int N, co
     const dim3 grid(car_div_up(M, kRowsPerBlock), g.tiles_alloc / NT);
     const size_t lds_bytes = (size_t)2 * NT * kTileFloats * sizeof(float);
     if (flags & CAR_LIN_NO_GLDS)
+        (void)hipGetLastError();
         hipLaunchKernelGGL((linear_kernel<NT, false>), grid, dim3(256), lds_bytes, stream, X, ldx, packed, K, N,
                            g.tiles_alloc, g.chunks, Y, ldy, M, flags);
     else
+        (void)hipGetLastError();
         hipLaunchKernelGGL((linear_kernel<NT, true>), grid, dim3(256), lds_bytes, stream, X, ldx, packed, K, N,
                            g.tiles_alloc, g.chunks, Y, ldy, M, flags);
     CAR_CHECK_LAUNCH("car_linear");
@@ -246,6 +248,7 @@ extern "C" int car_linear_pack(const float* W, int ldw, const float* bias, int K
     const PackGeom g = pack_geom(K, N);
     const long total = (long)g.chunks * g.tiles_alloc * kTileFloats;
     const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    (void)hipGetLastError();
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, ldw, bias, K, N, g.tiles_alloc,
                        total, packed);
     CAR_CHECK_LAUNCH("car_linear_pack");
