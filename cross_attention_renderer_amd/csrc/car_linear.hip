@@ -222,12 +222,11 @@ int launch_linear(const float* X, int ldx, const float* packed, int K, int N, co
                   long M, int flags, hipStream_t stream) {
     const dim3 grid(car_div_up(M, kRowsPerBlock), g.tiles_alloc / NT);
     const size_t lds_bytes = (size_t)2 * NT * kTileFloats * sizeof(float);
+    (void)hipGetLastError();
     if (flags & CAR_LIN_NO_GLDS)
-        (void)hipGetLastError();
         hipLaunchKernelGGL((linear_kernel<NT, false>), grid, dim3(256), lds_bytes, stream, X, ldx, packed, K, N,
                            g.tiles_alloc, g.chunks, Y, ldy, M, flags);
     else
-        (void)hipGetLastError();
         hipLaunchKernelGGL((linear_kernel<NT, true>), grid, dim3(256), lds_bytes, stream, X, ldx, packed, K, N,
                            g.tiles_alloc, g.chunks, Y, ldy, M, flags);
     CAR_CHECK_LAUNCH("car_linear");
