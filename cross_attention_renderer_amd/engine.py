@@ -68,6 +68,12 @@ class RenderEngine:
         self.linear_flags = 0          # tests may set NO_GLDS for A/B
         self.timing = None             # bench: dict layer name -> [(start, end) HIP events on the launch stream]
         self.pose_records = None       # tests: (b*V, 96) CarPose records to use instead of the host pose algebra
+        # first point-MLP layer as a gather over per-texel pre-projected maps (csrc/car_encode.hip) instead of a
+        # K=579 GEMM per sample; False selects the literal gather -> GEMM pipeline (A/B and stage tests)
+        self.project_maps = True
+        self._gmaps_key = None
+        self._gmaps: List[Tensor] = []
+        self._wpt: Optional[Tensor] = None
 
     # ------------------------------------------------------------------ weights
     def _weights(self, device) -> Dict[str, PackedLinear]:
@@ -108,6 +114,38 @@ class RenderEngine:
             self._maps = [t.detach().float().permute(0, 2, 3, 1).contiguous() for t in z]
             self._maps_key = key
         return self._maps
+
+    def _projected_maps(self, maps: List[Tensor], device):
+        """G_l = query_encode_latent.weight[:, ch_l] F_l per pyramid level (channel-last, C wide), plus the [C,4]
+        table (W1[:, C:C+3], b1).  Recomputed only when the pyramid or the layer's parameters change."""
+        m = self.m
+        w1, b1 = m.query_encode_latent.weight, m.query_encode_latent.bias
+        key = (self._maps_key, w1.data_ptr(), w1._version, b1.data_ptr(), b1._version, str(device))
+        if key == self._gmaps_key:
+            return self._gmaps, self._wpt
+        C = w1.shape[0]
+        w = w1.detach().reshape(C, -1).to(device=device, dtype=torch.float32)
+        gm, off = [], 0
+        for t in maps:
+            n, Hl, Wl, Cl = t.shape
+            layer = PackedLinear(w[:, off:off + Cl].contiguous(), None, device, "project_maps")
+            g = torch.empty(n, Hl, Wl, C, device=device, dtype=torch.float32)
+            self.linear(t, Cl, layer, g, C, n * Hl * Wl)
+            gm.append(g)
+            off += Cl
+        wpt = torch.cat([w[:, off:off + 3], b1.detach().to(device=device, dtype=torch.float32)[:, None]], dim=1).contiguous()
+        self._gmaps, self._wpt, self._gmaps_key = gm, wpt, key
+        return gm, wpt
+
+    def gather_encode(self, gmaps: List[Tensor], wpt: Tensor, pixel_val: Tensor, grid_in: Tensor, ptenc: Tensor,
+                      V: int, pts: int, out: Tensor, ld_out: int):
+        L = len(gmaps)
+        ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in gmaps])
+        hs = (ctypes.c_int * L)(*[g.shape[1] for g in gmaps])
+        ws = (ctypes.c_int * L)(*[g.shape[2] for g in gmaps])
+        _lib.check(self.lib.car_gather_encode(ptrs, hs, ws, L, gmaps[0].shape[3], _ptr(pixel_val), _ptr(grid_in),
+                                              _ptr(ptenc), _ptr(wpt), gmaps[0].shape[0], V, pts, _ptr(out), ld_out,
+                                              _stream()), "car_gather_encode")
 
     def _linspace(self, a: float, b_: float, P: int, device) -> Tensor:
         k = (a, b_, P, str(device))
@@ -188,7 +226,11 @@ class RenderEngine:
         single = (V == 1 and not m.no_latent_concat)
         grid_in = torch.empty(n, R, P, V, 2, **f32) if concat2 else None
         x1 = None
-        if concat2:
+        proj = concat2 and self.project_maps
+        if proj:
+            ld1 = 4                                   # only the 3 point channels: [S*V, 4]
+            x1 = torch.zeros(S * V, ld1, **f32)
+        elif concat2:
             ld1 = _round_up(C + 3, 32)
             x1 = torch.empty(S * V, ld1, **f32)
         elif single:
@@ -196,10 +238,18 @@ class RenderEngine:
             x1 = torch.empty(S, ld1, **f32)
         _lib.check(lib.car_sample_setup(_ptr(poses), _ptr(rays), _ptr(steps), b, V, R, P, H, W, int(m.no_sample),
                                         _ptr(pixel_val), _ptr(pt), _ptr(g), _ptr(grid_in), _ptr(x1),
-                                        ld1 if x1 is not None else 0, C, st), "car_sample_setup")
+                                        ld1 if x1 is not None else 0, 0 if proj else C, st), "car_sample_setup")
 
         # a7, a9-a11: per-sample features e
-        if concat2:
+        if proj:
+            gmaps, wpt = self._projected_maps(maps, dev)
+            h1 = torch.empty(S * V, C, **f32)
+            self.gather_encode(gmaps, wpt, pixel_val, grid_in, x1, V, R * P, h1, C)
+            e = torch.empty(S, V * (C // 2), **f32)
+            self.linear(h1, C, pk["query_encode_latent_2"], e, C // 2, S * V)
+            del h1
+            Ce = V * (C // 2)
+        elif concat2:
             self.gather(maps, pixel_val, R * P, 0, PLACE_OWN, V, x1, ld1, 0)
             gi = grid_in.view(b, V, R, P, V, 2)
             # pixel_val_stack (models.py:316): map (b, s) is sampled where the *other* line's points land in view s
@@ -222,9 +272,9 @@ class RenderEngine:
             Ce = C
         del x1
 
-        # a12: values and keys;  a13: geometric query
-        val = torch.empty(S, Dl, **f32)
-        self.linear(e, Ce, pk["latent_value"], val, Dl, S)
+        # a12: keys;  a13: geometric query.  The value projection (latent_value, no nonlinearity before the weighted sum)
+        # commutes with the attention average: sum_s w_s (Wv e_s + bv) = Wv (sum_s w_s e_s) + bv because the softmax
+        # weights of a ray sum to 1, so it is applied once per ray after the reduction instead of once per sample.
         k1 = torch.empty(S, 128, **f32)
         self.linear(e, Ce, pk["key_map"], k1, 128, S, RELU_OUT)
         key = torch.empty(S, 128, **f32)
@@ -238,12 +288,14 @@ class RenderEngine:
         depth = torch.empty(b, R, **f32)
         amax = torch.empty(n, R, dtype=torch.int32, device=dev)
         rep = m.repeat_attention
-        z1 = torch.empty(b * R, Dl if rep else V * Dl, **f32)
-        _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(val), Dl, b, V, R, P, None, 0.0, _ptr(at_wt), _ptr(z1),
-                                  z1.shape[1], 1 if rep else V, _ptr(pt), _ptr(poses), _ptr(depth), _ptr(amax), st),
-                   "car_attend")
+        ebar = torch.empty(b * R, Ce, **f32)
+        _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt), _ptr(ebar),
+                                  Ce, 1, _ptr(pt), _ptr(poses), _ptr(depth), _ptr(amax), st), "car_attend")
+        zrep = torch.empty(b * R, V * Dl, **f32)
         at_wt2 = None
         if rep:
+            z1 = torch.empty(b * R, Dl, **f32)
+            self.linear(ebar, Ce, pk["latent_value"], z1, Dl, b * R)
             # a15: second round; the z_embed half of query_repeat_embed is per ray, the local_coords half per sample
             hb = torch.empty(b * R, 128, **f32)
             self.linear(z1, Dl, pk["encode_latent"], hb, 128, b * R)
@@ -253,11 +305,17 @@ class RenderEngine:
             _lib.check(lib.car_add_ray_bias_relu(_ptr(k1), _ptr(uh), b, V, R, P, 128, st), "car_add_ray_bias_relu")
             self.linear(k1, 128, pk["query_repeat_embed_2"], key, 128, S)
             at_wt2 = torch.empty(n, R, P, **f32)
-            zrep = torch.empty(b * R, V * Dl, **f32)
-            _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(val), Dl, b, V, R, P, _ptr(z1), float(V), _ptr(at_wt2),
-                                      _ptr(zrep), V * Dl, V, None, None, None, None, st), "car_attend")
+            _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt2),
+                                      _ptr(ebar), Ce, 1, None, None, None, None, st), "car_attend")
+            # z = (Wv ebar2 + bv) + V * z1   (models.py:561-565: "+ z_local" per view, then the view sum)
+            zv = zrep.view(b * R, V, Dl)
+            zv[:, 0] = z1 * float(V)
+            self.linear(ebar, Ce, pk["latent_value"], zrep, V * Dl, b * R, ACCUM)
         else:
-            zrep = z1
+            self.linear(ebar, Ce, pk["latent_value"], zrep, V * Dl, b * R)
+        if V > 1:                                         # the per-view replication of models.py:541, 565, 605-606
+            zv = zrep.view(b * R, V, Dl)
+            zv[:, 1:] = zv[:, :1]
 
         # a17: light-field decoder
         hid = m.phi.d_hidden

@@ -97,6 +97,18 @@ int car_gather_bilinear(const float* const* maps, const int* level_c, const int*
                         int n_levels, int n_maps, const float* grid, long pts, int mode, int place, int V,
                         float* out, int ld_out, int col_out, void* stream);
 
+/* ---- a7 + a10 + first layer of a11, fused through linearity (models.py:278, 317, 330-341).
+ * gmaps[l]: [n_maps, Hl, Wl, C] = the pyramid level l pushed once per texel through its slice of the first point-MLP
+ * layer (G_l = query_encode_latent.weight[:, ch_l] F_l, computed with car_linear).  For sample i = (n, j), j < pts, and
+ * source view s the kernel writes row i*V + s of `out`:
+ *     relu( sum_l bilinear(G_l[map], grid) + wpt[:, 0:3] ptenc[row, 0:3] + wpt[:, 3] )
+ * where (map, grid, padding) = (n, pixel_val[i], border) if s is the sample's own view, else
+ * ((scene, s), grid_in[i, s], zeros).  ptenc [n_maps*pts*V, 4] = tanh(nan_to_num(T_s pt)/5) (car_sample_setup's xenc
+ * with ld 4); wpt [C, 4] = (W1[:, C:C+3], b1).  V must be 2. */
+int car_gather_encode(const float* const* gmaps, const int* level_h, const int* level_w, int n_levels, int C,
+                      const float* pixel_val, const float* grid_in, const float* ptenc, const float* wpt,
+                      int n_maps, int V, long pts, float* out, int ld_out, void* stream);
+
 /* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
  *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).
  * Weights are re-laid out once into the MFMA operand order by car_linear_pack (bias folded in as column K). */

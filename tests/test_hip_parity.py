@@ -169,6 +169,17 @@ def test_forward_host_poses_vs_reference(name):
     _check_outputs(out, lambda k: fx["out_" + k], "host poses vs reference fixture", frac=OUTLIER_FRAC, worst=OUTLIER_MAX)
 
 
+@pytest.mark.parametrize("name", ["t0_default", "t0_diverging", "t1_c1", "t2_c2", "t2_c5"])
+def test_literal_gather_gemm_pipeline_matches_oracle(name):
+    """The literal pipeline (materialised 579-wide rows -> K=579 GEMM), kept for A/B against the default path that
+    applies the first point-MLP layer per texel (csrc/car_encode.hip): both must sit within 1e-4 of the oracle."""
+    c, fx, ora, out = run_case(name, project_maps=False)
+    _check_outputs(out, lambda k: ora[k], "literal pipeline vs oracle")
+    _, _, _, out2 = run_case(name, project_maps=True)
+    assert rel_err(out["rgb"], out2["rgb"]) < 2e-5
+    assert err_stats(out["stages"]["interp_val"], out2["stages"]["interp_val"])["max"] < 5e-5
+
+
 def test_register_staged_weights_agree_with_lds_dma():
     """A/B of the two weight-staging variants of the MFMA kernel on a whole forward."""
     _, _, _, a = run_case("t1_c1")
