@@ -43,6 +43,9 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: its wheel bundles its own libamdhip64.so, and the process must end up with ONE
+    # HIP runtime (the one that owns torch's device context and streams) — loading ours first binds /opt/rocm's copy.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "

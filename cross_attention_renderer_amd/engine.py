@@ -163,7 +163,7 @@ class RenderEngine:
                                        flags | self.linear_flags, _stream()), "car_linear")
         if ev is not None:
             ev[1].record()
-            self.timing.setdefault(layer.name, []).append(ev)
+            self.timing.setdefault(layer.name, []).append((ev[0], ev[1], M, layer.K, layer.N))
 
     def gather(self, maps: List[Tensor], grid: Tensor, pts: int, mode: int, place: int, V: int, out: Tensor,
                ld_out: int, col_out: int):
