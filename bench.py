@@ -10,9 +10,9 @@ sides, as in BASELINE.md.  With N GPUs every rank renders its own frame of the t
 independent) and the rendered tiles [rgb, depth, valid] are exchanged with one RCCL all-gather per step.
 
 The JSON line also carries
-  roofline     : the dominant kernel (fp32-MFMA 1x1-conv ``linear_kernel``, the 579->576 layer) timed live with HIP
-                 events on the launch stream: algorithmic FLOP per launch / mean launch time vs the 157.3 TFLOP/s fp32
-                 matrix peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md);
+  roofline     : the dominant kernel (the MFMA kernel with the largest summed launch time) timed live with HIP events on
+                 the launch stream: algorithmic FLOP per launch / mean launch time vs the 157.3 TFLOP/s fp32 matrix peak
+                 of MI355X (/opt/skills/guides/MI355X_MICROARCH.md);
   cpu_baseline : the CPU oracle (a port of the reference forward, validated against it) timed on this host's cores
                  over a bounded sample of the same workload.
 """
@@ -168,12 +168,11 @@ def main():
         for name, evs in model._engine.timing.items():
             lat = [a.elapsed_time(b_) * 1e-3 for a, b_, *_ in evs]
             if lat and (best is None or sum(lat) > best[1]):
-                best = (name, sum(lat), lat, evs[0][2:])
+                best = (name, sum(lat), lat, evs[0][2], evs[0][3])
         if best is not None:
-            name, _, lat, (M, K, N) = best
+            name, _, lat, flop, desc = best
             mean = sum(lat) / len(lat)
-            flop = 2.0 * M * (K + 1) * N                     # algorithmic: one MAC per (row, input incl. bias, output)
-            roof = {"bound": "mfma", "kernel": f"linear_kernel ({name}: {K}->{N} on {M} rows)", "achieved": flop / mean / 1e12,
+            roof = {"bound": "mfma", "kernel": desc, "achieved": flop / mean / 1e12,
                     "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": flop / mean / FP32_MFMA_PEAK,
                     "traffic": None, "launches": len(lat), "ms_per_launch": mean * 1e3, "flop_per_launch": flop}
         line = {

@@ -36,6 +36,9 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
 
     // 1. logits: 16 lanes per sample, float4 per lane per step
     const int sub = tid & 15, grp = tid >> 4;            // 16 groups of 16 lanes
+    if (qb == nullptr) {                                 // logits were computed upstream (car_fused_samples)
+        for (int s = tid; s < S; s += 256) s_w[s] = qa[row_of(s)];
+    } else
     for (int s = grp; s < S; s += 16) {
         const long row = row_of(s);
         const float* a = qa + row * dq;
@@ -127,9 +130,9 @@ __global__ void add_ray_bias_relu_kernel(float* __restrict__ r, const float* __r
 extern "C" int car_attend(const float* qa, const float* qb, int dq, const float* val, int D, int b, int V, int R,
                           int P, const float* zprev, float zprev_scale, float* w_out, float* z_out, int ld_z, int reps,
                           const float* pt, const float* poses, float* depth, int32_t* w_argmax, void* stream) {
-    CAR_REQUIRE(qa && qb && val && w_out && z_out, "car_attend: null pointer");
+    CAR_REQUIRE(qa && val && w_out && z_out, "car_attend: null pointer");
     CAR_REQUIRE(b > 0 && V > 0 && V <= CAR_MAX_VIEWS && R > 0 && P > 0 && V * P <= kMaxSamples, "car_attend: bad sizes");
-    CAR_REQUIRE(dq > 0 && dq % 4 == 0 && D > 0 && reps >= 1 && ld_z >= reps * D, "car_attend: bad widths dq=%d D=%d", dq, D);
+    CAR_REQUIRE((!qb || (dq > 0 && dq % 4 == 0)) && D > 0 && reps >= 1 && ld_z >= reps * D, "car_attend: bad widths dq=%d D=%d", dq, D);
     CAR_REQUIRE(!pt || (poses && depth), "car_attend: pt needs poses and depth");
     (void)hipGetLastError();
     hipLaunchKernelGGL(attend_kernel, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, qa, qb, dq, val,

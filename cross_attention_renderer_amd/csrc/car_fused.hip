@@ -1,0 +1,389 @@
+// car_fused.hip — the per-sample part of the render forward as ONE kernel (first half of a14).
+//
+// For every epipolar sample (V = 2 context views) it computes, without touching HBM in between:
+//   geometry   pixel_val, fp64 Pluecker point, cross-view projections, geometric query g      (car_geom.h; models.py:261-331, 494-528)
+//   encode     h_s = relu(sum_l bilinear(G_l) + Wpt tanh(pt_s/5) + b1) for both source views s (per-texel first layer, see car_encode.hip)
+//   e          = [W2 h_0 + b2 ; W2 h_1 + b2]                      576 -> 288 per source        (models.py:333-344)
+//   qry        = Wq2 relu(Wq1 g + bq1) + bq2                      16 -> 128 -> 128             (models.py:529)
+//   ug         = Wr1[:,128:] g + br1                              local half of round 2's query (models.py:552-553)
+//   key        = Wk2 relu(Wk1 e + bk1) + bk2                      576 -> 128 -> 128            (models.py:491)
+//   logit      = <key, qry> / 16                                                              (models.py:532)
+// and writes e, qry, ug, logit, pt, pixel_val.  The per-ray softmax / reductions stay in car_attention.hip.
+//
+// CDNA4 mapping.  One workgroup = 4 waves = 128 consecutive samples, ONE wave per SIMD (up to 512 VGPRs): each wave owns
+// 32 samples for the whole chain.  All layers use v_mfma_f32_32x32x2_f32 with weights as the A operand and samples as the
+// B operand (see car_linear.hip), so a layer's accumulators (lane = sample, registers = channels) are exactly the next
+// layer's B operands: e, key and qry never leave the register file ("chained" layers; the K index of a chained layer is
+// permuted to the accumulator layout k = 32*T + (r&3) + 8*(r>>2) + 4*(lane>>5), which the host bakes into the packed
+// weights).  Only the encode output has to be transposed (gather lanes own channels, MFMA lanes own samples); it goes
+// through a wave-private 32x32 LDS tile per K chunk.  The 12 tap loads per output float4 of chunk c+1 are issued in three
+// level-sized batches between the three MFMA sub-blocks of chunk c, so their L2 latency hides under ~3000 matrix cycles.
+// The weights of all six layers (1.1 MB) stream L2 -> LDS by LDS-DMA, double buffered, one barrier per 32-wide K chunk,
+// shared by the four waves.  fp32 MFMA issues one 32x32x2 per 64 cycles per SIMD: everything else (gather FMAs, tanh,
+// fp64 geometry, LDS traffic) fits in its shadow; the kernel is matrix-pipe bound on 0.89 MFLOP per sample.
+#include "car_common.h"
+#include "car_geom.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int kC = 576;            // feature channels = width of h
+constexpr int kE = 288;            // per-source width of e
+constexpr int kD = 128;            // hidden width of the key / query MLPs
+constexpr int kKT = kC / 32;       // 18 K-chunks of the 576 -> 288 layer
+constexpr int kNTE = kE / 32;      // 9 output tiles
+constexpr int kNTD = kD / 32;      // 4 output tiles
+constexpr int kTile = 1024;        // packed floats per (chunk, tile)
+constexpr int kStageLd = 36;       // row stride of the wave-private h tile (floats): conflict-free b128 reads and writes
+
+// ---- packed-weight blob: tile offsets (units of kTile floats) of each layer, in consumption order -------------------
+constexpr int kOffW2 = 0;                          // 18 chunks x 9 tiles, standard K mapping
+constexpr int kOffQ1 = kOffW2 + kKT * kNTE;        // 1 chunk x 4 tiles, standard, bias folded at k = 16
+constexpr int kOffQ2 = kOffQ1 + kNTD;              // 4 chunks x 4 tiles, chained
+constexpr int kOffUG = kOffQ2 + 4 * kNTD;          // 1 chunk x 4 tiles, standard, bias folded
+constexpr int kOffK1 = kOffUG + kNTD;              // 18 chunks x 4 tiles, chained over [e_0 ; e_1]
+constexpr int kOffK2 = kOffK1 + 2 * kNTE * kNTD;   // 4 chunks x 4 tiles, chained
+constexpr int kBlobTiles = kOffK2 + 4 * kNTD;
+constexpr int kNumChunks = 2 * kKT + 1 + 4 + 1 + 2 * kNTE + 4;       // 64 weight chunks per 128-sample pass
+
+// bias table (floats): b2[288] | bq2[128] | bk1[128] | bk2[128]
+constexpr int kBiasE = 0, kBiasQ2 = kE, kBiasK1 = kE + kD, kBiasK2 = kE + 2 * kD, kBiasFloats = kE + 3 * kD;
+
+// ---- dynamic LDS carve-up (floats) --------------------------------------------------------------------------------
+constexpr int kLdsW = 0;                                   // [2][9][1024]          weight chunks           72 KB
+constexpr int kLdsStage = kLdsW + 2 * kNTE * kTile;        // [4][32][36]           h tiles, wave private    18 KB
+constexpr int kLdsTapI = kLdsStage + 4 * 32 * kStageLd;    // [4][32][2][3][4] int  tap texel indices        12 KB
+constexpr int kLdsTapW = kLdsTapI + 4 * 32 * 2 * 3 * 4;    // [4][32][2][3][4]      tap weights              12 KB
+constexpr int kLdsPe = kLdsTapW + 4 * 32 * 2 * 3 * 4;      // [4][32][2][4]         tanh(pt_s/5)              4 KB
+constexpr int kLdsWpt = kLdsPe + 4 * 32 * 2 * 4;           // [576][4]              (W1[:,C:C+3], b1)         9 KB
+constexpr int kLdsBias = kLdsWpt + kC * 4;                 // [672]                                           2.6 KB
+constexpr int kLdsFloats = kLdsBias + kBiasFloats;
+constexpr size_t kLdsBytes = (size_t)kLdsFloats * sizeof(float);
+
+struct FusedArgs {
+    const CarPose* poses;
+    const CarRay* rays;
+    const float* steps;
+    const float* gmap[3];
+    int gh[3], gw[3];
+    const float* wpt;        // [576][4]
+    const float* blob;       // kBlobTiles * 1024 floats
+    const float* bias;       // kBiasFloats
+    int b, V, R, P, H, W;
+    long S;                  // b*V*R*P samples
+    float* e;                // [S, 576]
+    float* qry;              // [S, 128]
+    float* ug;               // [S, 128]
+    float* logit;            // [S]
+    float* pt;               // [S, 3]
+    float* pixel_val;        // [S, 2]
+};
+
+// consumption order: W2 x18 (source 0) | K1 x9 (e_0 block) | W2 x18 (source 1) | K1 x9 (e_1 block) | K2 x4 | Q1 | Q2 x4 | UG
+__device__ __forceinline__ int chunk_tile_offset(int g) {
+    if (g < 18) return kOffW2 + g * kNTE;
+    if (g < 27) return kOffK1 + (g - 18) * kNTD;
+    if (g < 45) return kOffW2 + (g - 27) * kNTE;
+    if (g < 54) return kOffK1 + (9 + g - 45) * kNTD;
+    if (g < 58) return kOffK2 + (g - 54) * kNTD;
+    if (g < 59) return kOffQ1;
+    if (g < 63) return kOffQ2 + (g - 59) * kNTD;
+    return kOffUG;
+}
+__device__ __forceinline__ int chunk_tiles(int g) { return (g < 18 || (g >= 27 && g < 45)) ? kNTE : kNTD; }
+
+// LDS-DMA of weight chunk g into buffer (g & 1): every wave copies a quarter of every tile (see car_linear.hip for why
+// this is inline asm).  Nothing is issued past the last chunk.
+__device__ __forceinline__ void stream_issue(const float* __restrict__ blob, float* lds, int g, int tid, int wave) {
+    if (g >= kNumChunks) return;
+    const float* src = blob + (long)chunk_tile_offset(g) * kTile;
+    float* dst = lds + kLdsW + (g & 1) * kNTE * kTile;
+    const int nt = chunk_tiles(g);
+    for (int t = 0; t < nt; ++t) {
+        const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(dst + 4 * (t * 256 + wave * 64)));
+        const float* gsrc = src + 4 * (t * 256 + tid);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+}
+// end of a chunk: the DMA of the next chunk has landed and every wave is done reading the current one
+__device__ __forceinline__ void stream_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// 16 MFMA steps of one chunk on tiles [T0, T0+NTS) of acc, A from the LDS weight buffer, B from 16 registers
+template <int NT, int T0, int NTS>
+__device__ __forceinline__ void mfma_tiles(f32x16 (&acc)[NT], const float (&bv)[16], const float* wl) {
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+#pragma unroll
+        for (int t = T0; t < T0 + NTS; ++t) {
+            const float4 a = *reinterpret_cast<const float4*>(wl + (t * 4 + j4) * 256);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv[4 * j4 + 0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv[4 * j4 + 1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv[4 * j4 + 2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv[4 * j4 + 3], acc[t], 0, 0, 0);
+        }
+    }
+}
+
+// accumulators start at the layer's bias: lane (s, h) register r of tile t holds channel 32 t + (r&3) + 8 (r>>2) + 4 h
+template <int NT>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NT], const float* lbias, int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = lbias[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+}
+
+template <int NT>
+__device__ __forceinline__ void store_rows(const f32x16 (&acc)[NT], float* row, int h) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(row + 32 * t + 8 * g + 4 * h) =
+                make_float4(acc[t][4 * g + 0], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+}
+
+// one chained layer with 128 outputs: B operands are the NSRC x 16 registers of `src` (optionally through ReLU)
+template <int NSRC, bool RELU>
+__device__ __forceinline__ void chained_layer(f32x16 (&acc)[kNTD], const f32x16 (&src)[NSRC], const float* __restrict__ blob,
+                                              float* lds, int& g, int tid, int wave, int lane) {
+#pragma unroll
+    for (int T = 0; T < NSRC; ++T) {
+        stream_issue(blob, lds, g + 1, tid, wave);
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = RELU ? fmaxf(src[T][r], 0.0f) : src[T][r];
+        mfma_tiles<kNTD, 0, kNTD>(acc, bv, lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane);
+        stream_sync();
+        ++g;
+    }
+}
+
+__global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane & 31, h = lane >> 5;
+    const long i_raw = (long)blockIdx.x * 128 + wave * 32 + s;
+    const bool live = i_raw < a.S;
+    const long i = live ? i_raw : a.S - 1;
+
+    // ---- tables shared by the workgroup -----------------------------------------------------------------------------
+    for (int k = tid; k < kC; k += 256) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
+    for (int k = tid; k < kBiasFloats; k += 256) lds[kLdsBias + k] = a.bias[k];
+    int g = 0;                                     // index of the weight chunk being consumed
+    stream_issue(a.blob, lds, 0, tid, wave);
+
+    // ---- geometry of this lane's sample; lane half h prepares source view h ---------------------------------------
+    const int P = a.P, V = a.V;
+    const int p = (int)(i % P);
+    const long nr = i / P;
+    const int n = (int)(nr / a.R);
+    const int v = n % V, sc = n / V;
+    const CarPose& Ps = a.poses[n];
+    const CarRay ray = a.rays[nr];
+    CarSample smp;
+    for (int k = 0; k < 2; ++k) smp.grid[k] = ray.start[k] + (ray.end[k] - ray.start[k]) * a.steps[p];
+    car_sample_setup(Ps, a.poses + sc * 2, ray, 2, a.H, a.W, &smp);   // V == 2: literal so the per-view loops unroll (no scratch)
+    {
+        const int sv = h;                                              // this lane prepares source view sv of sample s
+        float gx, gy;
+        int mode, m;
+        if (sv == v) { gx = smp.grid[0]; gy = smp.grid[1]; mode = 0; m = n; }
+        else { gx = sv == 0 ? smp.grid_in[0][0] : smp.grid_in[1][0]; gy = sv == 0 ? smp.grid_in[0][1] : smp.grid_in[1][1]; mode = 1; m = sc * V + sv; }
+        int* ti = reinterpret_cast<int*>(lds + kLdsTapI) + ((wave * 32 + s) * 2 + sv) * 12;
+        float* tw = lds + kLdsTapW + ((wave * 32 + s) * 2 + sv) * 12;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            int idx[4];
+            float w[4];
+            car_bilinear_taps(gx, gy, a.gw[l], a.gh[l], mode, idx, w);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { ti[4 * l + t] = m * a.gh[l] * a.gw[l] + idx[t]; tw[4 * l + t] = w[t]; }
+        }
+        float* pe = lds + kLdsPe + ((wave * 32 + s) * 2 + sv) * 4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pe[k] = tanhf((sv == 0 ? smp.pt_in[0][k] : smp.pt_in[1][k]) / 5.0f);
+        pe[3] = 0.0f;
+    }
+    if (live && h == 0) {
+        a.pixel_val[2 * i] = smp.grid[0]; a.pixel_val[2 * i + 1] = smp.grid[1];
+        a.pt[3 * i + 0] = smp.pt[0]; a.pt[3 * i + 1] = smp.pt[1]; a.pt[3 * i + 2] = smp.pt[2];
+    }
+    // B operand of the two K=16 layers fed by g (standard mapping: lanes 0-31 carry k = 0..15, lanes 32-63 carry the
+    // folded bias input k = 16 and zeros)
+    float gb[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gb[k] = h == 0 ? smp.g[k] : (k == 0 ? 1.0f : 0.0f);
+    __syncthreads();                                                   // tables and tap records visible
+
+    // ---- gather machinery: lane owns rows rr = (lane>>3) + 8*it (it = 0..3) and channel quad qd = lane & 7 of a chunk ----
+    const int qd = lane & 7, r0 = lane >> 3;
+    float* stage = lds + kLdsStage + wave * 32 * kStageLd;
+    float4 hacc[4];                                                    // blended taps of the chunk being gathered
+    float4 tap[16];                                                    // one level's 4 taps x 4 rows in flight
+
+    auto gather_issue = [&](int sv, int c, int l) {                    // 16 loads: level l of chunk c, source sv
+        const float* base = a.gmap[l] + 32 * c + 4 * qd;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int* ti = reinterpret_cast<const int*>(lds + kLdsTapI) + ((wave * 32 + r0 + 8 * it) * 2 + sv) * 12 + 4 * l;
+            const int4 id = *reinterpret_cast<const int4*>(ti);
+            tap[4 * it + 0] = *reinterpret_cast<const float4*>(base + (long)id.x * kC);
+            tap[4 * it + 1] = *reinterpret_cast<const float4*>(base + (long)id.y * kC);
+            tap[4 * it + 2] = *reinterpret_cast<const float4*>(base + (long)id.z * kC);
+            tap[4 * it + 3] = *reinterpret_cast<const float4*>(base + (long)id.w * kC);
+        }
+    };
+    auto gather_blend = [&](int sv, int l) {                           // consume the level's taps
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * 32 + r0 + 8 * it) * 2 + sv) * 12 + 4 * l);
+            const float ww[4] = {w.x, w.y, w.z, w.w};
+            float4 acc4 = l == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : hacc[it];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 gq = tap[4 * it + t];
+                acc4.x = fmaf(ww[t], gq.x, acc4.x); acc4.y = fmaf(ww[t], gq.y, acc4.y);
+                acc4.z = fmaf(ww[t], gq.z, acc4.z); acc4.w = fmaf(ww[t], gq.w, acc4.w);
+            }
+            hacc[it] = acc4;
+        }
+    };
+    auto gather_finish = [&](int sv, int c) {                          // point term, bias, ReLU, into the wave's h tile
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rr = r0 + 8 * it;
+            const float4 pe = *reinterpret_cast<const float4*>(lds + kLdsPe + ((wave * 32 + rr) * 2 + sv) * 4);
+            const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 4 * (32 * c + 4 * qd));
+            const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+            float4 o = hacc[it];
+            o.x += fmaf(w0.z, pe.z, fmaf(w0.y, pe.y, w0.x * pe.x)) + w0.w;
+            o.y += fmaf(w1.z, pe.z, fmaf(w1.y, pe.y, w1.x * pe.x)) + w1.w;
+            o.z += fmaf(w2.z, pe.z, fmaf(w2.y, pe.y, w2.x * pe.x)) + w2.w;
+            o.w += fmaf(w3.z, pe.z, fmaf(w3.y, pe.y, w3.x * pe.x)) + w3.w;
+            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            *reinterpret_cast<float4*>(stage + rr * kStageLd + 4 * qd) = o;
+        }
+    };
+
+    // ---- e_s = W2 h_s + b2, then immediately its share of k1 = Wk1 [e_0 ; e_1] + bk1 (chained on the accumulators), then e_s
+    //      is stored and its registers are reused for the other source.  The gather of chunk cc+1 hides under the MFMAs of cc.
+    // first chunk of source 0: nothing to hide it under
+#pragma unroll
+    for (int l = 0; l < 3; ++l) { gather_issue(0, 0, l); gather_blend(0, l); }
+    gather_finish(0, 0);
+    stream_sync();                                                     // weight chunk 0 landed
+
+    f32x16 k1[kNTD];
+    init_bias<kNTD>(k1, lds + kLdsBias + kBiasK1, h);
+    f32x16 acc[kNTE];
+#pragma unroll 1
+    for (int sv = 0; sv < 2; ++sv) {
+        init_bias<kNTE>(acc, lds + kLdsBias + kBiasE, h);
+#pragma unroll 1
+        for (int c = 0; c < kKT; ++c) {
+            stream_issue(a.blob, lds, g + 1, tid, wave);
+            float bv[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 x = *reinterpret_cast<const float4*>(stage + s * kStageLd + 16 * h + 4 * q);
+                bv[4 * q + 0] = x.x; bv[4 * q + 1] = x.y; bv[4 * q + 2] = x.z; bv[4 * q + 3] = x.w;
+            }
+            // next chunk to gather: (sv, c+1), or (1, 0) after the last chunk of source 0.  Kept branch-free on purpose (a
+            // conditional gather makes hipcc copy the in-flight tap registers at the block boundary, i.e. wait for them
+            // before the MFMAs): after the very last chunk the gather harmlessly re-reads chunk (1, 0).
+            const int nsv = (c + 1 < kKT) ? sv : 1;
+            const int nc = (c + 1 < kKT) ? c + 1 : 0;
+            const float* wl = lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane;
+            gather_issue(nsv, nc, 0);
+            mfma_tiles<kNTE, 0, 3>(acc, bv, wl);
+            gather_blend(nsv, 0);
+            gather_issue(nsv, nc, 1);
+            mfma_tiles<kNTE, 3, 3>(acc, bv, wl);
+            gather_blend(nsv, 1);
+            gather_issue(nsv, nc, 2);
+            mfma_tiles<kNTE, 6, 3>(acc, bv, wl);
+            gather_blend(nsv, 2);
+            gather_finish(nsv, nc);
+            stream_sync();
+            ++g;
+        }
+        chained_layer<kNTE, false>(k1, acc, a.blob, lds, g, tid, wave, lane);
+        if (live) store_rows<kNTE>(acc, a.e + i * (2 * kE) + sv * kE, h);
+    }
+    f32x16 key[kNTD];
+    init_bias<kNTD>(key, lds + kLdsBias + kBiasK2, h);
+    chained_layer<kNTD, true>(key, k1, a.blob, lds, g, tid, wave, lane);
+
+    // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ;  ug = Wr1[:,128:] g + br1 ---------------------
+    f32x16 t1[kNTD], qv[kNTD];
+#pragma unroll
+    for (int t = 0; t < kNTD; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t1[t][r] = 0.0f;
+    stream_issue(a.blob, lds, g + 1, tid, wave);
+    mfma_tiles<kNTD, 0, kNTD>(t1, gb, lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane);          // q1 (bias folded)
+    stream_sync();
+    ++g;
+    init_bias<kNTD>(qv, lds + kLdsBias + kBiasQ2, h);
+    chained_layer<kNTD, true>(qv, t1, a.blob, lds, g, tid, wave, lane);                          // qry
+    float dot = 0.0f;
+#pragma unroll
+    for (int t = 0; t < kNTD; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dot = fmaf(key[t][r], qv[t][r], dot);
+    dot += __shfl_xor(dot, 32, 64);                                    // the other lane half holds the other channels
+    if (live) {
+        store_rows<kNTD>(qv, a.qry + i * kD, h);
+        if (h == 0) a.logit[i] = dot / 16.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < kNTD; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t1[t][r] = 0.0f;
+    stream_issue(a.blob, lds, g + 1, tid, wave);                       // past the last chunk: no-op
+    mfma_tiles<kNTD, 0, kNTD>(t1, gb, lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane);          // ug (bias folded)
+    if (live) store_rows<kNTD>(t1, a.ug + i * kD, h);
+}
+
+}  // namespace
+
+extern "C" size_t car_fused_blob_floats(void) { return (size_t)kBlobTiles * kTile; }
+extern "C" size_t car_fused_bias_floats(void) { return (size_t)kBiasFloats; }
+
+extern "C" int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                                 const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
+                                 const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                                 float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, void* stream) {
+    CAR_REQUIRE(poses && rays && steps && gmaps && level_h && level_w && wpt && blob && bias, "car_fused_samples: null input");
+    CAR_REQUIRE(e && qry && ug && logit && pt && pixel_val, "car_fused_samples: null output");
+    CAR_REQUIRE(n_levels == 3 && C == kC && V == 2, "car_fused_samples: built for 3 pyramid levels, C = %d, V = 2 (got %d, %d, %d)", kC, n_levels, C, V);
+    CAR_REQUIRE(b > 0 && R > 0 && P > 0 && H > 1 && W > 1, "car_fused_samples: bad sizes");
+    FusedArgs a;
+    a.poses = (const CarPose*)poses; a.rays = (const CarRay*)rays; a.steps = steps;
+    for (int l = 0; l < 3; ++l) {
+        a.gmap[l] = gmaps[l]; a.gh[l] = level_h[l]; a.gw[l] = level_w[l];
+        CAR_REQUIRE(a.gmap[l] && a.gh[l] > 0 && a.gw[l] > 0 && (long)b * V * a.gh[l] * a.gw[l] < 2147483647L, "car_fused_samples: bad level %d", l);
+    }
+    a.wpt = wpt; a.blob = blob; a.bias = bias;
+    a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
+    a.S = (long)b * V * R * P;
+    a.e = e; a.qry = qry; a.ug = ug; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)fused_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e1 != hipSuccess) { car_set_error("car_fused_samples: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
+        attr_set = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(fused_sample_kernel, dim3(car_div_up(a.S, 128)), dim3(256), kLdsBytes, (hipStream_t)stream, a);
+    CAR_CHECK_LAUNCH("car_fused_samples");
+    return CAR_OK;
+}

@@ -53,6 +53,59 @@ class PackedLinear:
                    "car_linear_pack")
 
 
+def _pack_tiles(W: Tensor, bias: Optional[Tensor], n_tiles: int, chunk_k: Tensor) -> Tensor:
+    """Packs weight rows into MFMA A-operand tiles.  ``chunk_k`` (chunks, 64 lanes, 16 steps) gives, for every chunk, lane
+    and MFMA step, the input index k that lane supplies (k == K selects the bias, k > K a zero).  Result:
+    (chunks, n_tiles, 4, 64, 4) floats = [chunk][tile][j4][lane][e] with step r = 4*j4 + e, output n = 32*tile + lane%32."""
+    N, K = W.shape
+    Wext = torch.zeros(32 * n_tiles, K + 2, dtype=torch.float32)
+    Wext[:N, :K] = W
+    if bias is not None:
+        Wext[:N, K] = bias
+    chunks = chunk_k.shape[0]
+    k = chunk_k.clamp(max=K + 1)                                             # (chunks, 64, 16)
+    lane = torch.arange(64)
+    n = (32 * torch.arange(n_tiles)[:, None] + (lane % 32)[None, :])         # (tiles, 64)
+    out = Wext[n[None, :, :, None].expand(chunks, -1, -1, 16), k[:, None, :, :].expand(-1, n_tiles, -1, -1)]   # (chunks,tiles,64,16)
+    return out.reshape(chunks, n_tiles, 64, 4, 4).permute(0, 1, 3, 2, 4).contiguous()
+
+
+def _std_k(chunks: int) -> Tensor:
+    """standard mapping: chunk c, lane l, step r -> k = 32 c + 16 (l >> 5) + r"""
+    c = torch.arange(chunks)[:, None, None]
+    lane = torch.arange(64)[None, :, None]
+    r = torch.arange(16)[None, None, :]
+    return 32 * c + 16 * (lane // 32) + r
+
+
+def _chained_k(n_src_tiles: int, base: int = 0) -> Tensor:
+    """chained mapping over the accumulator layout of a 32-row tile T: k = base + 32 T + (r&3) + 8 (r>>2) + 4 (l >> 5)"""
+    T = torch.arange(n_src_tiles)[:, None, None]
+    lane = torch.arange(64)[None, :, None]
+    r = torch.arange(16)[None, None, :]
+    return base + 32 * T + (r % 4) + 8 * (r // 4) + 4 * (lane // 32)
+
+
+def pack_fused_weights(m, device):
+    """Weights of the fused per-sample kernel (csrc/car_fused.hip) in its operand order: (blob, bias table)."""
+    f = lambda t: t.detach().float().cpu().reshape(t.shape[0], -1)
+    v = lambda t: t.detach().float().cpu()
+    C = m.query_encode_latent.weight.shape[0]
+    E2 = C // 2
+    wr = f(m.query_repeat_embed.weight)
+    parts = [
+        _pack_tiles(f(m.query_encode_latent_2.weight), None, E2 // 32, _std_k(C // 32)),                      # W2
+        _pack_tiles(f(m.query_embed.weight), v(m.query_embed.bias), 4, _std_k(1)),                            # Q1 (bias folded)
+        _pack_tiles(f(m.query_embed_2.weight), None, 4, _chained_k(4)),                                       # Q2
+        _pack_tiles(wr[:, 128:].contiguous(), v(m.query_repeat_embed.bias), 4, _std_k(1)),                    # UG (bias folded)
+        torch.cat([_pack_tiles(f(m.key_map.weight), None, 4, _chained_k(E2 // 32, base=E2 * sv)) for sv in range(2)]),   # K1
+        _pack_tiles(f(m.key_map_2.weight), None, 4, _chained_k(4)),                                           # K2
+    ]
+    blob = torch.cat([p_.reshape(-1) for p_ in parts]).to(device)
+    bias = torch.cat([v(m.query_encode_latent_2.bias), v(m.query_embed_2.bias), v(m.key_map.bias), v(m.key_map_2.bias)]).to(device)
+    return blob, bias
+
+
 class RenderEngine:
     """Per-module state of the HIP path: packed weights (re-packed when the parameters change) and the
     channel-last copies of the last feature pyramid."""
@@ -71,6 +124,11 @@ class RenderEngine:
         # first point-MLP layer as a gather over per-texel pre-projected maps (csrc/car_encode.hip) instead of a
         # K=579 GEMM per sample; False selects the literal gather -> GEMM pipeline (A/B and stage tests)
         self.project_maps = True
+        # geometry + encode + 576->288 + key/query MLPs + logits as one kernel (csrc/car_fused.hip); needs V == 2, three
+        # pyramid levels, C == 576.  False keeps the stage-by-stage pipeline (A/B and stage tests)
+        self.fuse_samples = True
+        self._fused_key = None
+        self._fused = None
         self._gmaps_key = None
         self._gmaps: List[Tensor] = []
         self._wpt: Optional[Tensor] = None
@@ -163,7 +221,8 @@ class RenderEngine:
                                        flags | self.linear_flags, _stream()), "car_linear")
         if ev is not None:
             ev[1].record()
-            self.timing.setdefault(layer.name, []).append((ev[0], ev[1], M, layer.K, layer.N))
+            self.timing.setdefault(layer.name, []).append(
+                (ev[0], ev[1], 2.0 * M * (layer.K + 1) * layer.N, f"linear_kernel {layer.name}: {layer.K}->{layer.N} on {M} rows"))
 
     def gather(self, maps: List[Tensor], grid: Tensor, pts: int, mode: int, place: int, V: int, out: Tensor,
                ld_out: int, col_out: int):
@@ -218,11 +277,16 @@ class RenderEngine:
         _lib.check(lib.car_ray_setup(_ptr(poses), _ptr(uv), b, V, R, H, W, P, int(m.no_sample), _ptr(steps),
                                      _ptr(rays), _ptr(coords9), _ptr(phi_x), ld_phi, st), "car_ray_setup")
 
+        concat2 = (V == 2 and not m.no_latent_concat)
+        fused = (self.fuse_samples and self.project_maps and concat2 and not m.no_sample and len(maps) == 3 and C == 576
+                 and m.hidden_dim == 128)
+        if fused:
+            return self._render_fused(inp, z, maps, poses, rays, coords9, phi_x, ld_phi, steps, b, V, R, P, H, W, debug)
+
         # a6, a8, a9, a13: samples
         pixel_val = torch.empty(n, R, P, 2, **f32)
         pt = torch.empty(n, R, P, 3, **f32)
         g = torch.empty(S, 16, **f32)
-        concat2 = (V == 2 and not m.no_latent_concat)
         single = (V == 1 and not m.no_latent_concat)
         grid_in = torch.empty(n, R, P, V, 2, **f32) if concat2 else None
         x1 = None
@@ -283,13 +347,72 @@ class RenderEngine:
         q = torch.empty(S, 128, **f32)
         self.linear(k1, 128, pk["query_embed_2"], q, 128, S)
 
+        return self._finish(inp, z, b, V, R, P, Ce, Dl, e, key, q, None, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi,
+                            debug)
+
+    def _render_fused(self, inp, z, maps, poses, rays, coords9, phi_x, ld_phi, steps, b, V, R, P, H, W, debug):
+        m, lib = self.m, self.lib
+        dev = poses.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        S = b * V * R * P
+        gmaps, wpt = self._projected_maps(maps, dev)
+        key = tuple((p_.data_ptr(), p_._version) for p_ in (
+            m.query_encode_latent_2.weight, m.query_encode_latent_2.bias, m.query_embed.weight, m.query_embed.bias,
+            m.query_embed_2.weight, m.query_embed_2.bias, m.query_repeat_embed.weight, m.query_repeat_embed.bias,
+            m.key_map.weight, m.key_map.bias, m.key_map_2.weight, m.key_map_2.bias)) + (str(dev),)
+        if key != self._fused_key:
+            self._fused = pack_fused_weights(m, dev)
+            assert self._fused[0].numel() == lib.car_fused_blob_floats() and self._fused[1].numel() == lib.car_fused_bias_floats()
+            self._fused_key = key
+        blob, bias = self._fused
+        e = torch.empty(S, 576, **f32)
+        q = torch.empty(S, 128, **f32)
+        ug = torch.empty(S, 128, **f32)
+        logit = torch.empty(S, **f32)
+        pt = torch.empty(S, 3, **f32)
+        pixel_val = torch.empty(S, 2, **f32)
+        L = 3
+        ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in gmaps])
+        hs = (ctypes.c_int * L)(*[t.shape[1] for t in gmaps])
+        ws = (ctypes.c_int * L)(*[t.shape[2] for t in gmaps])
+        ev = None
+        if self.timing is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        _lib.check(lib.car_fused_samples(_ptr(poses), _ptr(rays), _ptr(steps), ptrs, hs, ws, L, 576, _ptr(wpt), _ptr(blob),
+                                         _ptr(bias), b, V, R, P, H, W, _ptr(e), _ptr(q), _ptr(ug), _ptr(logit), _ptr(pt),
+                                         _ptr(pixel_val), _stream()), "car_fused_samples")
+        if ev is not None:
+            ev[1].record()
+            # algorithmic MACs per sample on the matrix pipe: 2 x 576x288 (e), 576x128 + 128x128 (key), 16x128 + 128x128 (qry),
+            # 16x128 (ug); the gather FMAs and the geometry are not counted
+            macs = 2 * 576 * 288 + 576 * 128 + 128 * 128 + 16 * 128 + 128 * 128 + 16 * 128
+            self.timing.setdefault("fused_samples", []).append(
+                (ev[0], ev[1], 2.0 * S * macs, f"fused_sample_kernel on {S} samples (e, key, qry, ug, logits)"))
+        return self._finish(inp, z, b, V, R, P, 576, m.latent_dim, e, None, q, logit, ug, pt, pixel_val, poses, rays, coords9,
+                            phi_x, ld_phi, debug, ug_ready=True)
+
+    def _finish(self, inp, z, b, V, R, P, Ce, Dl, e, key, q, logit, g_or_ug, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi,
+                debug, ug_ready=False):
+        """Attention rounds, decoder and output dict.  Either (key, q) or precomputed round-1
+        logits are given; ``g_or_ug`` is the geometric query g [S,16] or, with ug_ready, Wr1[:,128:] g + br1 [S,128]."""
+        m, lib = self.m, self.lib
+        dev = e.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        st = _stream()
+        pk = self._packed
+        n, S = b * V, b * V * R * P
+        n_qry = 1
+        qry = inp["query"]
+        k1 = torch.empty(S, 128, **f32) if not ug_ready else g_or_ug
         # a14 + a16: attention round 1, depth read-out
         at_wt = torch.empty(n, R, P, **f32)
         depth = torch.empty(b, R, **f32)
         amax = torch.empty(n, R, dtype=torch.int32, device=dev)
         rep = m.repeat_attention
         ebar = torch.empty(b * R, Ce, **f32)
-        _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt), _ptr(ebar),
+        _lib.check(lib.car_attend(_ptr(key) if logit is None else _ptr(logit), _ptr(q) if logit is None else None, 128,
+                                  _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt), _ptr(ebar),
                                   Ce, 1, _ptr(pt), _ptr(poses), _ptr(depth), _ptr(amax), st), "car_attend")
         zrep = torch.empty(b * R, V * Dl, **f32)
         at_wt2 = None
@@ -301,7 +424,10 @@ class RenderEngine:
             self.linear(z1, Dl, pk["encode_latent"], hb, 128, b * R)
             uh = torch.empty(b * R, 128, **f32)
             self.linear(hb, 128, pk["query_repeat_embed.h"], uh, 128, b * R)
-            self.linear(g, 16, pk["query_repeat_embed.g"], k1, 128, S)
+            if not ug_ready:
+                self.linear(g_or_ug, 16, pk["query_repeat_embed.g"], k1, 128, S)
+            if key is None:
+                key = torch.empty(S, 128, **f32)
             _lib.check(lib.car_add_ray_bias_relu(_ptr(k1), _ptr(uh), b, V, R, P, 128, st), "car_add_ray_bias_relu")
             self.linear(k1, 128, pk["query_repeat_embed_2"], key, 128, S)
             at_wt2 = torch.empty(n, R, P, **f32)
@@ -345,10 +471,11 @@ class RenderEngine:
             "uv": qry["uv"],
             # the reference returns pixel_val on the CPU (models.py:570), forcing a device sync on every call; here it
             # stays on the device unless debug is set
-            "pixel_val": pixel_val.cpu() if debug else pixel_val,
+            "pixel_val": pixel_val.view(n, R, P, 2).cpu() if debug else pixel_val.view(n, R, P, 2),
             "z": z,
         }
         if debug:
-            out["stages"] = {"rays": rays, "pt": pt, "local_coords": g.view(n, R, P, 16), "interp_val": e.view(n, R, P, Ce),
+            out["stages"] = {"rays": rays, "pt": pt.view(n, R, P, 3),
+                             "local_coords": None if ug_ready else g_or_ug.view(n, R, P, 16), "interp_val": e.view(n, R, P, Ce),
                              "z_final": zrep[:, :Dl].reshape(b, R, Dl), "at_wt2": at_wt2, "poses": poses}
         return out

@@ -109,6 +109,20 @@ int car_gather_encode(const float* const* gmaps, const int* level_h, const int* 
                       const float* pixel_val, const float* grid_in, const float* ptenc, const float* wpt,
                       int n_maps, int V, long pts, float* out, int ld_out, void* stream);
 
+/* ---- a6-a13 + logits of a14 in ONE kernel for the default configuration (V = 2, three pyramid levels, C = 576, hidden
+ * 128): geometry, per-texel-projected encode (car_gather_encode), 576->288 per source, key MLP, query MLP, round-2
+ * local query half and the round-1 logits, with e / key / qry chained through the MFMA accumulator registers
+ * (csrc/car_fused.hip).  `blob` / `bias` are the layer weights in the kernel's operand order; their sizes are given by
+ * car_fused_blob_floats() / car_fused_bias_floats() and their layout is documented in csrc/car_fused.hip (the Python
+ * host packs them in engine.pack_fused_weights).  Outputs: e [S,576], qry [S,128], ug [S,128], logit [S], pt [S,3],
+ * pixel_val [S,2] with S = b*V*R*P. */
+size_t car_fused_blob_floats(void);
+size_t car_fused_bias_floats(void);
+int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                      const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
+                      const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                      float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, void* stream);
+
 /* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
  *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).
  * Weights are re-laid out once into the MFMA operand order by car_linear_pack (bias folded in as column K). */
@@ -118,7 +132,8 @@ int car_linear(const float* X, int ldx, const float* packed, int K, int N, float
                void* stream);
 
 /* ---- a14-a16: per-ray softmax attention over the V*P samples (models.py:532-594)
- * qa, qb [b*V,R,P,dq] (row stride dq): logit = <qa,qb>/16.  val [b*V,R,P,D].
+ * qa, qb [b*V,R,P,dq] (row stride dq): logit = <qa,qb>/16; with qb == NULL, qa is the precomputed logit [b*V,R,P]
+ * (dq ignored).  val [b*V,R,P,D].
  * w_out [b*V,R,P] softmax weights (ordered [view 1's P, view 2's P] per ray).
  * z_out [b,R,ld_z]: sum_s w_s val_s (+ zprev_scale * zprev[b,R,D] if zprev != NULL), written `reps` times
  *   side by side (the per-view replication of models.py:541, 565, 605-606).

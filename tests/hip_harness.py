@@ -33,7 +33,8 @@ def to_device(inp, device):
     return {k: {kk: vv.to(device) for kk, vv in v.items()} for k, v in inp.items()}
 
 
-def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_poses=False, project_maps=True):
+def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_poses=False, project_maps=True,
+             fuse_samples=True):
     """Returns (config, fixture, oracle output dict (CPU), HIP output dict (tensors moved to CPU)).
 
     fixture_poses=True: both sides use the relative-pose matrices stored in the fixture (the ones the reference
@@ -48,6 +49,7 @@ def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_pos
     m._engine.linear_flags = linear_flags
     m._engine.pose_records = poses
     m._engine.project_maps = project_maps
+    m._engine.fuse_samples = fuse_samples
     with torch.no_grad():
         out = m(to_device(inp, device), z=[t.to(device) for t in z], debug=debug)
     torch.cuda.synchronize()

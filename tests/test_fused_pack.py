@@ -1,0 +1,58 @@
+"""CPU check of the operand packing consumed by csrc/car_fused.hip: evaluating a layer exactly the way the kernel walks
+the packed tiles (chunk, tile, MFMA step, lane half) must reproduce W x for the standard and the chained K mappings."""
+import torch
+
+from cross_attention_renderer_amd import synthetic as S
+from cross_attention_renderer_amd.engine import pack_fused_weights
+from cross_attention_renderer_amd.models import CrossAttentionRenderer
+
+
+def _walk(tiles, x_of):
+    """tiles (chunks, n_tiles, 4, 64, 4); x_of(chunk, r, h) -> scalar B operand of lane half h at MFMA step r."""
+    chunks, nt = tiles.shape[:2]
+    y = torch.zeros(32 * nt, dtype=torch.float64)
+    for c in range(chunks):
+        for j4 in range(4):
+            for e in range(4):
+                r = 4 * j4 + e
+                for h in range(2):
+                    a = tiles[c, :, j4, 32 * h:32 * h + 32, e].double().reshape(-1)      # outputs 0..32*nt-1
+                    y += a * x_of(c, r, h)
+    return y
+
+
+def test_fused_blob_layout():
+    from cross_attention_renderer_amd import _lib
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=8).eval()
+    S.perturb_parameters(m, seed=1)
+    blob, bias = pack_fused_weights(m, "cpu")
+    lib = _lib.load()
+    assert blob.numel() == lib.car_fused_blob_floats() and bias.numel() == lib.car_fused_bias_floats()
+    g = torch.Generator().manual_seed(0)
+    T = 1024
+    perm = lambda r, h: (r & 3) + 8 * (r >> 2) + 4 * h
+    # W2: standard mapping, 18 chunks x 9 tiles
+    x = torch.randn(576, generator=g).double()
+    y = _walk(blob[:162 * T].reshape(18, 9, 4, 64, 4), lambda c, r, h: x[32 * c + 16 * h + r])
+    want = m.query_encode_latent_2.weight.detach().reshape(288, 576).double() @ x
+    assert (y - want).abs().max() < 1e-5
+    # Q1: standard, one chunk, bias folded at k = 16 (upper lane half, step 0 carries the constant 1)
+    gq = torch.randn(16, generator=g).double()
+    y = _walk(blob[162 * T:166 * T].reshape(1, 4, 4, 64, 4), lambda c, r, h: gq[r] if h == 0 else (1.0 if r == 0 else 0.0))
+    want = m.query_embed.weight.detach().reshape(128, 16).double() @ gq + m.query_embed.bias.detach().double()
+    assert (y - want).abs().max() < 1e-5
+    # Q2 / K2: chained over a 128-wide accumulator
+    for off, layer in ((166, m.query_embed_2), (258, m.key_map_2)):
+        x = torch.randn(128, generator=g).double()
+        y = _walk(blob[off * T:(off + 16) * T].reshape(4, 4, 4, 64, 4), lambda c, r, h: x[32 * c + perm(r, h)])
+        assert (y - layer.weight.detach().reshape(128, 128).double() @ x).abs().max() < 1e-5
+    # UG: standard with folded bias, the local_coords half of query_repeat_embed
+    y = _walk(blob[182 * T:186 * T].reshape(1, 4, 4, 64, 4), lambda c, r, h: gq[r] if h == 0 else (1.0 if r == 0 else 0.0))
+    wr = m.query_repeat_embed.weight.detach().reshape(128, 144).double()
+    assert (y - (wr[:, 128:] @ gq + m.query_repeat_embed.bias.detach().double())).abs().max() < 1e-5
+    # K1: chained over [e_0 ; e_1], 18 chunks x 4 tiles
+    x = torch.randn(576, generator=g).double()
+    y = _walk(blob[186 * T:258 * T].reshape(18, 4, 4, 64, 4), lambda c, r, h: x[288 * (c // 9) + 32 * (c % 9) + perm(r, h)])
+    assert (y - m.key_map.weight.detach().reshape(128, 576).double() @ x).abs().max() < 1e-5
+    # bias table order
+    assert torch.equal(bias[:288], m.query_encode_latent_2.bias.detach()) and torch.equal(bias[416:544], m.key_map.bias.detach())

@@ -108,7 +108,7 @@ def test_gather_matches_grid_sample():
 
 @pytest.mark.parametrize("name", ["t0_default", "t0_query_at_ctx0", "t0_diverging", "t1_c1", "t2_c5", "t0_no_sample", "t0_nview1"])
 def test_geometry_stages_match_oracle(name):
-    c, fx, ora, out = run_case(name)
+    c, fx, ora, out = run_case(name, fuse_samples=False)
     st, hs = ora["stages"], out["stages"]
     rays = hs["rays"]
     # with the host computing the reference's own pose algebra the device geometry reproduces the oracle to the bit,
@@ -175,15 +175,30 @@ def test_literal_gather_gemm_pipeline_matches_oracle(name):
     applies the first point-MLP layer per texel (csrc/car_encode.hip): both must sit within 1e-4 of the oracle."""
     c, fx, ora, out = run_case(name, project_maps=False)
     _check_outputs(out, lambda k: ora[k], "literal pipeline vs oracle")
-    _, _, _, out2 = run_case(name, project_maps=True)
+    _, _, _, out2 = run_case(name, project_maps=True, fuse_samples=False)
     assert rel_err(out["rgb"], out2["rgb"]) < 2e-5
     assert err_stats(out["stages"]["interp_val"], out2["stages"]["interp_val"])["max"] < 5e-5
 
 
+@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c3", "t2_c5"])
+def test_fused_sample_kernel_matches_stage_pipeline(name):
+    """A/B of csrc/car_fused.hip (geometry + encode + e + key/query MLPs + logits in one kernel, everything chained through
+    the MFMA accumulators) against the stage-by-stage kernels; both against the oracle at 1e-4."""
+    c, fx, ora, fused = run_case(name, fuse_samples=True)
+    assert fused["stages"]["local_coords"] is None, "the fused kernel was not selected"
+    _, _, _, staged = run_case(name, fuse_samples=False)
+    assert rel_err(fused["stages"]["pt"], staged["stages"]["pt"]) < 1e-6
+    assert rel_err(fused["pixel_val"], staged["pixel_val"]) < 1e-6
+    assert err_stats(fused["stages"]["interp_val"], staged["stages"]["interp_val"])["max"] < 2e-5
+    assert rel_err(fused["at_wt"], staged["at_wt"]) < 1e-5
+    assert rel_err(fused["rgb"], staged["rgb"]) < 2e-5
+    _check_outputs(fused, lambda k: ora[k], "fused vs oracle")
+
+
 def test_register_staged_weights_agree_with_lds_dma():
     """A/B of the two weight-staging variants of the MFMA kernel on a whole forward."""
-    _, _, _, a = run_case("t1_c1")
-    _, _, _, b_ = run_case("t1_c1", linear_flags=8)
+    _, _, _, a = run_case("t1_c1", fuse_samples=False)
+    _, _, _, b_ = run_case("t1_c1", linear_flags=8, fuse_samples=False)
     assert rel_err(a["rgb"], b_["rgb"]) < 1e-6
 
 

@@ -44,6 +44,8 @@ def main():
                  ("rgb vs REF", out["rgb"], fx["out_rgb"]), ("depth vs REF", out["depth_ray"], fx["out_depth_ray"]),
                  ("at_wt vs REF", out["at_wt"], fx["out_at_wt"])]
         for label, a, b_ in rows:
+            if a is None or b_ is None:
+                continue
             try:
                 print(f"    {label:14s} {fmt(err_stats(a, b_))}")
             except Exception as ex:
