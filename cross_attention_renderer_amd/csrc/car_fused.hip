@@ -226,59 +226,59 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
     // ---- gather machinery: lane owns rows rr = (lane>>3) + 8*it (it = 0..3) and channel quad qd = lane & 7 of a chunk ----
     const int qd = lane & 7, r0 = lane >> 3;
     float* stage = lds + kLdsStage + wave * 32 * kStageLd;
-    float4 hacc[4];                                                    // blended taps of the chunk being gathered
-    float4 tap[16];                                                    // one level's 4 taps x 4 rows in flight
+    float4 hacc[4];                                                    // h of the chunk being gathered, 4 rows x float4
+    float4 tapA[16], tapB[16];                                         // two levels' worth of taps (4 rows x 4 taps) in flight
 
-    auto gather_issue = [&](int sv, int c, int l) {                    // 16 loads: level l of chunk c, source sv
+    // The gather of chunk c+1 is cut into per-row pieces that are dealt out between the 36 MFMA groups of chunk c (see
+    // the slot table in the chunk loop): a wave has ONE instruction stream, so anything not sitting between two MFMAs
+    // leaves the matrix pipe idle.
+    auto issue_row = [&](float4 (&tap)[16], int sv, int c, int l, int it) {          // 4 tap loads of one row
         const float* base = a.gmap[l] + 32 * c + 4 * qd;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int* ti = reinterpret_cast<const int*>(lds + kLdsTapI) + ((wave * 32 + r0 + 8 * it) * 2 + sv) * 12 + 4 * l;
-            const int4 id = *reinterpret_cast<const int4*>(ti);
-            tap[4 * it + 0] = *reinterpret_cast<const float4*>(base + (long)id.x * kC);
-            tap[4 * it + 1] = *reinterpret_cast<const float4*>(base + (long)id.y * kC);
-            tap[4 * it + 2] = *reinterpret_cast<const float4*>(base + (long)id.z * kC);
-            tap[4 * it + 3] = *reinterpret_cast<const float4*>(base + (long)id.w * kC);
-        }
+        const int* ti = reinterpret_cast<const int*>(lds + kLdsTapI) + ((wave * 32 + r0 + 8 * it) * 2 + sv) * 12 + 4 * l;
+        const int4 id = *reinterpret_cast<const int4*>(ti);
+        tap[4 * it + 0] = *reinterpret_cast<const float4*>(base + (long)id.x * kC);
+        tap[4 * it + 1] = *reinterpret_cast<const float4*>(base + (long)id.y * kC);
+        tap[4 * it + 2] = *reinterpret_cast<const float4*>(base + (long)id.z * kC);
+        tap[4 * it + 3] = *reinterpret_cast<const float4*>(base + (long)id.w * kC);
     };
-    auto gather_blend = [&](int sv, int l) {                           // consume the level's taps
+    auto blend_row = [&](const float4 (&tap)[16], int sv, int l, int it) {           // hacc[it] += sum_t w_t tap_t
+        const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * 32 + r0 + 8 * it) * 2 + sv) * 12 + 4 * l);
+        const float ww[4] = {w.x, w.y, w.z, w.w};
+        float4 acc4 = hacc[it];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * 32 + r0 + 8 * it) * 2 + sv) * 12 + 4 * l);
-            const float ww[4] = {w.x, w.y, w.z, w.w};
-            float4 acc4 = l == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : hacc[it];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 gq = tap[4 * it + t];
-                acc4.x = fmaf(ww[t], gq.x, acc4.x); acc4.y = fmaf(ww[t], gq.y, acc4.y);
-                acc4.z = fmaf(ww[t], gq.z, acc4.z); acc4.w = fmaf(ww[t], gq.w, acc4.w);
-            }
-            hacc[it] = acc4;
+        for (int t = 0; t < 4; ++t) {
+            const float4 gq = tap[4 * it + t];
+            acc4.x = fmaf(ww[t], gq.x, acc4.x); acc4.y = fmaf(ww[t], gq.y, acc4.y);
+            acc4.z = fmaf(ww[t], gq.z, acc4.z); acc4.w = fmaf(ww[t], gq.w, acc4.w);
         }
+        hacc[it] = acc4;
     };
-    auto gather_finish = [&](int sv, int c) {                          // point term, bias, ReLU, into the wave's h tile
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rr = r0 + 8 * it;
-            const float4 pe = *reinterpret_cast<const float4*>(lds + kLdsPe + ((wave * 32 + rr) * 2 + sv) * 4);
-            const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 4 * (32 * c + 4 * qd));
-            const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
-            float4 o = hacc[it];
-            o.x += fmaf(w0.z, pe.z, fmaf(w0.y, pe.y, w0.x * pe.x)) + w0.w;
-            o.y += fmaf(w1.z, pe.z, fmaf(w1.y, pe.y, w1.x * pe.x)) + w1.w;
-            o.z += fmaf(w2.z, pe.z, fmaf(w2.y, pe.y, w2.x * pe.x)) + w2.w;
-            o.w += fmaf(w3.z, pe.z, fmaf(w3.y, pe.y, w3.x * pe.x)) + w3.w;
-            o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-            *reinterpret_cast<float4*>(stage + rr * kStageLd + 4 * qd) = o;
-        }
+    auto affine_row = [&](int sv, int c, int it) {                     // hacc[it] = Wpt tanh(pt_sv/5) + b1 (start value)
+        const int rr = r0 + 8 * it;
+        const float4 pe = *reinterpret_cast<const float4*>(lds + kLdsPe + ((wave * 32 + rr) * 2 + sv) * 4);
+        const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 4 * (32 * c + 4 * qd));
+        const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+        hacc[it] = make_float4(fmaf(w0.z, pe.z, fmaf(w0.y, pe.y, w0.x * pe.x)) + w0.w,
+                               fmaf(w1.z, pe.z, fmaf(w1.y, pe.y, w1.x * pe.x)) + w1.w,
+                               fmaf(w2.z, pe.z, fmaf(w2.y, pe.y, w2.x * pe.x)) + w2.w,
+                               fmaf(w3.z, pe.z, fmaf(w3.y, pe.y, w3.x * pe.x)) + w3.w);
+    };
+    auto finish_row = [&](int it) {                                    // ReLU, into the wave's h tile
+        const float4 o = hacc[it];
+        *reinterpret_cast<float4*>(stage + (r0 + 8 * it) * kStageLd + 4 * qd) =
+            make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
     };
 
     // ---- e_s = W2 h_s + b2, then immediately its share of k1 = Wk1 [e_0 ; e_1] + bk1 (chained on the accumulators), then e_s
     //      is stored and its registers are reused for the other source.  The gather of chunk cc+1 hides under the MFMAs of cc.
     // first chunk of source 0: nothing to hide it under
 #pragma unroll
-    for (int l = 0; l < 3; ++l) { gather_issue(0, 0, l); gather_blend(0, l); }
-    gather_finish(0, 0);
+    for (int it = 0; it < 4; ++it) {
+        affine_row(0, 0, it);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) { issue_row(tapA, 0, 0, l, it); blend_row(tapA, 0, l, it); }
+        finish_row(it);
+    }
     stream_sync();                                                     // weight chunk 0 landed
 
     f32x16 k1[kNTD];
@@ -302,16 +302,26 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
             const int nsv = (c + 1 < kKT) ? sv : 1;
             const int nc = (c + 1 < kKT) ? c + 1 : 0;
             const float* wl = lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane;
-            gather_issue(nsv, nc, 0);
-            mfma_tiles<kNTE, 0, 3>(acc, bv, wl);
-            gather_blend(nsv, 0);
-            gather_issue(nsv, nc, 1);
-            mfma_tiles<kNTE, 3, 3>(acc, bv, wl);
-            gather_blend(nsv, 1);
-            gather_issue(nsv, nc, 2);
-            mfma_tiles<kNTE, 6, 3>(acc, bv, wl);
-            gather_blend(nsv, 2);
-            gather_finish(nsv, nc);
+            // 36 groups of (one ds_read_b128 of weights + 4 dependent MFMAs); between them, one piece of the next chunk's
+            // gather.  Slot table (level 2 = full resolution, the slowest to arrive, goes first):
+            //   0-3 issue L2 -> tapA      4-7 affine start values     12-15 issue L1 -> tapB     16-19 blend L2 (tapA)
+            //   24-27 issue L0 -> tapA    28-31 blend L1 (tapB)       32-35 blend L0 (tapA), then ReLU + LDS write
+#pragma unroll
+            for (int gq = 0; gq < 36; ++gq) {
+                const int j4 = gq / 9, t = gq % 9;
+                const float4 aw = *reinterpret_cast<const float4*>(wl + (t * 4 + j4) * 256);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, bv[4 * j4 + 0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, bv[4 * j4 + 1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, bv[4 * j4 + 2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, bv[4 * j4 + 3], acc[t], 0, 0, 0);
+                if (gq < 4) issue_row(tapA, nsv, nc, 2, gq);
+                else if (gq < 8) affine_row(nsv, nc, gq - 4);
+                else if (gq >= 12 && gq < 16) issue_row(tapB, nsv, nc, 1, gq - 12);
+                else if (gq >= 16 && gq < 20) blend_row(tapA, nsv, 2, gq - 16);
+                else if (gq >= 24 && gq < 28) issue_row(tapA, nsv, nc, 0, gq - 24);
+                else if (gq >= 28 && gq < 32) blend_row(tapB, nsv, 1, gq - 28);
+                else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
+            }
             stream_sync();
             ++g;
         }

@@ -189,7 +189,7 @@ def test_fused_sample_kernel_matches_stage_pipeline(name):
     _, _, _, staged = run_case(name, fuse_samples=False)
     assert rel_err(fused["stages"]["pt"], staged["stages"]["pt"]) < 1e-6
     assert rel_err(fused["pixel_val"], staged["pixel_val"]) < 1e-6
-    assert err_stats(fused["stages"]["interp_val"], staged["stages"]["interp_val"])["max"] < 2e-5
+    assert err_stats(fused["stages"]["interp_val"], staged["stages"]["interp_val"])["max"] < 5e-5
     assert rel_err(fused["at_wt"], staged["at_wt"]) < 1e-5
     assert rel_err(fused["rgb"], staged["rgb"]) < 2e-5
     _check_outputs(fused, lambda k: ora[k], "fused vs oracle")
