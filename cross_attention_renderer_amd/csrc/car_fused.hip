@@ -109,6 +109,18 @@ __device__ __forceinline__ void stream_issue(const float* __restrict__ blob, flo
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
     }
 }
+// one tile (4 KB) of weight chunk g: used to deal the DMA issue out between MFMA groups instead of paying ~300 cycles of
+// scalar/address work at every chunk boundary.  Must only run after the barrier that ended chunk g - 2.
+__device__ __forceinline__ void stream_issue_tile(const float* __restrict__ blob, float* lds, int g, int t, int tid, int wave) {
+    if (g >= kNumChunks || t >= chunk_tiles(g)) return;
+    const float* src = blob + (long)chunk_tile_offset(g) * kTile;
+    float* dst = lds + kLdsW + (g & 1) * kNTE * kTile;
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(dst + 4 * (t * 256 + wave * 64)));
+    const float* gsrc = src + 4 * (t * 256 + tid);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 // end of a chunk: the DMA of the next chunk has landed and every wave is done reading the current one
 __device__ __forceinline__ void stream_sync() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -156,11 +168,20 @@ __device__ __forceinline__ void chained_layer(f32x16 (&acc)[kNTD], const f32x16 
                                               float* lds, int& g, int tid, int wave, int lane) {
 #pragma unroll
     for (int T = 0; T < NSRC; ++T) {
-        stream_issue(blob, lds, g + 1, tid, wave);
         float bv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) bv[r] = RELU ? fmaxf(src[T][r], 0.0f) : src[T][r];
-        mfma_tiles<kNTD, 0, kNTD>(acc, bv, lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane);
+        const float* wl = lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane;
+#pragma unroll
+        for (int gq = 0; gq < 4 * kNTD; ++gq) {
+            const int j4 = gq / kNTD, t = gq % kNTD;
+            const float4 aw = *reinterpret_cast<const float4*>(wl + (t * 4 + j4) * 256);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, bv[4 * j4 + 0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, bv[4 * j4 + 1], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, bv[4 * j4 + 2], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, bv[4 * j4 + 3], acc[t], 0, 0, 0);
+            if (gq < kNTE) stream_issue_tile(blob, lds, g + 1, gq, tid, wave);       // next chunk may have up to 9 tiles
+        }
         stream_sync();
         ++g;
     }
@@ -284,18 +305,17 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
     f32x16 k1[kNTD];
     init_bias<kNTD>(k1, lds + kLdsBias + kBiasK1, h);
     f32x16 acc[kNTE];
+    float bv[16];                                                      // B operands of the current chunk (this lane's 16 channels)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(stage + s * kStageLd + 16 * h + 4 * q);
+        bv[4 * q + 0] = x.x; bv[4 * q + 1] = x.y; bv[4 * q + 2] = x.z; bv[4 * q + 3] = x.w;
+    }
 #pragma unroll 1
     for (int sv = 0; sv < 2; ++sv) {
         init_bias<kNTE>(acc, lds + kLdsBias + kBiasE, h);
 #pragma unroll 1
         for (int c = 0; c < kKT; ++c) {
-            stream_issue(a.blob, lds, g + 1, tid, wave);
-            float bv[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 x = *reinterpret_cast<const float4*>(stage + s * kStageLd + 16 * h + 4 * q);
-                bv[4 * q + 0] = x.x; bv[4 * q + 1] = x.y; bv[4 * q + 2] = x.z; bv[4 * q + 3] = x.w;
-            }
             // next chunk to gather: (sv, c+1), or (1, 0) after the last chunk of source 0.  Kept branch-free on purpose (a
             // conditional gather makes hipcc copy the in-flight tap registers at the block boundary, i.e. wait for them
             // before the MFMAs): after the very last chunk the gather harmlessly re-reads chunk (1, 0).
@@ -303,9 +323,10 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
             const int nc = (c + 1 < kKT) ? c + 1 : 0;
             const float* wl = lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane;
             // 36 groups of (one ds_read_b128 of weights + 4 dependent MFMAs); between them, one piece of the next chunk's
-            // gather.  Slot table (level 2 = full resolution, the slowest to arrive, goes first):
-            //   0-3 issue L2 -> tapA      4-7 affine start values     12-15 issue L1 -> tapB     16-19 blend L2 (tapA)
-            //   24-27 issue L0 -> tapA    28-31 blend L1 (tapB)       32-35 blend L0 (tapA), then ReLU + LDS write
+            // gather or of the next weight chunk's DMA issue.  Slot table (level 2 = full resolution, the slowest to
+            // arrive, goes first):
+            //   0-3 issue L2 -> tapA    4-12 DMA tile 0..8    4-7 affine start values    12-15 issue L1 -> tapB
+            //   16-19 blend L2 (tapA)   20-23 issue L0 -> tapA    28-31 blend L1 (tapB)   32-35 blend L0, ReLU, LDS write
 #pragma unroll
             for (int gq = 0; gq < 36; ++gq) {
                 const int j4 = gq / 9, t = gq % 9;
@@ -314,13 +335,21 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, bv[4 * j4 + 1], acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, bv[4 * j4 + 2], acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, bv[4 * j4 + 3], acc[t], 0, 0, 0);
+                if (gq >= 4 && gq < 13) stream_issue_tile(a.blob, lds, g + 1, gq - 4, tid, wave);
                 if (gq < 4) issue_row(tapA, nsv, nc, 2, gq);
                 else if (gq < 8) affine_row(nsv, nc, gq - 4);
                 else if (gq >= 12 && gq < 16) issue_row(tapB, nsv, nc, 1, gq - 12);
                 else if (gq >= 16 && gq < 20) blend_row(tapA, nsv, 2, gq - 16);
-                else if (gq >= 24 && gq < 28) issue_row(tapA, nsv, nc, 0, gq - 24);
+                else if (gq >= 20 && gq < 24) issue_row(tapA, nsv, nc, 0, gq - 20);
                 else if (gq >= 28 && gq < 32) blend_row(tapB, nsv, 1, gq - 28);
                 else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
+            }
+            // B operands of the next chunk: this wave's own LDS tile, written just above (LDS ops of a wave are in order);
+            // read before the barrier so the latency overlaps it
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 x = *reinterpret_cast<const float4*>(stage + s * kStageLd + 16 * h + 4 * q);
+                bv[4 * q + 0] = x.x; bv[4 * q + 1] = x.y; bv[4 * q + 2] = x.z; bv[4 * q + 3] = x.w;
             }
             stream_sync();
             ++g;
