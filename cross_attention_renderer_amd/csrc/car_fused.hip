@@ -23,6 +23,7 @@
 // fp64 geometry, LDS traffic) fits in its shadow; the kernel is matrix-pipe bound on 0.89 MFLOP per sample.
 #include "car_common.h"
 #include "car_geom.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -72,6 +73,7 @@ struct FusedArgs {
     const float* blob;       // kBlobTiles * 1024 floats
     const float* bias;       // kBiasFloats
     int b, V, R, P, H, W;
+    int xcd_bands;           // 1: remap workgroups so each XCD gets a contiguous band of rays
     long S;                  // b*V*R*P samples
     float* e;                // [S, 576]
     float* qry;              // [S, 128]
@@ -109,20 +111,35 @@ __device__ __forceinline__ void stream_issue(const float* __restrict__ blob, flo
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
     }
 }
-// one tile (4 KB) of weight chunk g: used to deal the DMA issue out between MFMA groups instead of paying ~300 cycles of
-// scalar/address work at every chunk boundary.  Must only run after the barrier that ended chunk g - 2.
-__device__ __forceinline__ void stream_issue_tile(const float* __restrict__ blob, float* lds, int g, int t, int tid, int wave) {
-    if (g >= kNumChunks || t >= chunk_tiles(g)) return;
-    const float* src = blob + (long)chunk_tile_offset(g) * kTile;
-    float* dst = lds + kLdsW + (g & 1) * kNTE * kTile;
-    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(dst + 4 * (t * 256 + wave * 64)));
-    const float* gsrc = src + 4 * (t * 256 + tid);
+// Descriptor of the weight chunk to prefetch, resolved ONCE per chunk (scalar code with branches) so that the per-tile
+// issue below is straight-line code: a branch inside the unrolled MFMA body splits it into basic blocks and pins the
+// gather/DMA pieces (and their waits) to the block boundaries.
+struct NextChunk { const float* src; float* dst; int nt; };
+__device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, float* lds, int g) {
+    const int ge = g < kNumChunks ? g : kNumChunks - 1;            // past the end: re-copy the last chunk onto itself (same bytes)
+    NextChunk n;
+    n.src = blob + (long)chunk_tile_offset(ge) * kTile;
+    n.dst = lds + kLdsW + (ge & 1) * kNTE * kTile;
+    n.nt = chunk_tiles(ge);
+    return n;
+}
+// one tile (4 KB) of the next weight chunk; t may exceed the chunk's tile count, then an earlier tile is copied again
+// (identical bytes, harmless).  Must only run after the barrier that ended the chunk which last used that buffer.
+template <int ABL = 0>
+__device__ __forceinline__ void stream_issue_tile(const NextChunk& n, int t, int tid, int wave) {
+    if constexpr (ABL == 3) return;
+    int te = t < n.nt ? t : t - n.nt;
+    te = te < n.nt ? te : te - n.nt;
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(n.dst + 4 * (te * 256 + wave * 64)));
+    const float* gsrc = n.src + 4 * (te * 256 + tid);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 // end of a chunk: the DMA of the next chunk has landed and every wave is done reading the current one
+template <int ABL = 0>
 __device__ __forceinline__ void stream_sync() {
+    if constexpr (ABL == 3) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
@@ -163,7 +180,7 @@ __device__ __forceinline__ void store_rows(const f32x16 (&acc)[NT], float* row, 
 }
 
 // one chained layer with 128 outputs: B operands are the NSRC x 16 registers of `src` (optionally through ReLU)
-template <int NSRC, bool RELU>
+template <int NSRC, bool RELU, int ABL = 0>
 __device__ __forceinline__ void chained_layer(f32x16 (&acc)[kNTD], const f32x16 (&src)[NSRC], const float* __restrict__ blob,
                                               float* lds, int& g, int tid, int wave, int lane) {
 #pragma unroll
@@ -172,26 +189,46 @@ __device__ __forceinline__ void chained_layer(f32x16 (&acc)[kNTD], const f32x16 
 #pragma unroll
         for (int r = 0; r < 16; ++r) bv[r] = RELU ? fmaxf(src[T][r], 0.0f) : src[T][r];
         const float* wl = lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane;
+        const NextChunk nx = next_chunk(blob, lds, g + 1);
+        // slots are pinned with sched_barrier(0) (hipcc otherwise regroups the pieces and shrinks the latency slack they
+        // were placed for); the A operand of the next group is therefore read one slot ahead by hand
+        float4 aw = *reinterpret_cast<const float4*>(wl);
 #pragma unroll
         for (int gq = 0; gq < 4 * kNTD; ++gq) {
             const int j4 = gq / kNTD, t = gq % kNTD;
-            const float4 aw = *reinterpret_cast<const float4*>(wl + (t * 4 + j4) * 256);
+            const int gn = gq + 1 < 4 * kNTD ? gq + 1 : gq;
+            const float4 an = *reinterpret_cast<const float4*>(wl + ((gn % kNTD) * 4 + gn / kNTD) * 256);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, bv[4 * j4 + 0], acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, bv[4 * j4 + 1], acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, bv[4 * j4 + 2], acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, bv[4 * j4 + 3], acc[t], 0, 0, 0);
-            if (gq < kNTE) stream_issue_tile(blob, lds, g + 1, gq, tid, wave);       // next chunk may have up to 9 tiles
+            if (gq < kNTE) stream_issue_tile<ABL>(nx, gq, tid, wave);                // next chunk may have up to 9 tiles
+            aw = an;
+            __builtin_amdgcn_sched_barrier(0);
         }
-        stream_sync();
+        stream_sync<ABL>();
         ++g;
     }
 }
 
+// ABL > 0 are timing-only ablations (results are wrong by construction), selected with CAR_FUSED_ABLATE for tools/bench_fused.py:
+//   1 no tap loads   2 no gather work at all   3 = 2 + no weight DMA / barriers   4 = 0 but without the chained layers
+//   5 / 6 / 7 no tap loads of pyramid level 2 / 1 / 0
+template <int ABL, int SCHED = 0>
 __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 31, h = lane >> 5;
-    const long i_raw = (long)blockIdx.x * 128 + wave * 32 + s;
+    // XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only), so give every XCD
+    // a contiguous band of sample groups (= consecutive rays = neighbouring epipolar lines): each private L2 then holds
+    // its own band's texels instead of one eighth of everybody's.
+    const int nblk = gridDim.x;
+    int blk = blockIdx.x;
+    if (a.xcd_bands) {
+        const int q8 = nblk / 8, r8 = nblk % 8, xcd = blk % 8, idx = blk / 8;
+        blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;     // bijective for any grid size
+    }
+    const long i_raw = (long)blk * 128 + wave * 32 + s;
     const bool live = i_raw < a.S;
     const long i = live ? i_raw : a.S - 1;
 
@@ -254,6 +291,8 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
     // the slot table in the chunk loop): a wave has ONE instruction stream, so anything not sitting between two MFMAs
     // leaves the matrix pipe idle.
     auto issue_row = [&](float4 (&tap)[16], int sv, int c, int l, int it) {          // 4 tap loads of one row
+        if constexpr (ABL == 1 || ABL == 2 || ABL == 3) return;
+        if constexpr (ABL >= 5 && ABL <= 7) { if (l == 7 - ABL) return; }              // 5: no level-2 taps, 6: no level 1, 7: no level 0
         const float* base = a.gmap[l] + 32 * c + 4 * qd;
         const int* ti = reinterpret_cast<const int*>(lds + kLdsTapI) + ((wave * 32 + r0 + 8 * it) * 2 + sv) * 12 + 4 * l;
         const int4 id = *reinterpret_cast<const int4*>(ti);
@@ -263,6 +302,7 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
         tap[4 * it + 3] = *reinterpret_cast<const float4*>(base + (long)id.w * kC);
     };
     auto blend_row = [&](const float4 (&tap)[16], int sv, int l, int it) {           // hacc[it] += sum_t w_t tap_t
+        if constexpr (ABL == 2 || ABL == 3) return;
         const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * 32 + r0 + 8 * it) * 2 + sv) * 12 + 4 * l);
         const float ww[4] = {w.x, w.y, w.z, w.w};
         float4 acc4 = hacc[it];
@@ -275,6 +315,7 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
         hacc[it] = acc4;
     };
     auto affine_row = [&](int sv, int c, int it) {                     // hacc[it] = Wpt tanh(pt_sv/5) + b1 (start value)
+        if constexpr (ABL == 2 || ABL == 3) return;
         const int rr = r0 + 8 * it;
         const float4 pe = *reinterpret_cast<const float4*>(lds + kLdsPe + ((wave * 32 + rr) * 2 + sv) * 4);
         const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 4 * (32 * c + 4 * qd));
@@ -285,6 +326,7 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
                                fmaf(w3.z, pe.z, fmaf(w3.y, pe.y, w3.x * pe.x)) + w3.w);
     };
     auto finish_row = [&](int it) {                                    // ReLU, into the wave's h tile
+        if constexpr (ABL == 2 || ABL == 3) return;
         const float4 o = hacc[it];
         *reinterpret_cast<float4*>(stage + (r0 + 8 * it) * kStageLd + 4 * qd) =
             make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
@@ -322,27 +364,53 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
             const int nsv = (c + 1 < kKT) ? sv : 1;
             const int nc = (c + 1 < kKT) ? c + 1 : 0;
             const float* wl = lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane;
+            const NextChunk nx = next_chunk(a.blob, lds, g + 1);
             // 36 groups of (one ds_read_b128 of weights + 4 dependent MFMAs); between them, one piece of the next chunk's
             // gather or of the next weight chunk's DMA issue.  Slot table (level 2 = full resolution, the slowest to
             // arrive, goes first):
             //   0-3 issue L2 -> tapA    4-12 DMA tile 0..8    4-7 affine start values    12-15 issue L1 -> tapB
             //   16-19 blend L2 (tapA)   20-23 issue L0 -> tapA    28-31 blend L1 (tapB)   32-35 blend L0, ReLU, LDS write
+            float4 aw = *reinterpret_cast<const float4*>(wl);
 #pragma unroll
             for (int gq = 0; gq < 36; ++gq) {
                 const int j4 = gq / 9, t = gq % 9;
-                const float4 aw = *reinterpret_cast<const float4*>(wl + (t * 4 + j4) * 256);
+                const int gn = gq + 1 < 36 ? gq + 1 : gq;
+                const float4 an = *reinterpret_cast<const float4*>(wl + ((gn % 9) * 4 + gn / 9) * 256);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, bv[4 * j4 + 0], acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, bv[4 * j4 + 1], acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, bv[4 * j4 + 2], acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, bv[4 * j4 + 3], acc[t], 0, 0, 0);
-                if (gq >= 4 && gq < 13) stream_issue_tile(a.blob, lds, g + 1, gq - 4, tid, wave);
-                if (gq < 4) issue_row(tapA, nsv, nc, 2, gq);
-                else if (gq < 8) affine_row(nsv, nc, gq - 4);
-                else if (gq >= 12 && gq < 16) issue_row(tapB, nsv, nc, 1, gq - 12);
-                else if (gq >= 16 && gq < 20) blend_row(tapA, nsv, 2, gq - 16);
-                else if (gq >= 20 && gq < 24) issue_row(tapA, nsv, nc, 0, gq - 20);
-                else if (gq >= 28 && gq < 32) blend_row(tapB, nsv, 1, gq - 28);
-                else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
+                if constexpr (SCHED == 0) {
+                    if (gq >= 4 && gq < 13) stream_issue_tile<ABL>(nx, gq - 4, tid, wave);
+                    if (gq < 4) issue_row(tapA, nsv, nc, 2, gq);
+                    else if (gq < 8) affine_row(nsv, nc, gq - 4);
+                    else if (gq >= 12 && gq < 16) issue_row(tapB, nsv, nc, 1, gq - 12);
+                    else if (gq >= 16 && gq < 20) blend_row(tapA, nsv, 2, gq - 16);
+                    else if (gq >= 20 && gq < 24) issue_row(tapA, nsv, nc, 0, gq - 20);
+                    else if (gq >= 28 && gq < 32) blend_row(tapB, nsv, 1, gq - 28);
+                    else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
+                } else if constexpr (SCHED == 1) {
+                    // both big levels ahead of the DMA in the wave's in-order VMEM queue
+                    if (gq >= 8 && gq < 17) stream_issue_tile<ABL>(nx, gq - 8, tid, wave);
+                    if (gq < 4) issue_row(tapA, nsv, nc, 2, gq);
+                    else if (gq < 8) issue_row(tapB, nsv, nc, 1, gq - 4);
+                    else if (gq < 12) affine_row(nsv, nc, gq - 8);
+                    else if (gq >= 16 && gq < 20) blend_row(tapA, nsv, 2, gq - 16);
+                    else if (gq >= 20 && gq < 24) issue_row(tapA, nsv, nc, 0, gq - 20);
+                    else if (gq >= 24 && gq < 28) blend_row(tapB, nsv, 1, gq - 24);
+                    else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
+                } else {
+                    // DMA first (3 tiles per slot), every tap batch 16 slots ahead of its consumer except level 0
+                    if (gq < 3) { stream_issue_tile<ABL>(nx, 3 * gq, tid, wave); stream_issue_tile<ABL>(nx, 3 * gq + 1, tid, wave); stream_issue_tile<ABL>(nx, 3 * gq + 2, tid, wave); }
+                    else if (gq < 7) issue_row(tapA, nsv, nc, 2, gq - 3);
+                    else if (gq < 11) issue_row(tapB, nsv, nc, 1, gq - 7);
+                    else if (gq < 15) affine_row(nsv, nc, gq - 11);
+                    else if (gq >= 20 && gq < 24) blend_row(tapA, nsv, 2, gq - 20);
+                    else if (gq >= 24 && gq < 28) { issue_row(tapA, nsv, nc, 0, gq - 24); blend_row(tapB, nsv, 1, gq - 24); }
+                    else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
+                }
+                aw = an;
+                __builtin_amdgcn_sched_barrier(0);       // pin the slot (see chained_layer)
             }
             // B operands of the next chunk: this wave's own LDS tile, written just above (LDS ops of a wave are in order);
             // read before the barrier so the latency overlaps it
@@ -351,15 +419,17 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
                 const float4 x = *reinterpret_cast<const float4*>(stage + s * kStageLd + 16 * h + 4 * q);
                 bv[4 * q + 0] = x.x; bv[4 * q + 1] = x.y; bv[4 * q + 2] = x.z; bv[4 * q + 3] = x.w;
             }
-            stream_sync();
+            stream_sync<ABL>();
             ++g;
         }
-        chained_layer<kNTE, false>(k1, acc, a.blob, lds, g, tid, wave, lane);
+        if constexpr (ABL == 4) { g += kNTE; }
+        else chained_layer<kNTE, false, ABL>(k1, acc, a.blob, lds, g, tid, wave, lane);
         if (live) store_rows<kNTE>(acc, a.e + i * (2 * kE) + sv * kE, h);
     }
     f32x16 key[kNTD];
     init_bias<kNTD>(key, lds + kLdsBias + kBiasK2, h);
-    chained_layer<kNTD, true>(key, k1, a.blob, lds, g, tid, wave, lane);
+    if constexpr (ABL != 4) chained_layer<kNTD, true, ABL>(key, k1, a.blob, lds, g, tid, wave, lane);
+    else g += 4;
 
     // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ;  ug = Wr1[:,128:] g + br1 ---------------------
     f32x16 t1[kNTD], qv[kNTD];
@@ -372,7 +442,8 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
     stream_sync();
     ++g;
     init_bias<kNTD>(qv, lds + kLdsBias + kBiasQ2, h);
-    chained_layer<kNTD, true>(qv, t1, a.blob, lds, g, tid, wave, lane);                          // qry
+    if constexpr (ABL != 4) chained_layer<kNTD, true, ABL>(qv, t1, a.blob, lds, g, tid, wave, lane);   // qry
+    else g += 4;
     float dot = 0.0f;
 #pragma unroll
     for (int t = 0; t < kNTD; ++t)
@@ -414,15 +485,20 @@ extern "C" int car_fused_samples(const float* poses, const float* rays, const fl
     a.wpt = wpt; a.blob = blob; a.bias = bias;
     a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
     a.S = (long)b * V * R * P;
+    const char* xb = getenv("CAR_FUSED_XCD_BANDS");
+    a.xcd_bands = xb ? atoi(xb) : 1;
     a.e = e; a.qry = qry; a.ug = ug; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)fused_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        if (e1 != hipSuccess) { car_set_error("car_fused_samples: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
-        attr_set = true;
-    }
+    const char* abl_env = getenv("CAR_FUSED_ABLATE");
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    const char* sch_env = getenv("CAR_FUSED_SCHED");
+    const int sch = sch_env ? atoi(sch_env) : 1;
+    void (*kern)(const FusedArgs) = (abl == 0 && sch == 1) ? fused_sample_kernel<0, 1> : (abl == 0 && sch == 2) ? fused_sample_kernel<0, 2> : (abl == 0 && sch == 0) ? fused_sample_kernel<0, 0> : abl == 1 ? fused_sample_kernel<1> : abl == 2 ? fused_sample_kernel<2> : abl == 3 ? fused_sample_kernel<3>
+                                    : abl == 4 ? fused_sample_kernel<4> : abl == 5 ? fused_sample_kernel<5> : abl == 6 ? fused_sample_kernel<6>
+                                    : abl == 7 ? fused_sample_kernel<7> : fused_sample_kernel<0>;
+    hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e1 != hipSuccess) { car_set_error("car_fused_samples: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(fused_sample_kernel, dim3(car_div_up(a.S, 128)), dim3(256), kLdsBytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3(car_div_up(a.S, 128)), dim3(256), kLdsBytes, (hipStream_t)stream, a);
     CAR_CHECK_LAUNCH("car_fused_samples");
     return CAR_OK;
 }
