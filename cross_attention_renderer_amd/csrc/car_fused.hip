@@ -47,7 +47,7 @@ constexpr int kOffUG = kOffQ2 + 4 * kNTD;          // 1 chunk x 4 tiles, standar
 constexpr int kOffK1 = kOffUG + kNTD;              // 18 chunks x 4 tiles, chained over [e_0 ; e_1]
 constexpr int kOffK2 = kOffK1 + 2 * kNTE * kNTD;   // 4 chunks x 4 tiles, chained
 constexpr int kBlobTiles = kOffK2 + 4 * kNTD;
-constexpr int kNumChunks = 2 * kKT + 1 + 4 + 1 + 2 * kNTE + 4;       // 64 weight chunks per 128-sample pass
+constexpr int kNumChunks = 2 * kKT + 2 * 5 + 2 + 1 + 2 + 1;           // 52 weight chunks per 128-sample pass
 
 // bias table (floats): b2[288] | bq2[128] | bk1[128] | bk2[128]
 constexpr int kBiasE = 0, kBiasQ2 = kE, kBiasK1 = kE + kD, kBiasK2 = kE + 2 * kD, kBiasFloats = kE + 3 * kD;
@@ -83,18 +83,29 @@ struct FusedArgs {
     float* pixel_val;        // [S, 2]
 };
 
-// consumption order: W2 x18 (source 0) | K1 x9 (e_0 block) | W2 x18 (source 1) | K1 x9 (e_1 block) | K2 x4 | Q1 | Q2 x4 | UG
+// consumption order (a "chunk" is what one LDS buffer holds between two barriers):
+//   W2 x18 (source 0, 9 tiles) | K1 over e_0 x5 (source tiles {0,1},{2,3},{4,5},{6,7},{8}: 8,8,8,8,4 tiles) | W2 x18 (source 1) |
+//   K1 over e_1 x5 | K2 x2 (8 tiles) | Q1 (4) | Q2 x2 (8) | UG (4)
+// The chained layers take two 32-row source tiles per chunk so that a chunk lasts >= 8192 matrix cycles: an LDS-DMA needs
+// ~1.1 us from issue to landing, which a 4096-cycle chunk cannot hide.
+constexpr int kChK1 = 5;                                   // chunks per K1 half
+constexpr int kG_K1a = kKT, kG_W2b = kG_K1a + kChK1, kG_K1b = kG_W2b + kKT, kG_K2 = kG_K1b + kChK1, kG_Q1 = kG_K2 + 2,
+              kG_Q2 = kG_Q1 + 1, kG_UG = kG_Q2 + 2;
 __device__ __forceinline__ int chunk_tile_offset(int g) {
-    if (g < 18) return kOffW2 + g * kNTE;
-    if (g < 27) return kOffK1 + (g - 18) * kNTD;
-    if (g < 45) return kOffW2 + (g - 27) * kNTE;
-    if (g < 54) return kOffK1 + (9 + g - 45) * kNTD;
-    if (g < 58) return kOffK2 + (g - 54) * kNTD;
-    if (g < 59) return kOffQ1;
-    if (g < 63) return kOffQ2 + (g - 59) * kNTD;
+    if (g < kG_K1a) return kOffW2 + g * kNTE;
+    if (g < kG_W2b) return kOffK1 + (g - kG_K1a) * 2 * kNTD;
+    if (g < kG_K1b) return kOffW2 + (g - kG_W2b) * kNTE;
+    if (g < kG_K2) return kOffK1 + kNTE * kNTD + (g - kG_K1b) * 2 * kNTD;
+    if (g < kG_Q1) return kOffK2 + (g - kG_K2) * 2 * kNTD;
+    if (g < kG_Q2) return kOffQ1;
+    if (g < kG_UG) return kOffQ2 + (g - kG_Q2) * 2 * kNTD;
     return kOffUG;
 }
-__device__ __forceinline__ int chunk_tiles(int g) { return (g < 18 || (g >= 27 && g < 45)) ? kNTE : kNTD; }
+__device__ __forceinline__ int chunk_tiles(int g) {
+    if (g < kG_K1a || (g >= kG_W2b && g < kG_K1b)) return kNTE;
+    if (g == kG_W2b - 1 || g == kG_K2 - 1 || g == kG_Q1 || g == kG_UG) return kNTD;       // odd last K1 tile, Q1, UG
+    return 2 * kNTD;
+}
 
 // LDS-DMA of weight chunk g into buffer (g & 1): every wave copies a quarter of every tile (see car_linear.hip for why
 // this is inline asm).  Nothing is issued past the last chunk.
@@ -184,27 +195,42 @@ template <int NSRC, bool RELU, int ABL = 0>
 __device__ __forceinline__ void chained_layer(f32x16 (&acc)[kNTD], const f32x16 (&src)[NSRC], const float* __restrict__ blob,
                                               float* lds, int& g, int tid, int wave, int lane) {
 #pragma unroll
-    for (int T = 0; T < NSRC; ++T) {
-        float bv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bv[r] = RELU ? fmaxf(src[T][r], 0.0f) : src[T][r];
+    for (int T0 = 0; T0 < NSRC; T0 += 2) {
+        constexpr int kG = 4 * kNTD;                                   // MFMA groups per source tile
+        const int nsrc = T0 + 1 < NSRC ? 2 : 1;
         const float* wl = lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane;
         const NextChunk nx = next_chunk(blob, lds, g + 1);
         // slots are pinned with sched_barrier(0) (hipcc otherwise regroups the pieces and shrinks the latency slack they
         // were placed for); the A operand of the next group is therefore read one slot ahead by hand
-        float4 aw = *reinterpret_cast<const float4*>(wl);
+        float4 aw[kNTD];
 #pragma unroll
-        for (int gq = 0; gq < 4 * kNTD; ++gq) {
-            const int j4 = gq / kNTD, t = gq % kNTD;
-            const int gn = gq + 1 < 4 * kNTD ? gq + 1 : gq;
-            const float4 an = *reinterpret_cast<const float4*>(wl + ((gn % kNTD) * 4 + gn / kNTD) * 256);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, bv[4 * j4 + 0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, bv[4 * j4 + 1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, bv[4 * j4 + 2], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, bv[4 * j4 + 3], acc[t], 0, 0, 0);
-            if (gq < kNTE) stream_issue_tile<ABL>(nx, gq, tid, wave);                // next chunk may have up to 9 tiles
-            aw = an;
-            __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < kNTD; ++t) aw[t] = *reinterpret_cast<const float4*>(wl + (t * 4) * 256);
+        // (source tile Tl, step group j4, step e, out tile t): round-robin over the 4 out tiles, see the e-path loop
+#pragma unroll
+        for (int Tl = 0; Tl < 2; ++Tl)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < kNTD; ++t) {
+            const int mi = Tl * 4 * kG + j4 * 4 * kNTD + e * kNTD + t;
+            if (mi < nsrc * 4 * kG) {
+            const f32x16& sv = src[T0 + Tl < NSRC ? T0 + Tl : NSRC - 1];
+            float bq = sv[4 * j4 + e];
+            if (RELU) bq = fmaxf(bq, 0.f);
+            const float av = e == 0 ? aw[t].x : e == 1 ? aw[t].y : e == 2 ? aw[t].z : aw[t].w;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq, acc[t], 0, 0, 0);
+            if (e == 3) {                                              // refresh tile t's A operand for its next step group
+                const int nj = j4 + 1 < 4 ? j4 + 1 : 0, nT = j4 + 1 < 4 ? Tl : Tl + 1;
+                if (nT < nsrc) aw[t] = *reinterpret_cast<const float4*>(wl + ((nT * kNTD + t) * 4 + nj) * 256);
+            }
+            if (mi % 4 == 3) {
+                const int gq = mi / 4;
+                if (gq < kNTE) stream_issue_tile<ABL>(nx, gq, tid, wave);            // next chunk may have up to 9 tiles
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            }
         }
         stream_sync<ABL>();
         ++g;
@@ -370,16 +396,26 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
             // arrive, goes first):
             //   0-3 issue L2 -> tapA    4-12 DMA tile 0..8    4-7 affine start values    12-15 issue L1 -> tapB
             //   16-19 blend L2 (tapA)   20-23 issue L0 -> tapA    28-31 blend L1 (tapB)   32-35 blend L0, ReLU, LDS write
-            float4 aw = *reinterpret_cast<const float4*>(wl);
+            // MFMA order: for each 4-step group j4, steps e = 0..3 round-robin over the 9 output tiles, so consecutive MFMAs
+            // never share an accumulator (a VALU instruction between two MFMAs on the SAME accumulator costs ~40 extra
+            // cycles; between independent ones it is nearly free).  The A operand of tile t (4 steps = one ds_read_b128)
+            // is refreshed in place right after its last use, 8 MFMAs before it is needed again.
+            float4 aw[kNTE];
 #pragma unroll
-            for (int gq = 0; gq < 36; ++gq) {
-                const int j4 = gq / 9, t = gq % 9;
-                const int gn = gq + 1 < 36 ? gq + 1 : gq;
-                const float4 an = *reinterpret_cast<const float4*>(wl + ((gn % 9) * 4 + gn / 9) * 256);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.x, bv[4 * j4 + 0], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.y, bv[4 * j4 + 1], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.z, bv[4 * j4 + 2], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw.w, bv[4 * j4 + 3], acc[t], 0, 0, 0);
+            for (int t = 0; t < kNTE; ++t) aw[t] = *reinterpret_cast<const float4*>(wl + (t * 4) * 256);
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+            for (int qs = 0; qs < kNTE; ++qs) {                          // 9 slots per step group, 4 MFMAs each
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int e = (4 * qs + k4) / kNTE, t = (4 * qs + k4) % kNTE;
+                    const float av = e == 0 ? aw[t].x : e == 1 ? aw[t].y : e == 2 ? aw[t].z : aw[t].w;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[4 * j4 + e], acc[t], 0, 0, 0);
+                    if (e == 3 && j4 < 3) aw[t] = *reinterpret_cast<const float4*>(wl + (t * 4 + j4 + 1) * 256);
+                }
+                {
+                const int gq = j4 * kNTE + qs;                           // slot 0..35: one piece after every 4th MFMA
                 if constexpr (SCHED == 0) {
                     if (gq >= 4 && gq < 13) stream_issue_tile<ABL>(nx, gq - 4, tid, wave);
                     if (gq < 4) issue_row(tapA, nsv, nc, 2, gq);
@@ -399,6 +435,15 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
                     else if (gq >= 20 && gq < 24) issue_row(tapA, nsv, nc, 0, gq - 20);
                     else if (gq >= 24 && gq < 28) blend_row(tapB, nsv, 1, gq - 24);
                     else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
+                } else if constexpr (SCHED == 3) {
+                    // one tap set in flight at a time (16 loads + the DMA): 8 slots of slack each
+                    if (gq >= 4 && gq < 13) stream_issue_tile<ABL>(nx, gq - 4, tid, wave);
+                    if (gq < 4) { issue_row(tapA, nsv, nc, 2, gq); affine_row(nsv, nc, gq); }
+                    else if (gq >= 8 && gq < 12) blend_row(tapA, nsv, 2, gq - 8);
+                    else if (gq >= 12 && gq < 16) issue_row(tapB, nsv, nc, 1, gq - 12);
+                    else if (gq >= 20 && gq < 24) blend_row(tapB, nsv, 1, gq - 20);
+                    else if (gq >= 24 && gq < 28) issue_row(tapA, nsv, nc, 0, gq - 24);
+                    else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
                 } else {
                     // DMA first (3 tiles per slot), every tap batch 16 slots ahead of its consumer except level 0
                     if (gq < 3) { stream_issue_tile<ABL>(nx, 3 * gq, tid, wave); stream_issue_tile<ABL>(nx, 3 * gq + 1, tid, wave); stream_issue_tile<ABL>(nx, 3 * gq + 2, tid, wave); }
@@ -409,8 +454,11 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
                     else if (gq >= 24 && gq < 28) { issue_row(tapA, nsv, nc, 0, gq - 24); blend_row(tapB, nsv, 1, gq - 24); }
                     else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
                 }
-                aw = an;
-                __builtin_amdgcn_sched_barrier(0);       // pin the slot (see chained_layer)
+                // Pin the slot (see chained_layer).  Measured on MI355X: with one wave per SIMD the gather's VALU/VMEM issue time
+                // is NOT hidden under the wave's own MFMAs (SQ_ACTIVE_INST_VALU adds 1:1 to SQ_WAVE_CYCLES), and spreading a
+                // piece over the four MFMA gaps with sched_group_barrier is slower than leaving it as one lump (9.4 vs 9.0 ms).
+                __builtin_amdgcn_sched_barrier(0);
+                }
             }
             // B operands of the next chunk: this wave's own LDS tile, written just above (LDS ops of a wave are in order);
             // read before the barrier so the latency overlaps it
@@ -422,14 +470,14 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
             stream_sync<ABL>();
             ++g;
         }
-        if constexpr (ABL == 4) { g += kNTE; }
+        if constexpr (ABL == 4) { g += kChK1; }
         else chained_layer<kNTE, false, ABL>(k1, acc, a.blob, lds, g, tid, wave, lane);
         if (live) store_rows<kNTE>(acc, a.e + i * (2 * kE) + sv * kE, h);
     }
     f32x16 key[kNTD];
     init_bias<kNTD>(key, lds + kLdsBias + kBiasK2, h);
     if constexpr (ABL != 4) chained_layer<kNTD, true, ABL>(key, k1, a.blob, lds, g, tid, wave, lane);
-    else g += 4;
+    else g += 2;
 
     // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ;  ug = Wr1[:,128:] g + br1 ---------------------
     f32x16 t1[kNTD], qv[kNTD];
@@ -443,7 +491,7 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
     ++g;
     init_bias<kNTD>(qv, lds + kLdsBias + kBiasQ2, h);
     if constexpr (ABL != 4) chained_layer<kNTD, true, ABL>(qv, t1, a.blob, lds, g, tid, wave, lane);   // qry
-    else g += 4;
+    else g += 2;
     float dot = 0.0f;
 #pragma unroll
     for (int t = 0; t < kNTD; ++t)
@@ -492,7 +540,7 @@ extern "C" int car_fused_samples(const float* poses, const float* rays, const fl
     const int abl = abl_env ? atoi(abl_env) : 0;
     const char* sch_env = getenv("CAR_FUSED_SCHED");
     const int sch = sch_env ? atoi(sch_env) : 1;
-    void (*kern)(const FusedArgs) = (abl == 0 && sch == 1) ? fused_sample_kernel<0, 1> : (abl == 0 && sch == 2) ? fused_sample_kernel<0, 2> : (abl == 0 && sch == 0) ? fused_sample_kernel<0, 0> : abl == 1 ? fused_sample_kernel<1> : abl == 2 ? fused_sample_kernel<2> : abl == 3 ? fused_sample_kernel<3>
+    void (*kern)(const FusedArgs) = (abl == 0 && sch == 1) ? fused_sample_kernel<0, 1> : (abl == 0 && sch == 2) ? fused_sample_kernel<0, 2> : (abl == 0 && sch == 0) ? fused_sample_kernel<0, 0> : (abl == 0 && sch == 3) ? fused_sample_kernel<0, 3> : abl == 1 ? fused_sample_kernel<1> : abl == 2 ? fused_sample_kernel<2> : abl == 3 ? fused_sample_kernel<3>
                                     : abl == 4 ? fused_sample_kernel<4> : abl == 5 ? fused_sample_kernel<5> : abl == 6 ? fused_sample_kernel<6>
                                     : abl == 7 ? fused_sample_kernel<7> : fused_sample_kernel<0>;
     hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
