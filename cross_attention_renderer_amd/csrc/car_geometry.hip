@@ -61,7 +61,7 @@ __global__ void sample_kernel(const CarPose* __restrict__ poses, const CarRay* _
                               const float* __restrict__ steps, int b, int V, int R, int P, int H, int W,
                               int no_sample, float* __restrict__ pixel_val, float* __restrict__ pt,
                               float* __restrict__ g, float* __restrict__ grid_in, float* __restrict__ xenc,
-                              int ld_xenc, int col_xenc) {
+                              int ld_xenc, int col_xenc, float* __restrict__ pt_in) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)b * V * R * P) return;
     const int p = (int)(i % P);
@@ -86,6 +86,9 @@ __global__ void sample_kernel(const CarPose* __restrict__ poses, const CarRay* _
             grid_in[(i * V + s) * 2 + 0] = S.grid_in[s][0];
             grid_in[(i * V + s) * 2 + 1] = S.grid_in[s][1];
         }
+    if (pt_in)
+        for (int s = 0; s < V; ++s)
+            for (int k = 0; k < 3; ++k) pt_in[(i * V + s) * 3 + k] = S.pt_in[s][k];
     if (xenc) {
         if (V == 1) {          // models.py:482-483: pt[isnan] = 0 (already scrubbed); tanh(pt/5), tanh(pt/100)
             float* x = xenc + i * (long)ld_xenc + col_xenc;
@@ -141,7 +144,7 @@ extern "C" int car_ray_setup(const float* poses, const float* uv, int b, int V, 
 
 extern "C" int car_sample_setup(const float* poses, const float* rays, const float* steps, int b, int V, int R,
                                 int P, int H, int W, int no_sample, float* pixel_val, float* pt, float* g,
-                                float* grid_in, float* xenc, int ld_xenc, int col_xenc, void* stream) {
+                                float* grid_in, float* xenc, int ld_xenc, int col_xenc, float* pt_in, void* stream) {
     CAR_REQUIRE(poses && rays && steps, "car_sample_setup: null pointer");
     CAR_REQUIRE(b > 0 && V > 0 && V <= CAR_MAX_VIEWS && R > 0 && P > 0 && H > 1 && W > 1, "car_sample_setup: bad sizes");
     CAR_REQUIRE(!xenc || (ld_xenc >= col_xenc + (V == 1 ? 6 : 3) && col_xenc >= 0), "car_sample_setup: xenc window out of row");
@@ -149,8 +152,31 @@ extern "C" int car_sample_setup(const float* poses, const float* rays, const flo
     (void)hipGetLastError();
     hipLaunchKernelGGL(sample_kernel, dim3(car_div_up(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const CarPose*)poses, (const CarRay*)rays, steps, b, V, R, P, H, W, no_sample, pixel_val, pt, g,
-                       grid_in, xenc, ld_xenc, col_xenc);
+                       grid_in, xenc, ld_xenc, col_xenc, pt_in);
     CAR_CHECK_LAUNCH("car_sample_setup");
+    return CAR_OK;
+}
+
+namespace {
+__global__ void project_points_kernel(const CarPose* __restrict__ poses, const float* __restrict__ pts, long npts, int V,
+                                      int view, int H, int W, long total, float* __restrict__ grid) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int sc = (int)(i / npts);
+    const float q[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    car_project_grid(poses[sc * V + view].kc, q, H, W, grid + 2 * i);
+}
+}  // namespace
+
+extern "C" int car_project_points(const float* poses, const float* pts, int n_scenes, long npts, int V, int view, int H,
+                                  int W, float* grid, void* stream) {
+    CAR_REQUIRE(poses && pts && grid, "car_project_points: null pointer");
+    CAR_REQUIRE(n_scenes > 0 && npts > 0 && V > 0 && view >= 0 && view < V && H > 1 && W > 1, "car_project_points: bad sizes");
+    const long total = (long)n_scenes * npts;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(project_points_kernel, dim3(car_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const CarPose*)poses, pts, npts, V, view, H, W, total, grid);
+    CAR_CHECK_LAUNCH("car_project_points");
     return CAR_OK;
 }
 

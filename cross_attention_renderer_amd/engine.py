@@ -250,8 +250,6 @@ class RenderEngine:
             raise ValueError("forward supports one query view per scene (reference models.py:213, 619)")
         if V != m.n_view:
             raise ValueError(f"input has {V} context views, module was built with n_view={m.n_view}")
-        if V == 3 and not m.no_latent_concat:
-            raise NotImplementedError("n_view=3 with latent concat is not built yet on the HIP engine")
         P, H, W = m.npoints, m.H, m.W
         n, S = b * V, b * V * R * P
         st = _stream()
@@ -288,11 +286,16 @@ class RenderEngine:
         pt = torch.empty(n, R, P, 3, **f32)
         g = torch.empty(S, 16, **f32)
         single = (V == 1 and not m.no_latent_concat)
+        concat3 = (V == 3 and not m.no_latent_concat)
         grid_in = torch.empty(n, R, P, V, 2, **f32) if concat2 else None
+        pt_in = torch.empty(n, R, P, V, 3, **f32) if concat3 else None
         x1 = None
         proj = concat2 and self.project_maps
         if proj:
             ld1 = 4                                   # only the 3 point channels: [S*V, 4]
+            x1 = torch.zeros(S * V, ld1, **f32)
+        elif concat3:
+            ld1 = 4                                   # point channels only; the 579-wide rows are assembled below
             x1 = torch.zeros(S * V, ld1, **f32)
         elif concat2:
             ld1 = _round_up(C + 3, 32)
@@ -302,7 +305,8 @@ class RenderEngine:
             x1 = torch.empty(S, ld1, **f32)
         _lib.check(lib.car_sample_setup(_ptr(poses), _ptr(rays), _ptr(steps), b, V, R, P, H, W, int(m.no_sample),
                                         _ptr(pixel_val), _ptr(pt), _ptr(g), _ptr(grid_in), _ptr(x1),
-                                        ld1 if x1 is not None else 0, 0 if proj else C, st), "car_sample_setup")
+                                        ld1 if x1 is not None else 0, 0 if (proj or concat3) else C, _ptr(pt_in), st),
+                   "car_sample_setup")
 
         # a7, a9-a11: per-sample features e
         if proj:
@@ -325,6 +329,9 @@ class RenderEngine:
             self.linear(h1, C, pk["query_encode_latent_2"], e, C // 2, S * V)
             del h1
             Ce = V * (C // 2)
+        elif concat3:
+            e = self._encode_three_views(maps, poses, pixel_val, x1, pt_in, b, R, P, H, W, C, pk)
+            Ce = 3 * (C // 2)
         elif single:
             self.gather(maps, pixel_val, R * P, 0, PLACE_PLAIN, V, x1, ld1, 0)
             e = torch.empty(S, C, **f32)
@@ -349,6 +356,47 @@ class RenderEngine:
 
         return self._finish(inp, z, b, V, R, P, Ce, Dl, e, key, q, None, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi,
                             debug)
+
+    def _encode_three_views(self, maps, poses, pixel_val, ptenc, pt_in, b, R, P, H, W, C, pk):
+        """Cross-view exchange for three context views (models.py:345-475), restated literally: for the samples of context c
+        the row is the channel-interleaved concatenation of enc(own features, point in frame c) and, for every other view o
+        in ascending order, enc(features of view o where context o's points — moved into frame c, projected with view o's
+        intrinsics — land in image o, those points in frame c).  All arithmetic is in HIP kernels (gather, projection, the two
+        1x1 layers); torch only moves rows into place."""
+        V, pts = 3, R * P
+        S = b * V * pts
+        dev = pixel_val.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        ld = _round_up(C + 3, 32)
+        x3 = torch.empty(S * 3, ld, **f32)
+        x3v = x3.view(b, V, pts, 3, ld)                     # [scene, context c, point, component k, channel]
+        pe = ptenc.view(b, V, pts, V, 4)                    # tanh(nan_to_num(T_s pt)/5): [scene, context, point, frame s]
+        pin = pt_in.view(b, V, pts, V, 3)
+        tmp = torch.empty(S, C, **f32)
+        self.gather(maps, pixel_val, pts, 0, PLACE_PLAIN, V, tmp, C, 0)
+        x3v[:, :, :, 0, :C] = tmp.view(b, V, pts, C)
+        per_view = [[t.view(b, V, *t.shape[1:])[:, o].contiguous() for t in maps] for o in range(V)]
+        tmp2 = torch.empty(b * pts, C, **f32)
+        grid = torch.empty(b, pts, 2, **f32)
+        for c in range(V):
+            x3v[:, c, :, 0, C:C + 3] = pe[:, c, :, c, :3]
+            k = 1
+            for o in range(V):
+                if o == c:
+                    continue
+                q = pin[:, o, :, c, :].contiguous()         # context o's points expressed in frame c
+                _lib.check(self.lib.car_project_points(_ptr(poses), _ptr(q), b, pts, V, o, H, W, _ptr(grid), _stream()),
+                           "car_project_points")
+                self.gather(per_view[o], grid, pts, 1, PLACE_PLAIN, 1, tmp2, C, 0)
+                x3v[:, c, :, k, :C] = tmp2.view(b, pts, C)
+                x3v[:, c, :, k, C:C + 3] = pe[:, o, :, c, :3]
+                k += 1
+        h1 = torch.empty(S * 3, C, **f32)
+        self.linear(x3, ld, pk["query_encode_latent"], h1, C, S * 3, RELU_OUT)
+        enc = torch.empty(S * 3, C // 2, **f32)
+        self.linear(h1, C, pk["query_encode_latent_2"], enc, C // 2, S * 3)
+        # channel index = ch*3 + k (torch.cat on dim 2 then flatten(1, 2), models.py:446)
+        return enc.view(S, 3, C // 2).permute(0, 2, 1).contiguous().view(S, 3 * (C // 2))
 
     def _render_fused(self, inp, z, maps, poses, rays, coords9, phi_x, ld_phi, steps, b, V, R, P, H, W, debug):
         m, lib = self.m, self.lib

@@ -81,10 +81,17 @@ int car_ray_setup(const float* poses, const float* uv, int b, int V, int R, int 
  *   grid_in   [b*V,R,P,V,2] where the point lands in every context view s
  *   xenc/ld_xenc/col_xenc   tanh(nan_to_num(T_s pt)/5) written to xenc[((n*R+r)*P+p)*V + s][col..col+3)
  *                           (the 3 point channels of models.py:330-338); with V == 1: tanh(pt/5), tanh(pt/100)
- *                           at [col..col+6) (models.py:483). */
+ *                           at [col..col+6) (models.py:483)
+ *   pt_in     [b*V,R,P,V,3] nan_to_num(T_s pt): the point in every context frame s (models.py:288-289, 322-325) */
 int car_sample_setup(const float* poses, const float* rays, const float* steps, int b, int V, int R, int P,
                      int H, int W, int no_sample, float* pixel_val, float* pt, float* g, float* grid_in,
-                     float* xenc, int ld_xenc, int col_xenc, void* stream);
+                     float* xenc, int ld_xenc, int col_xenc, float* pt_in, void* stream);
+
+/* geometry.project + normalize_for_grid_sample on explicit points (models.py:390-397, the three-view exchange):
+ * pts [n_scenes, npts, 3] camera-frame points -> grid [n_scenes, npts, 2], using the intrinsics of context view `view`
+ * of each scene (poses[(scene*V + view)].kc). */
+int car_project_points(const float* poses, const float* pts, int n_scenes, long npts, int V, int view, int H, int W,
+                       float* grid, void* stream);
 
 /* ---- a7/a10: F.grid_sample(bilinear, align_corners=False) over a channel-last pyramid (models.py:278, 317)
  * maps[l] : device pointer to level l, [n_maps, Hl, Wl, Cl] (NHWC); level_c/h/w host arrays of n_levels ints.

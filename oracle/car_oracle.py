@@ -433,8 +433,34 @@ def render_forward(params: Mapping[str, Tensor], inp: Mapping, z: List[Tensor], 
                 halves.append(enc(torch.cat([f, torch.tanh(p3 / 5.0)], dim=-1)))
             per_ctx.append(torch.cat(halves, dim=-1))
         e = torch.stack(per_ctx, dim=1).flatten(0, 1)         # (bV,R,P,2*C/2)
+    elif V == 3:
+        # three context views (models.py:345-475).  For the samples of context c the reference concatenates, channel-
+        # interleaved, the encodings of (i) c's own features with its point in frame c and (ii) for every other view o in
+        # ascending order: the features of view o sampled where *context o's* points — moved into frame c but projected
+        # with view o's intrinsics — land in image o, together with those points in frame c.  (The frames are mixed in the
+        # reference, models.py:385-397; it is restated literally.)
+        ptv = pt.reshape(b, V, R, P, 3)
+        pts_in = [_apply_4x4(T_rel[s][:, :, None, None], ptv) for s in range(V)]            # [s][:, c] = T_s pt_c
+        feat_ownv = feat_own.reshape(b, V, R, P, C)
+
+        def enc(x: Tensor) -> Tensor:
+            h = F.relu(_conv1x1(x, params["query_encode_latent.weight"], params["query_encode_latent.bias"]))
+            return _conv1x1(h, params["query_encode_latent_2.weight"], params["query_encode_latent_2.bias"])
+
+        per_ctx = []
+        for c in range(V):
+            comps = [enc(torch.cat([feat_ownv[:, c], torch.tanh(torch.nan_to_num(pts_in[c][:, c], 0.0) / 5.0)], dim=-1))]
+            for o in range(V):
+                if o == c:
+                    continue
+                q = pts_in[c][:, o]                                                         # context o's points in frame c
+                grid = _norm_for_grid(_project_pixels(q, K_ctx[:, o, None, None]), H, W)
+                feat = gather_pyramid([lat.reshape(b, V, *lat.shape[1:])[:, o] for lat in z], grid, "zeros")
+                comps.append(enc(torch.cat([feat, torch.tanh(torch.nan_to_num(q, 0.0) / 5.0)], dim=-1)))
+            per_ctx.append(torch.stack(comps, dim=-1).flatten(-2, -1))                      # channel index = ch*3 + k
+        e = torch.stack(per_ctx, dim=1).flatten(0, 1)
     else:
-        raise NotImplementedError("n_view=3 is restated in oracle/car_oracle_nview3.py")
+        raise NotImplementedError(f"n_view={V}")
     st.update(interp_val=e)
 
     # a12 values and keys (models.py:487-491)

@@ -34,9 +34,11 @@ CASES: Dict[str, dict] = {
     "t0_no_sample": dict(tier=0, H=16, P=8, b=1, rays=64, no_sample=True, **TINY),
     "t0_no_latent_concat": dict(tier=0, H=16, P=8, b=1, rays=64, no_latent_concat=True, **TINY),
     "t0_nview1": dict(tier=0, H=16, P=8, b=2, rays=64, n_view=1, **TINY),
+    "t0_nview3": dict(tier=0, H=16, P=8, b=2, rays=48, n_view=3, **TINY),
     "t0_p5": dict(tier=0, H=16, P=5, b=1, rays=37, **TINY),            # ragged sizes
     # ---- T1: real widths, C1 shape -----------------------------------------------------------
     "t1_c1": dict(tier=1, H=64, P=32, b=1, rays=256, **REAL),
+    "t1_nview3": dict(tier=1, H=64, P=16, b=1, rays=64, n_view=3, **REAL),
     "t1_c1_diverging": dict(tier=1, H=64, P=32, b=1, rays=128, yaw_deg=38.0, baseline=0.9, **REAL),
     # ---- T2: real widths, bench shapes -------------------------------------------------------
     "t2_c2": dict(tier=2, H=256, P=64, b=1, rays=64, **REAL),

@@ -21,7 +21,7 @@ def fmt(e):
 
 
 def main():
-    names = sys.argv[1:] or [n for n, c in C.CASES.items() if c.get("n_view", 2) != 3]
+    names = sys.argv[1:] or list(C.CASES)
     print("device:", torch.cuda.get_device_name(0))
     for name in names:
         t0 = time.time()
