@@ -1,0 +1,63 @@
+"""Render/eval plumbing (cross_attention_renderer_amd/harness.py, experiment_scripts/): CPU checks of the pieces that
+need no GPU, and a GPU run of both entry points on a small synthetic pair."""
+import os
+import subprocess
+import sys
+import zlib
+
+import pytest
+import torch
+
+from cross_attention_renderer_amd import harness, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_trajectory_interpolates_between_context_cameras():
+    inp = synthetic.stereo_scene(16, b=2, uv=synthetic.pixel_grid(16, 16)[:4].contiguous())
+    frames = harness.trajectory(inp, 5)
+    c2w = inp["context"]["cam2world"]
+    assert len(frames) == 5
+    assert torch.allclose(frames[0]["query"]["cam2world"][:, 0], c2w[:, 0], atol=1e-6)
+    assert torch.allclose(frames[-1]["query"]["cam2world"][:, 0], c2w[:, 1], atol=1e-6)
+    mid = frames[2]["query"]["cam2world"][0, 0]
+    assert torch.allclose(mid[:3, :3] @ mid[:3, :3].T, torch.eye(3), atol=1e-5)          # still a rotation
+    assert torch.allclose(mid[:3, 3], (c2w[0, 0, :3, 3] + c2w[0, 1, :3, 3]) / 2, atol=1e-6)
+
+
+def test_png_writer_and_psnr(tmp_path):
+    img = torch.rand(5, 7, 3) * 2 - 1
+    p = tmp_path / "x.png"
+    harness.write_png(str(p), img)
+    data = p.read_bytes()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n" and b"IHDR" in data and b"IEND" in data
+    idat = data[data.index(b"IDAT") + 4: data.index(b"IEND") - 8]
+    raw = zlib.decompress(idat)
+    assert len(raw) == 5 * (1 + 7 * 3)
+    assert harness.psnr(img, img) == float("inf")
+    assert abs(harness.psnr(torch.zeros(4), torch.full((4,), 0.1)) - 20.0) < 1e-4
+
+
+def test_entry_points_parse_reference_flags():
+    sys.path.insert(0, os.path.join(ROOT, "experiment_scripts"))
+    import common
+    opt = common.parser("x").parse_args(["--experiment_name", "e", "--views", "2", "--gpus", "1", "--model", "midas_vit",
+                                         "--checkpoint_path", "c.pth", "--no_sample", "--no_latent_concat",
+                                         "--no_multiview", "--batch_size", "3"])
+    assert opt.views == 2 and opt.no_sample and opt.batch_size == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,extra", [("render_realestate10k_traj.py", ["--n_frames", "2"]),
+                                          ("eval_realestate10k.py", ["--batch_size", "1"])])
+def test_entry_points_run_on_gpu(script, extra, tmp_path):
+    cmd = [sys.executable, os.path.join(ROOT, "experiment_scripts", script), "--experiment_name", "t", "--views", "2",
+           "--synthetic", "--img_sidelength", "64", "--out_dir", str(tmp_path), "--logging_root", str(tmp_path)] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    if script.startswith("render"):
+        assert (tmp_path / "frame_0001.png").exists()
+        assert "rays/s" in out.stdout
+    else:
+        psnr = float(out.stdout.split("psnr vs unchunked render")[1].split("dB")[0])
+        assert psnr > 100.0, out.stdout          # chunking must not change the image
