@@ -119,7 +119,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)      # nccl == RCCL on ROCm
 
     import __graft_entry__ as ge
-    ge.build()
+    if rank == 0:
+        ge.build()                                   # one builder per node: concurrent hipcc runs would race on the .so
+    if dist is not None:
+        dist.barrier()
     from cross_attention_renderer_amd.engine import RenderEngine
     from cross_attention_renderer_amd.sharding import TileGather
 
@@ -175,6 +178,16 @@ def main():
             roof = {"bound": "mfma", "kernel": desc, "achieved": flop / mean / 1e12,
                     "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": flop / mean / FP32_MFMA_PEAK,
                     "traffic": None, "launches": len(lat), "ms_per_launch": mean * 1e3, "flop_per_launch": flop}
+            # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
+            # profiles/ and MI355X_MICROARCH.md §HBM); PMC collection cannot run inside the timed bench itself
+            try:
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                    tr = json.load(f).get(name)
+                if tr:
+                    roof["traffic"] = tr["bytes_per_launch"]
+                    roof["traffic_source"] = tr["source"]
+            except OSError:
+                pass
         line = {
             "metric": "rendered_rays_per_sec", "value": rays_total / elapsed, "unit": "rays/s",
             "frames_per_sec": world * args.steps / elapsed,
