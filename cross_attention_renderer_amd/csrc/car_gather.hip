@@ -4,8 +4,8 @@
 // Layout: each pyramid level is [n_maps, Hl, Wl, Cl] (NHWC), so one texel is Cl contiguous floats; a thread
 // owns one float4 of channels of one output row, consecutive lanes own consecutive channel quads: the four
 // tap reads and the write are 16 B per lane, coalesced across the lanes that share a row (a 256-channel
-// texel is exactly 64 lanes x float4).  This stand-alone stage is HBM/L2-bound: per output row it writes
-// sum(Cl)*4 bytes and reads 4 taps of the same size out of L2 / Infinity Cache.
+// texel is exactly 64 lanes x float4).  This stand-alone stage is HBM-bound: per output row it writes
+// sum(Cl)*4 bytes; the 4 taps of the same size come out of L2 / Infinity Cache (the maps are 75 MB).
 #include "car_common.h"
 #include "car_geom.h"
 
@@ -18,38 +18,82 @@ struct GatherLevels {
     int n_levels;
 };
 
+constexpr int kGRows = 16;          // output rows per workgroup
+
+// A workgroup handles 16 consecutive sampled points: the bilinear tap indices / weights are computed once per (point,
+// level) into LDS, then every thread moves float4s: 4 tap reads (L2 / Infinity Cache resident maps), one 16-byte store.
+// The stage is bound by the HBM write of the gathered rows.
 __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps, const float* __restrict__ grid,
                                                      long pts, int mode, int place, int V, float* __restrict__ out,
                                                      int ld_out, int col_out) {
+    __shared__ int s_idx[kGRows][CAR_MAX_LEVELS][4];
+    __shared__ float s_w[kGRows][CAR_MAX_LEVELS][4];
+    __shared__ long s_row[kGRows];
     const int qpr = L.q0[L.n_levels];
-    const long total = (long)n_maps * pts * qpr;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int q = (int)(idx % qpr);
-        const long mp = idx / qpr;                       // m*pts + i
-        const int m = (int)(mp / pts);
-        const long i = mp % pts;
-        int l = 0;
-        while (l + 1 < L.n_levels && q >= L.q0[l + 1]) ++l;
-        const int cq = q - L.q0[l];
-        const float gx = grid[2 * mp], gy = grid[2 * mp + 1];
-        int tidx[4];
-        float tw[4];
-        car_bilinear_taps(gx, gy, L.w[l], L.h[l], mode, tidx, tw);
-        const float* base = L.map[l] + (long)m * L.h[l] * L.w[l] * L.c[l] + 4 * cq;
-        const float4 a = *reinterpret_cast<const float4*>(base + (long)tidx[0] * L.c[l]);
-        const float4 b4 = *reinterpret_cast<const float4*>(base + (long)tidx[1] * L.c[l]);
-        const float4 c4 = *reinterpret_cast<const float4*>(base + (long)tidx[2] * L.c[l]);
-        const float4 d4 = *reinterpret_cast<const float4*>(base + (long)tidx[3] * L.c[l]);
-        float4 r;   // ((nw + ne) + sw) + se, products rounded individually (ATen's vectorised CPU kernel order)
-        r.x = ((a.x * tw[0] + b4.x * tw[1]) + c4.x * tw[2]) + d4.x * tw[3];
-        r.y = ((a.y * tw[0] + b4.y * tw[1]) + c4.y * tw[2]) + d4.y * tw[3];
-        r.z = ((a.z * tw[0] + b4.z * tw[1]) + c4.z * tw[2]) + d4.z * tw[3];
-        r.w = ((a.w * tw[0] + b4.w * tw[1]) + c4.w * tw[2]) + d4.w * tw[3];
-        long row;
-        if (place == CAR_PLACE_PLAIN) row = mp;
-        else if (place == CAR_PLACE_OWN) row = mp * V + (m % V);
-        else { const int sc = m / 2, s = m % 2; row = (((long)(sc * 2 + (1 - s))) * pts + i) * 2 + s; }
-        *reinterpret_cast<float4*>(out + row * ld_out + col_out + 4 * q) = r;
+    const long total_rows = (long)n_maps * pts;
+    const int tid = threadIdx.x;
+    for (long row0 = (long)blockIdx.x * kGRows; row0 < total_rows; row0 += (long)gridDim.x * kGRows) {
+        if (tid < kGRows * L.n_levels) {
+            const int rl = tid / L.n_levels, l = tid % L.n_levels;
+            long mp = row0 + rl;
+            if (mp >= total_rows) mp = total_rows - 1;
+            const int m = (int)(mp / pts);
+            int tidx[4];
+            float tw[4];
+            car_bilinear_taps(grid[2 * mp], grid[2 * mp + 1], L.w[l], L.h[l], mode, tidx, tw);
+            for (int t = 0; t < 4; ++t) { s_idx[rl][l][t] = m * L.h[l] * L.w[l] + tidx[t]; s_w[rl][l][t] = tw[t]; }
+            if (l == 0) {
+                const long i = mp % pts;
+                long row;
+                if (place == CAR_PLACE_PLAIN) row = mp;
+                else if (place == CAR_PLACE_OWN) row = mp * V + (m % V);
+                else { const int sc = m / 2, s = m % 2; row = (((long)(sc * 2 + (1 - s))) * pts + i) * 2 + s; }
+                s_row[rl] = row;
+            }
+        }
+        __syncthreads();
+        // three items (12 tap loads) in flight per thread before the first store: the stage lives on memory-level parallelism
+        const int n_items = kGRows * qpr;
+        for (int it0 = tid; it0 < n_items; it0 += 3 * 256) {
+            float4 tp[3][4];
+            float wv[3][4];
+            long orow[3];
+            int oq[3];
+            bool ok[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int item = it0 + u * 256;
+                const int ci = item < n_items ? item : tid;             // clamp: harmless duplicate read, store masked
+                const int rl = ci / qpr, q = ci % qpr;
+                ok[u] = item < n_items && row0 + rl < total_rows;
+                int l = 0;
+                while (l + 1 < L.n_levels && q >= L.q0[l + 1]) ++l;
+                const float* base = L.map[l] + 4 * (q - L.q0[l]);
+                const long cl = L.c[l];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    tp[u][t] = *reinterpret_cast<const float4*>(base + (long)s_idx[rl][l][t] * cl);
+                    wv[u][t] = s_w[rl][l][t];
+                }
+                orow[u] = s_row[rl];
+                oq[u] = q;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (!ok[u]) continue;
+                float4 r;   // ((nw + ne) + sw) + se, products rounded individually (ATen's vectorised CPU kernel order)
+                r.x = ((tp[u][0].x * wv[u][0] + tp[u][1].x * wv[u][1]) + tp[u][2].x * wv[u][2]) + tp[u][3].x * wv[u][3];
+                r.y = ((tp[u][0].y * wv[u][0] + tp[u][1].y * wv[u][1]) + tp[u][2].y * wv[u][2]) + tp[u][3].y * wv[u][3];
+                r.z = ((tp[u][0].z * wv[u][0] + tp[u][1].z * wv[u][1]) + tp[u][2].z * wv[u][2]) + tp[u][3].z * wv[u][3];
+                r.w = ((tp[u][0].w * wv[u][0] + tp[u][1].w * wv[u][1]) + tp[u][2].w * wv[u][2]) + tp[u][3].w * wv[u][3];
+                // streaming store: the gathered rows are written once and must not evict the feature maps from L2
+                __builtin_nontemporal_store(r.x, out + orow[u] * ld_out + col_out + 4 * oq[u] + 0);
+                __builtin_nontemporal_store(r.y, out + orow[u] * ld_out + col_out + 4 * oq[u] + 1);
+                __builtin_nontemporal_store(r.z, out + orow[u] * ld_out + col_out + 4 * oq[u] + 2);
+                __builtin_nontemporal_store(r.w, out + orow[u] * ld_out + col_out + 4 * oq[u] + 3);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -77,8 +121,9 @@ extern "C" int car_gather_bilinear(const float* const* maps, const int* level_c,
     for (int l = n_levels; l < CAR_MAX_LEVELS; ++l) { L.map[l] = nullptr; L.c[l] = L.h[l] = L.w[l] = 0; if (l > n_levels) L.q0[l] = q; }
     CAR_REQUIRE(ld_out % 4 == 0 && col_out % 4 == 0 && col_out >= 0 && col_out + 4 * q <= ld_out,
                 "car_gather_bilinear: output window [%d,%d) must be float4-aligned inside a row of %d", col_out, col_out + 4 * q, ld_out);
-    const long total = (long)n_maps * pts * q;
-    const unsigned blocks = (unsigned)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    CAR_REQUIRE((long)n_maps * level_h[0] * level_w[0] < 2147483647L, "car_gather_bilinear: map too large for 32-bit texel indices");
+    const long groups = ((long)n_maps * pts + kGRows - 1) / kGRows;
+    const unsigned blocks = (unsigned)(groups < 65536 ? groups : 65536);
     (void)hipGetLastError();
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L, n_maps, grid, pts, mode,
                        place, V, out, ld_out, col_out);
