@@ -28,7 +28,16 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
+
+// PREC = 1: the 576 -> 288 layer runs on the f16 matrix pipe with both operands split into two fp16 halves,
+//   x = hi + lo,  hi = fp16(x), lo = fp16(x - hi),      x*w ~= hi_x*hi_w + hi_x*lo_w + lo_x*hi_w
+// (three v_mfma_f32_32x32x16_f16 per 16-wide K step instead of eight v_mfma_f32_32x32x2_f32: every fp16 x fp16 product is
+// exact in the fp32 accumulator, the dropped lo*lo term is 2^-22 relative, so the result is fp32-class — it is checked
+// against the oracle at 1e-4 like the fp32 kernel, which stays selectable).  The weights are pre-scaled by 2^kWShift on
+// the host so their low halves stay out of the fp16 subnormal range; the accumulators are scaled back exactly.
+constexpr int kWShift = 8;
 
 constexpr int kC = 576;            // feature channels = width of h
 constexpr int kE = 288;            // per-source width of e
@@ -74,6 +83,7 @@ struct FusedArgs {
     const float* bias;       // kBiasFloats
     int b, V, R, P, H, W;
     int xcd_bands;           // 1: remap workgroups so each XCD gets a contiguous band of rays
+    int prec;                // 0: fp32 MFMA for the 576->288 layer; 1: split-fp16 MFMA (blob packed accordingly)
     long S;                  // b*V*R*P samples
     float* e;                // [S, 576]
     float* qry;              // [S, 128]
@@ -240,7 +250,7 @@ __device__ __forceinline__ void chained_layer(f32x16 (&acc)[kNTD], const f32x16 
 // ABL > 0 are timing-only ablations (results are wrong by construction), selected with CAR_FUSED_ABLATE for tools/bench_fused.py:
 //   1 no tap loads   2 no gather work at all   3 = 2 + no weight DMA / barriers   4 = 0 but without the chained layers
 //   5 / 6 / 7 no tap loads of pyramid level 2 / 1 / 0
-template <int ABL, int SCHED = 0>
+template <int ABL, int SCHED = 0, int PREC = 0>
 __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -382,6 +392,10 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
 #pragma unroll 1
     for (int sv = 0; sv < 2; ++sv) {
         init_bias<kNTE>(acc, lds + kLdsBias + kBiasE, h);
+        if constexpr (PREC == 1) {
+#pragma unroll
+            for (int t = 0; t < kNTE; ++t) acc[t] *= (float)(1 << kWShift);        // the packed weights carry 2^kWShift
+        }
 #pragma unroll 1
         for (int c = 0; c < kKT; ++c) {
             // next chunk to gather: (sv, c+1), or (1, 0) after the last chunk of source 0.  Kept branch-free on purpose (a
@@ -396,26 +410,7 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
             // arrive, goes first):
             //   0-3 issue L2 -> tapA    4-12 DMA tile 0..8    4-7 affine start values    12-15 issue L1 -> tapB
             //   16-19 blend L2 (tapA)   20-23 issue L0 -> tapA    28-31 blend L1 (tapB)   32-35 blend L0, ReLU, LDS write
-            // MFMA order: for each 4-step group j4, steps e = 0..3 round-robin over the 9 output tiles, so consecutive MFMAs
-            // never share an accumulator (a VALU instruction between two MFMAs on the SAME accumulator costs ~40 extra
-            // cycles; between independent ones it is nearly free).  The A operand of tile t (4 steps = one ds_read_b128)
-            // is refreshed in place right after its last use, 8 MFMAs before it is needed again.
-            float4 aw[kNTE];
-#pragma unroll
-            for (int t = 0; t < kNTE; ++t) aw[t] = *reinterpret_cast<const float4*>(wl + (t * 4) * 256);
-#pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4)
-#pragma unroll
-            for (int qs = 0; qs < kNTE; ++qs) {                          // 9 slots per step group, 4 MFMAs each
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const int e = (4 * qs + k4) / kNTE, t = (4 * qs + k4) % kNTE;
-                    const float av = e == 0 ? aw[t].x : e == 1 ? aw[t].y : e == 2 ? aw[t].z : aw[t].w;
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[4 * j4 + e], acc[t], 0, 0, 0);
-                    if (e == 3 && j4 < 3) aw[t] = *reinterpret_cast<const float4*>(wl + (t * 4 + j4 + 1) * 256);
-                }
-                {
-                const int gq = j4 * kNTE + qs;                           // slot 0..35: one piece after every 4th MFMA
+            auto piece = [&](int gq) {            // slot gq = 0..35 of the chunk: one piece of the next chunk's gather / DMA issue
                 if constexpr (SCHED == 0) {
                     if (gq >= 4 && gq < 13) stream_issue_tile<ABL>(nx, gq - 4, tid, wave);
                     if (gq < 4) issue_row(tapA, nsv, nc, 2, gq);
@@ -454,11 +449,59 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
                     else if (gq >= 24 && gq < 28) { issue_row(tapA, nsv, nc, 0, gq - 24); blend_row(tapB, nsv, 1, gq - 24); }
                     else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
                 }
+            };
+            if constexpr (PREC == 1) {
+                // split this lane's 16 activations (two 8-wide K groups) into fp16 high and low halves
+                half8 bhi[2], blo[2];
+#pragma unroll
+                for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                    for (int e8 = 0; e8 < 8; ++e8) {
+                        const float x = bv[8 * kg + e8];
+                        const _Float16 hi = (_Float16)x;
+                        bhi[kg][e8] = hi;
+                        blo[kg][e8] = (_Float16)(x - (float)hi);
+                    }
+                // packed tile: [kg][hi|lo][lane][8 halves]; 18 slots of (two ds_read_b128, three MFMAs), two pieces each
+#pragma unroll
+                for (int t = 0; t < kNTE; ++t)
+#pragma unroll
+                    for (int kg = 0; kg < 2; ++kg) {
+                        const float4 ahf = *reinterpret_cast<const float4*>(wl + t * kTile + ((kg * 2 + 0) * 64) * 4);
+                        const float4 alf = *reinterpret_cast<const float4*>(wl + t * kTile + ((kg * 2 + 1) * 64) * 4);
+                        const half8 ah = __builtin_bit_cast(half8, ahf), al = __builtin_bit_cast(half8, alf);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[kg], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[kg], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[kg], acc[t], 0, 0, 0);
+                        piece(2 * (t * 2 + kg));
+                        piece(2 * (t * 2 + kg) + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            } else {
+            // MFMA order: for each 4-step group j4, steps e = 0..3 round-robin over the 9 output tiles, so consecutive MFMAs
+            // never share an accumulator (a VALU instruction between two MFMAs on the SAME accumulator costs ~40 extra
+            // cycles; between independent ones it is nearly free).  The A operand of tile t (4 steps = one ds_read_b128)
+            // is refreshed in place right after its last use, 8 MFMAs before it is needed again.
+            float4 aw[kNTE];
+#pragma unroll
+            for (int t = 0; t < kNTE; ++t) aw[t] = *reinterpret_cast<const float4*>(wl + (t * 4) * 256);
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+            for (int qs = 0; qs < kNTE; ++qs) {                          // 9 slots per step group, 4 MFMAs each
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const int e = (4 * qs + k4) / kNTE, t = (4 * qs + k4) % kNTE;
+                    const float av = e == 0 ? aw[t].x : e == 1 ? aw[t].y : e == 2 ? aw[t].z : aw[t].w;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[4 * j4 + e], acc[t], 0, 0, 0);
+                    if (e == 3 && j4 < 3) aw[t] = *reinterpret_cast<const float4*>(wl + (t * 4 + j4 + 1) * 256);
+                }
+                piece(j4 * kNTE + qs);
                 // Pin the slot (see chained_layer).  Measured on MI355X: with one wave per SIMD the gather's VALU/VMEM issue time
                 // is NOT hidden under the wave's own MFMAs (SQ_ACTIVE_INST_VALU adds 1:1 to SQ_WAVE_CYCLES), and spreading a
                 // piece over the four MFMA gaps with sched_group_barrier is slower than leaving it as one lump (9.4 vs 9.0 ms).
                 __builtin_amdgcn_sched_barrier(0);
-                }
+            }
             }
             // B operands of the next chunk: this wave's own LDS tile, written just above (LDS ops of a wave are in order);
             // read before the barrier so the latency overlaps it
@@ -469,6 +512,10 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
             }
             stream_sync<ABL>();
             ++g;
+        }
+        if constexpr (PREC == 1) {
+#pragma unroll
+            for (int t = 0; t < kNTE; ++t) acc[t] *= 1.0f / (float)(1 << kWShift);  // exact power of two
         }
         if constexpr (ABL == 4) { g += kChK1; }
         else chained_layer<kNTE, false, ABL>(k1, acc, a.blob, lds, g, tid, wave, lane);
@@ -519,7 +566,8 @@ extern "C" size_t car_fused_bias_floats(void) { return (size_t)kBiasFloats; }
 extern "C" int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
                                  const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
                                  const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                                 float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, void* stream) {
+                                 float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, int prec,
+                                 void* stream) {
     CAR_REQUIRE(poses && rays && steps && gmaps && level_h && level_w && wpt && blob && bias, "car_fused_samples: null input");
     CAR_REQUIRE(e && qry && ug && logit && pt && pixel_val, "car_fused_samples: null output");
     CAR_REQUIRE(n_levels == 3 && C == kC && V == 2, "car_fused_samples: built for 3 pyramid levels, C = %d, V = 2 (got %d, %d, %d)", kC, n_levels, C, V);
@@ -536,11 +584,15 @@ extern "C" int car_fused_samples(const float* poses, const float* rays, const fl
     const char* xb = getenv("CAR_FUSED_XCD_BANDS");
     a.xcd_bands = xb ? atoi(xb) : 1;
     a.e = e; a.qry = qry; a.ug = ug; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
+    CAR_REQUIRE(prec == 0 || prec == 1, "car_fused_samples: prec must be 0 (fp32 MFMA) or 1 (split fp16 MFMA)");
+    a.prec = prec;
     const char* abl_env = getenv("CAR_FUSED_ABLATE");
     const int abl = abl_env ? atoi(abl_env) : 0;
     const char* sch_env = getenv("CAR_FUSED_SCHED");
     const int sch = sch_env ? atoi(sch_env) : 1;
-    void (*kern)(const FusedArgs) = (abl == 0 && sch == 1) ? fused_sample_kernel<0, 1> : (abl == 0 && sch == 2) ? fused_sample_kernel<0, 2> : (abl == 0 && sch == 0) ? fused_sample_kernel<0, 0> : (abl == 0 && sch == 3) ? fused_sample_kernel<0, 3> : abl == 1 ? fused_sample_kernel<1> : abl == 2 ? fused_sample_kernel<2> : abl == 3 ? fused_sample_kernel<3>
+    void (*kern)(const FusedArgs) = (prec == 1 && abl == 0) ? fused_sample_kernel<0, 1, 1> : (prec == 1 && abl == 1) ? fused_sample_kernel<1, 1, 1>
+                                    : (prec == 1 && abl == 2) ? fused_sample_kernel<2, 1, 1> : (prec == 1 && abl == 3) ? fused_sample_kernel<3, 1, 1>
+                                    : (prec == 1 && abl == 4) ? fused_sample_kernel<4, 1, 1> : (abl == 0 && sch == 1) ? fused_sample_kernel<0, 1> : (abl == 0 && sch == 2) ? fused_sample_kernel<0, 2> : (abl == 0 && sch == 0) ? fused_sample_kernel<0, 0> : (abl == 0 && sch == 3) ? fused_sample_kernel<0, 3> : abl == 1 ? fused_sample_kernel<1> : abl == 2 ? fused_sample_kernel<2> : abl == 3 ? fused_sample_kernel<3>
                                     : abl == 4 ? fused_sample_kernel<4> : abl == 5 ? fused_sample_kernel<5> : abl == 6 ? fused_sample_kernel<6>
                                     : abl == 7 ? fused_sample_kernel<7> : fused_sample_kernel<0>;
     hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);

@@ -86,15 +86,38 @@ def _chained_k(n_src_tiles: int, base: int = 0) -> Tensor:
     return base + 32 * T + (r % 4) + 8 * (r // 4) + 4 * (lane // 32)
 
 
-def pack_fused_weights(m, device):
+W_SHIFT = 8          # kWShift of csrc/car_fused.hip: packed fp16 weights carry a factor 2^8
+
+
+def _pack_tiles_f16_split(W: Tensor, n_tiles: int, chunk_k: Tensor) -> Tensor:
+    """Split-fp16 operand tiles of the f16 matrix pipe: per (chunk, tile) [K group (2)][hi | lo][lane (64)][8 halves],
+    returned as float32 words (same 1024 floats per tile as the fp32 packing).  w * 2^W_SHIFT = hi + lo with hi = fp16(.),
+    lo = fp16(. - hi): the scale keeps the low halves out of the fp16 subnormal range; the kernel undoes it exactly."""
+    N, K = W.shape
+    Wext = torch.zeros(32 * n_tiles, K + 1, dtype=torch.float32)
+    Wext[:N, :K] = W * float(1 << W_SHIFT)
+    chunks = chunk_k.shape[0]
+    k = chunk_k.clamp(max=K)                                                 # (chunks, 64, 16); k >= K -> zero column
+    lane = torch.arange(64)
+    n = 32 * torch.arange(n_tiles)[:, None] + (lane % 32)[None, :]           # (tiles, 64)
+    w = Wext[n[None, :, :, None].expand(chunks, -1, -1, 16), k[:, None, :, :].expand(-1, n_tiles, -1, -1)]   # (chunks,tiles,64,16)
+    hi = w.half()
+    lo = (w - hi.float()).half()
+    both = torch.stack([hi, lo], dim=2)                                      # (chunks, tiles, hl, 64, 16)
+    both = both.reshape(chunks, n_tiles, 2, 64, 2, 8).permute(0, 1, 4, 2, 3, 5).contiguous()   # -> (.., kg, hl, lane, 8)
+    return both.view(torch.float32).reshape(chunks, n_tiles, 1024)
+
+
+def pack_fused_weights(m, device, split_fp16: bool = False):
     """Weights of the fused per-sample kernel (csrc/car_fused.hip) in its operand order: (blob, bias table)."""
     f = lambda t: t.detach().float().cpu().reshape(t.shape[0], -1)
     v = lambda t: t.detach().float().cpu()
     C = m.query_encode_latent.weight.shape[0]
     E2 = C // 2
     wr = f(m.query_repeat_embed.weight)
+    w2 = f(m.query_encode_latent_2.weight)
     parts = [
-        _pack_tiles(f(m.query_encode_latent_2.weight), None, E2 // 32, _std_k(C // 32)),                      # W2
+        _pack_tiles_f16_split(w2, E2 // 32, _std_k(C // 32)) if split_fp16 else _pack_tiles(w2, None, E2 // 32, _std_k(C // 32)),   # W2
         _pack_tiles(f(m.query_embed.weight), v(m.query_embed.bias), 4, _std_k(1)),                            # Q1 (bias folded)
         _pack_tiles(f(m.query_embed_2.weight), None, 4, _chained_k(4)),                                       # Q2
         _pack_tiles(wr[:, 128:].contiguous(), v(m.query_repeat_embed.bias), 4, _std_k(1)),                    # UG (bias folded)
@@ -127,6 +150,9 @@ class RenderEngine:
         # geometry + encode + 576->288 + key/query MLPs + logits as one kernel (csrc/car_fused.hip); needs V == 2, three
         # pyramid levels, C == 576.  False keeps the stage-by-stage pipeline (A/B and stage tests)
         self.fuse_samples = True
+        # 576->288 layer of the fused kernel on the f16 matrix pipe with fp16 hi/lo operand splits (3 products per term,
+        # fp32-class accuracy) instead of the fp32 pipe
+        self.split_fp16 = True
         self._fused_key = None
         self._fused = None
         self._pose_key = None
@@ -424,9 +450,9 @@ class RenderEngine:
         key = tuple((p_.data_ptr(), p_._version) for p_ in (
             m.query_encode_latent_2.weight, m.query_encode_latent_2.bias, m.query_embed.weight, m.query_embed.bias,
             m.query_embed_2.weight, m.query_embed_2.bias, m.query_repeat_embed.weight, m.query_repeat_embed.bias,
-            m.key_map.weight, m.key_map.bias, m.key_map_2.weight, m.key_map_2.bias)) + (str(dev),)
+            m.key_map.weight, m.key_map.bias, m.key_map_2.weight, m.key_map_2.bias)) + (str(dev), self.split_fp16)
         if key != self._fused_key:
-            self._fused = pack_fused_weights(m, dev)
+            self._fused = pack_fused_weights(m, dev, self.split_fp16)
             assert self._fused[0].numel() == lib.car_fused_blob_floats() and self._fused[1].numel() == lib.car_fused_bias_floats()
             self._fused_key = key
         blob, bias = self._fused
@@ -446,7 +472,7 @@ class RenderEngine:
             ev[0].record()
         _lib.check(lib.car_fused_samples(_ptr(poses), _ptr(rays), _ptr(steps), ptrs, hs, ws, L, 576, _ptr(wpt), _ptr(blob),
                                          _ptr(bias), b, V, R, P, H, W, _ptr(e), _ptr(q), _ptr(ug), _ptr(logit), _ptr(pt),
-                                         _ptr(pixel_val), _stream()), "car_fused_samples")
+                                         _ptr(pixel_val), int(self.split_fp16), _stream()), "car_fused_samples")
         if ev is not None:
             ev[1].record()
             # algorithmic MACs per sample on the matrix pipe: 2 x 576x288 (e), 576x128 + 128x128 (key), 16x128 + 128x128 (qry),

@@ -122,13 +122,14 @@ int car_gather_encode(const float* const* gmaps, const int* level_h, const int* 
  * (csrc/car_fused.hip).  `blob` / `bias` are the layer weights in the kernel's operand order; their sizes are given by
  * car_fused_blob_floats() / car_fused_bias_floats() and their layout is documented in csrc/car_fused.hip (the Python
  * host packs them in engine.pack_fused_weights).  Outputs: e [S,576], qry [S,128], ug [S,128], logit [S], pt [S,3],
- * pixel_val [S,2] with S = b*V*R*P. */
+ * pixel_val [S,2] with S = b*V*R*P.  prec 0: every layer on the fp32 matrix pipe; prec 1: the 576->288 layer on the f16 pipe
+ * with both operands split into fp16 high/low halves (3 products per term, fp32-class accuracy; `blob` must be packed for it). */
 size_t car_fused_blob_floats(void);
 size_t car_fused_bias_floats(void);
 int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
                       const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
                       const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                      float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, void* stream);
+                      float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, int prec, void* stream);
 
 /* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
  *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).

@@ -56,3 +56,26 @@ def test_fused_blob_layout():
     assert (y - m.key_map.weight.detach().reshape(128, 576).double() @ x).abs().max() < 1e-5
     # bias table order
     assert torch.equal(bias[:288], m.query_encode_latent_2.bias.detach()) and torch.equal(bias[416:544], m.key_map.bias.detach())
+
+
+def test_split_fp16_packing_reconstructs_the_weights():
+    """hi + lo of the packed fp16 halves reproduces W * 2^8 to ~2^-21 relative, in the [K group][hi|lo][lane][8] order."""
+    from cross_attention_renderer_amd.engine import W_SHIFT, _pack_tiles_f16_split, _std_k
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=8).eval()
+    S.perturb_parameters(m, seed=2)
+    W = m.query_encode_latent_2.weight.detach().reshape(288, 576)
+    tiles = _pack_tiles_f16_split(W, 9, _std_k(18)).view(torch.float16).reshape(18, 9, 2, 2, 64, 8).float()
+    rec = (tiles[:, :, :, 0] + tiles[:, :, :, 1]) / float(1 << W_SHIFT)        # (chunk, tile, kg, lane, e)
+    for c, t, kg, lane, e in [(0, 0, 0, 0, 0), (3, 2, 1, 37, 5), (17, 8, 1, 63, 7), (9, 4, 0, 31, 3)]:
+        n, k = 32 * t + lane % 32, 32 * c + 16 * (lane // 32) + 8 * kg + e
+        assert abs(rec[c, t, kg, lane, e].item() - W[n, k].item()) <= 2e-6 * abs(W[n, k].item()) + 1e-9
+    # thanks to the 2^8 scale most low halves are normal fp16 numbers; the subnormal ones belong to residuals that are tiny
+    # anyway (absolute error <= 2^-25 in scaled units)
+    lo = tiles[:, :, :, 1].abs()
+    assert (lo[lo > 0] >= 6.1e-5).float().mean() > 0.9
+    n_idx = 32 * torch.arange(9)[:, None] + (torch.arange(64) % 32)[None, :]
+    for c in (0, 7, 17):
+        for kg in (0, 1):
+            k_idx = 32 * c + 16 * (torch.arange(64) // 32)[:, None] + 8 * kg + torch.arange(8)[None, :]      # (lane, e)
+            want = W[n_idx[:, :, None].expand(9, 64, 8), k_idx[None].expand(9, 64, 8)]
+            assert (rec[c, :, kg] - want).abs().max() <= 4e-7 * W.abs().max()

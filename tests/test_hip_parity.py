@@ -195,6 +195,19 @@ def test_fused_sample_kernel_matches_stage_pipeline(name):
     _check_outputs(fused, lambda k: ora[k], "fused vs oracle")
 
 
+@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c3", "t2_c5"])
+def test_split_fp16_layer_is_fp32_class(name):
+    """The 576->288 layer on the f16 matrix pipe with fp16 hi/lo operand splits (three exact products per term) against the
+    same kernel on the fp32 pipe: the per-sample features must agree to ~1e-6, i.e. far inside the 1e-4 contract."""
+    c, fx, ora, a = run_case(name, split_fp16=True)
+    _, _, _, b_ = run_case(name, split_fp16=False)
+    e = err_stats(a["stages"]["interp_val"], b_["stages"]["interp_val"])
+    assert e["max"] < 5e-6, e
+    assert rel_err(a["rgb"], b_["rgb"]) < 1e-5
+    _check_outputs(a, lambda k: ora[k], "split-fp16 vs oracle")
+    _check_outputs(b_, lambda k: ora[k], "fp32 pipe vs oracle")
+
+
 def test_register_staged_weights_agree_with_lds_dma():
     """A/B of the two weight-staging variants of the MFMA kernel on a whole forward."""
     _, _, _, a = run_case("t1_c1", fuse_samples=False)
