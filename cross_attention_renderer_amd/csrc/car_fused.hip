@@ -201,7 +201,7 @@ __device__ __forceinline__ void store_rows(const f32x16 (&acc)[NT], float* row, 
 }
 
 // one chained layer with 128 outputs: B operands are the NSRC x 16 registers of `src` (optionally through ReLU)
-template <int NSRC, bool RELU, int ABL = 0>
+template <int NSRC, bool RELU, int ABL = 0, int PREC = 0>
 __device__ __forceinline__ void chained_layer(f32x16 (&acc)[kNTD], const f32x16 (&src)[NSRC], const float* __restrict__ blob,
                                               float* lds, int& g, int tid, int wave, int lane) {
 #pragma unroll
@@ -212,6 +212,41 @@ __device__ __forceinline__ void chained_layer(f32x16 (&acc)[kNTD], const f32x16 
         const NextChunk nx = next_chunk(blob, lds, g + 1);
         // slots are pinned with sched_barrier(0) (hipcc otherwise regroups the pieces and shrinks the latency slack they
         // were placed for); the A operand of the next group is therefore read one slot ahead by hand
+        if constexpr (PREC == 1) {
+            // split-fp16 path: per source tile, the 16 accumulator values of this lane become two 8-wide K groups (hi, lo);
+            // packed tile (Tl, t): [kg][hi|lo][lane][8 halves].  3 MFMAs of 32 cycles per (t, kg).
+#pragma unroll
+            for (int Tl = 0; Tl < 2; ++Tl) {
+                if (Tl < nsrc) {
+                    const f32x16& sv = src[T0 + Tl < NSRC ? T0 + Tl : NSRC - 1];
+                    half8 bhi[2], blo[2];
+#pragma unroll
+                    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                        for (int e8 = 0; e8 < 8; ++e8) {
+                            float x = sv[8 * kg + e8];
+                            if (RELU) x = fmaxf(x, 0.f);
+                            const _Float16 hi = (_Float16)x;
+                            bhi[kg][e8] = hi;
+                            blo[kg][e8] = (_Float16)(x - (float)hi);
+                        }
+#pragma unroll
+                    for (int t = 0; t < kNTD; ++t)
+#pragma unroll
+                        for (int kg = 0; kg < 2; ++kg) {
+                            const float* wt = wl + (Tl * kNTD + t) * kTile;
+                            const half8 ah = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wt + ((kg * 2 + 0) * 64) * 4));
+                            const half8 al = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wt + ((kg * 2 + 1) * 64) * 4));
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[kg], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[kg], acc[t], 0, 0, 0);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[kg], acc[t], 0, 0, 0);
+                            const int gq = (Tl * kNTD + t) * 2 + kg;
+                            if (gq < kNTE) stream_issue_tile<ABL>(nx, gq, tid, wave);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                }
+            }
+        } else {
         float4 aw[kNTD];
 #pragma unroll
         for (int t = 0; t < kNTD; ++t) aw[t] = *reinterpret_cast<const float4*>(wl + (t * 4) * 256);
@@ -242,9 +277,17 @@ __device__ __forceinline__ void chained_layer(f32x16 (&acc)[kNTD], const f32x16 
             }
             }
         }
+        }
         stream_sync<ABL>();
         ++g;
     }
+}
+
+// scale helpers of the split-fp16 layers: accumulators start at bias * 2^kWShift and are scaled back exactly
+template <int NT>
+__device__ __forceinline__ void scale_acc(f32x16 (&acc)[NT], float f) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] *= f;
 }
 
 // ABL > 0 are timing-only ablations (results are wrong by construction), selected with CAR_FUSED_ABLATE for tools/bench_fused.py:
@@ -382,6 +425,7 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
 
     f32x16 k1[kNTD];
     init_bias<kNTD>(k1, lds + kLdsBias + kBiasK1, h);
+    if constexpr (PREC == 1) scale_acc<kNTD>(k1, (float)(1 << kWShift));
     f32x16 acc[kNTE];
     float bv[16];                                                      // B operands of the current chunk (this lane's 16 channels)
 #pragma unroll
@@ -518,13 +562,15 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
             for (int t = 0; t < kNTE; ++t) acc[t] *= 1.0f / (float)(1 << kWShift);  // exact power of two
         }
         if constexpr (ABL == 4) { g += kChK1; }
-        else chained_layer<kNTE, false, ABL>(k1, acc, a.blob, lds, g, tid, wave, lane);
+        else chained_layer<kNTE, false, ABL, PREC>(k1, acc, a.blob, lds, g, tid, wave, lane);
         if (live) store_rows<kNTE>(acc, a.e + i * (2 * kE) + sv * kE, h);
     }
     f32x16 key[kNTD];
     init_bias<kNTD>(key, lds + kLdsBias + kBiasK2, h);
-    if constexpr (ABL != 4) chained_layer<kNTD, true, ABL>(key, k1, a.blob, lds, g, tid, wave, lane);
+    if constexpr (PREC == 1) { scale_acc<kNTD>(k1, 1.0f / (float)(1 << kWShift)); scale_acc<kNTD>(key, (float)(1 << kWShift)); }
+    if constexpr (ABL != 4) chained_layer<kNTD, true, ABL, PREC>(key, k1, a.blob, lds, g, tid, wave, lane);
     else g += 2;
+    if constexpr (PREC == 1) scale_acc<kNTD>(key, 1.0f / (float)(1 << kWShift));
 
     // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ;  ug = Wr1[:,128:] g + br1 ---------------------
     f32x16 t1[kNTD], qv[kNTD];
@@ -537,8 +583,10 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
     stream_sync();
     ++g;
     init_bias<kNTD>(qv, lds + kLdsBias + kBiasQ2, h);
-    if constexpr (ABL != 4) chained_layer<kNTD, true, ABL>(qv, t1, a.blob, lds, g, tid, wave, lane);   // qry
+    if constexpr (PREC == 1) scale_acc<kNTD>(qv, (float)(1 << kWShift));
+    if constexpr (ABL != 4) chained_layer<kNTD, true, ABL, PREC>(qv, t1, a.blob, lds, g, tid, wave, lane);   // qry
     else g += 2;
+    if constexpr (PREC == 1) scale_acc<kNTD>(qv, 1.0f / (float)(1 << kWShift));
     float dot = 0.0f;
 #pragma unroll
     for (int t = 0; t < kNTD; ++t)

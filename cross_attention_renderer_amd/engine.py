@@ -116,13 +116,15 @@ def pack_fused_weights(m, device, split_fp16: bool = False):
     E2 = C // 2
     wr = f(m.query_repeat_embed.weight)
     w2 = f(m.query_encode_latent_2.weight)
+    # 128-output chained layers: fp32 tiles, or fp16 hi/lo tiles when the f16 matrix pipe is used
+    pk4 = (lambda W, ck: _pack_tiles_f16_split(W, 4, ck)) if split_fp16 else (lambda W, ck: _pack_tiles(W, None, 4, ck))
     parts = [
         _pack_tiles_f16_split(w2, E2 // 32, _std_k(C // 32)) if split_fp16 else _pack_tiles(w2, None, E2 // 32, _std_k(C // 32)),   # W2
         _pack_tiles(f(m.query_embed.weight), v(m.query_embed.bias), 4, _std_k(1)),                            # Q1 (bias folded)
-        _pack_tiles(f(m.query_embed_2.weight), None, 4, _chained_k(4)),                                       # Q2
+        pk4(f(m.query_embed_2.weight), _chained_k(4)),                                                        # Q2
         _pack_tiles(wr[:, 128:].contiguous(), v(m.query_repeat_embed.bias), 4, _std_k(1)),                    # UG (bias folded)
-        torch.cat([_pack_tiles(f(m.key_map.weight), None, 4, _chained_k(E2 // 32, base=E2 * sv)) for sv in range(2)]),   # K1
-        _pack_tiles(f(m.key_map_2.weight), None, 4, _chained_k(4)),                                           # K2
+        torch.cat([pk4(f(m.key_map.weight), _chained_k(E2 // 32, base=E2 * sv)) for sv in range(2)]),         # K1
+        pk4(f(m.key_map_2.weight), _chained_k(4)),                                                            # K2
     ]
     blob = torch.cat([p_.reshape(-1) for p_ in parts]).to(device)
     bias = torch.cat([v(m.query_encode_latent_2.bias), v(m.query_embed_2.bias), v(m.key_map.bias), v(m.key_map_2.bias)]).to(device)
