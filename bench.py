@@ -30,7 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 H, P, V, CHUNK = 256, 64, 2, 8192
-FP32_MFMA_PEAK = 157.3e12
+FP32_MFMA_PEAK = 157.3e12          # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md)
+F16_MFMA_PEAK = 2.5e15             # v_mfma_f32_32x32x16_f16, dense (never the 2:1-sparse marketing figure)
 
 
 def build_model(device):
@@ -175,8 +176,14 @@ def main():
         if best is not None:
             name, _, lat, flop, desc = best
             mean = sum(lat) / len(lat)
+            # Peak of the pipe the kernel's matrix work runs on.  With the fp16 hi/lo split every fp32 multiply-add costs three
+            # f16 MFMA products, so the roof for *algorithmic* fp32 FLOPs is the dense f16 peak / 3.
+            split = "split x3" in desc
+            peak = F16_MFMA_PEAK / 3 if split else FP32_MFMA_PEAK
             roof = {"bound": "mfma", "kernel": desc, "achieved": flop / mean / 1e12,
-                    "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": flop / mean / FP32_MFMA_PEAK,
+                    "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flop / mean / peak,
+                    "peak_note": ("dense f16 MFMA peak 2500 / 3 products per fp32 term" if split else "dense fp32 MFMA peak"),
+                    "frac_of_fp32_pipe_peak": flop / mean / FP32_MFMA_PEAK,
                     "traffic": None, "launches": len(lat), "ms_per_launch": mean * 1e3, "flop_per_launch": flop}
             # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
             # profiles/ and MI355X_MICROARCH.md §HBM); PMC collection cannot run inside the timed bench itself

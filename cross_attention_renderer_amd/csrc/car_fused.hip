@@ -246,6 +246,9 @@ __device__ __forceinline__ void chained_layer(f32x16 (&acc)[kNTD], const f32x16 
                         }
                 }
             }
+            // a single-source-tile chunk has only 8 slots: issue the rest of a 9-tile successor here
+#pragma unroll
+            for (int gq = nsrc * 2 * kNTD; gq < kNTE; ++gq) stream_issue_tile<ABL>(nx, gq, tid, wave);
         } else {
         float4 aw[kNTD];
 #pragma unroll

@@ -480,8 +480,9 @@ class RenderEngine:
             # algorithmic MACs per sample on the matrix pipe: 2 x 576x288 (e), 576x128 + 128x128 (key), 16x128 + 128x128 (qry),
             # 16x128 (ug); the gather FMAs and the geometry are not counted
             macs = 2 * 576 * 288 + 576 * 128 + 128 * 128 + 16 * 128 + 128 * 128 + 16 * 128
+            pipe = "f16 matrix pipe, fp16 hi/lo split x3" if self.split_fp16 else "fp32 matrix pipe"
             self.timing.setdefault("fused_samples", []).append(
-                (ev[0], ev[1], 2.0 * S * macs, f"fused_sample_kernel on {S} samples (e, key, qry, ug, logits)"))
+                (ev[0], ev[1], 2.0 * S * macs, f"fused_sample_kernel on {S} samples (e, key, qry, ug, logits; {pipe})"))
         return self._finish(inp, z, b, V, R, P, 576, m.latent_dim, e, None, q, logit, ug, pt, pixel_val, poses, rays, coords9,
                             phi_x, ld_phi, debug, ug_ready=True)
 
