@@ -55,16 +55,16 @@ def make_frame(alpha: float, device):
     return inp, z
 
 
-def render_frame(model, inp, z, tile):
-    """One step: 8 forward calls of 8192 rays, results packed as [rgb(3), depth, valid] per ray."""
+def render_frame(model, inp, z, tile, chunk_rays=CHUNK):
+    """One step: the frame's 65 536 rays in forward calls of ``chunk_rays`` rays, results packed as [rgb(3), depth, valid]."""
     uv_all = inp["query"]["uv"]
     R = uv_all.shape[2]
-    for c0 in range(0, R, CHUNK):
-        chunk = {"context": inp["context"], "query": dict(inp["query"], uv=uv_all[:, :, c0:c0 + CHUNK])}
+    for c0 in range(0, R, chunk_rays):
+        chunk = {"context": inp["context"], "query": dict(inp["query"], uv=uv_all[:, :, c0:c0 + chunk_rays])}
         out = model(chunk, z=z)
-        tile[c0:c0 + CHUNK, 0:3] = out["rgb"][0, 0]
-        tile[c0:c0 + CHUNK, 3:4] = out["depth_ray"][0]
-        tile[c0:c0 + CHUNK, 4:5] = out["valid_mask"][0]
+        tile[c0:c0 + chunk_rays, 0:3] = out["rgb"][0, 0]
+        tile[c0:c0 + chunk_rays, 3:4] = out["depth_ray"][0]
+        tile[c0:c0 + chunk_rays, 4:5] = out["valid_mask"][0]
     return tile
 
 
@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-rays", type=int, default=4096, help="rays in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--chunk-rays", type=int, default=65536,
+                    help="rays per forward call: the whole frame by default (a 288 GB GPU does not need the reference render script's 8192-ray chunks; --chunk-rays 8192 reproduces them)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,7 +139,7 @@ def main():
     gather = TileGather(world, R, 5, dev) if world > 1 else None
 
     def step():
-        render_frame(model, inp, z, tile)
+        render_frame(model, inp, z, tile, args.chunk_rays)
         if gather is not None:
             gather(tile)
 
@@ -201,7 +203,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "256x256 query frame, 64 samples/view, 2 context views (config 2), 8 chunks x 8192 rays",
+            "config": {"workload": f"256x256 query frame, 64 samples/view, 2 context views (config 2), {-(-65536 // args.chunk_rays)} forward calls x {args.chunk_rays} rays",
                        "rays_per_step_per_gpu": R, "parallelism": f"ray-sharded frames x{world}, RCCL all-gather of tiles"},
             "roofline": roof,
             "cpu_baseline": cpu_baseline(args.cpu_rays) if args.cpu_rays > 0 else None,

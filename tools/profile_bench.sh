@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --steps 1 --warmup 1 --cpu-rays 0"
+BENCH="python $ROOT/bench.py --steps 1 --warmup 1 --cpu-rays 0 ${BENCH_EXTRA:-}"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o bench -- $BENCH > $OUT/fetch.log 2>&1
