@@ -36,6 +36,7 @@ SIGNATURES = {
     "car_linear": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_long, c_int, _P]),
     "car_attend": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P, c_int, c_int,
                            _P, _P, _P, _P, _P]),
+    "car_round2_logits": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "car_add_ray_bias_relu": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "car_finalize": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
 }

@@ -1,0 +1,100 @@
+// car_round2.hip — per-sample part of the second attention round in one kernel (reference
+// models.py:548-556):
+//     q2    = Wr2 relu(ug + uh[ray]) + br2         ug = Wr1[:,128:] g + br1 (per sample, from the fused kernel),
+//                                                  uh = Wr1[:,:128] encode_latent(z1)   (per ray)
+//     logit = <q2, qry> / 16
+// q2 never exists in memory: it is produced in the MFMA accumulators (weights as A operand, samples as B operand, see
+// car_linear.hip) and immediately dotted with the sample's qry row.  The 128x128 layer (64 KB packed) is loaded into LDS
+// once per workgroup, so there is no weight stream and no barrier in the main loop.  HBM-bound: it reads ug and qry
+// (2 x 512 B per sample) and writes 4 B per sample.
+#include "car_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kD = 128, kNT = 4, kTile = 1024, kChunks = 4;
+constexpr size_t kLdsBytes = (size_t)(kChunks * kNT * kTile + kD) * sizeof(float);
+
+__global__ void __launch_bounds__(256, 2) round2_kernel(const float* __restrict__ ug, const float* __restrict__ uh,
+                                                        const float* __restrict__ qry, const float* __restrict__ wpacked,
+                                                        const float* __restrict__ bias, int V, int R, int P, long S,
+                                                        float* __restrict__ logit) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane & 31, h = lane >> 5;
+    for (int k = tid; k < kChunks * kNT * kTile / 4; k += 256)
+        *reinterpret_cast<float4*>(lds + 4 * k) = *reinterpret_cast<const float4*>(wpacked + 4 * k);
+    if (tid < kD) lds[kChunks * kNT * kTile + tid] = bias[tid];
+    __syncthreads();
+    const float* lbias = lds + kChunks * kNT * kTile;
+
+    for (long row0 = ((long)blockIdx.x * 4 + wave) * 32; row0 < S; row0 += (long)gridDim.x * 128) {
+        const long row = row0 + s < S ? row0 + s : S - 1;
+        const long nr = row / P;                                   // (scene-view n, ray r)
+        const long ray = ((nr / R) / V) * R + nr % R;              // (scene, ray): uh is shared by the views
+        const float* xrow = ug + row * kD;
+        const float* urow = uh + ray * kD;
+        f32x16 acc[kNT];
+#pragma unroll
+        for (int t = 0; t < kNT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = lbias[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            float bv[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 x = *reinterpret_cast<const float4*>(xrow + 32 * c + 16 * h + 4 * q);
+                const float4 u = *reinterpret_cast<const float4*>(urow + 32 * c + 16 * h + 4 * q);
+                bv[4 * q + 0] = fmaxf(x.x + u.x, 0.f); bv[4 * q + 1] = fmaxf(x.y + u.y, 0.f);
+                bv[4 * q + 2] = fmaxf(x.z + u.z, 0.f); bv[4 * q + 3] = fmaxf(x.w + u.w, 0.f);
+            }
+            const float* wl = lds + c * kNT * kTile + 4 * lane;
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) {
+                    const float4 a = *reinterpret_cast<const float4*>(wl + (t * 4 + j4) * 256);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv[4 * j4 + 0], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv[4 * j4 + 1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv[4 * j4 + 2], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv[4 * j4 + 3], acc[t], 0, 0, 0);
+                }
+        }
+        // <q2, qry>: lane (s, h) holds channels 32 t + 8 g + 4 h + (0..3) of its sample in acc[t][4g..4g+3]
+        const float* qrow = qry + row * kD;
+        float dot = 0.0f;
+#pragma unroll
+        for (int t = 0; t < kNT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 qv = *reinterpret_cast<const float4*>(qrow + 32 * t + 8 * g + 4 * h);
+                dot = fmaf(acc[t][4 * g + 0], qv.x, dot); dot = fmaf(acc[t][4 * g + 1], qv.y, dot);
+                dot = fmaf(acc[t][4 * g + 2], qv.z, dot); dot = fmaf(acc[t][4 * g + 3], qv.w, dot);
+            }
+        dot += __shfl_xor(dot, 32, 64);
+        if (h == 0 && row0 + s < S) logit[row0 + s] = dot / 16.0f;
+    }
+}
+
+}  // namespace
+
+extern "C" int car_round2_logits(const float* ug, const float* uh, const float* qry, const float* wpacked, const float* bias,
+                                 int b, int V, int R, int P, float* logit, void* stream) {
+    CAR_REQUIRE(ug && uh && qry && wpacked && bias && logit, "car_round2_logits: null pointer");
+    CAR_REQUIRE(b > 0 && V > 0 && R > 0 && P > 0, "car_round2_logits: bad sizes");
+    const long S = (long)b * V * R * P;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)round2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+        if (e != hipSuccess) { car_set_error("car_round2_logits: cannot reserve LDS: %s", hipGetErrorString(e)); return CAR_E_LAUNCH; }
+        attr = true;
+    }
+    const long groups = (S + 127) / 128;
+    const unsigned blocks = (unsigned)(groups < 2048 ? groups : 2048);       // 2 workgroups per CU x 256 CUs x 4: grid-stride
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(round2_kernel, dim3(blocks), dim3(256), kLdsBytes, (hipStream_t)stream, ug, uh, qry, wpacked, bias, V, R,
+                       P, S, logit);
+    CAR_CHECK_LAUNCH("car_round2_logits");
+    return CAR_OK;
+}

@@ -131,6 +131,13 @@ def pack_fused_weights(m, device, split_fp16: bool = False):
     return blob, bias
 
 
+def pack_round2_weights(m, device):
+    """query_repeat_embed_2 (128 -> 128) in the operand order of csrc/car_round2.hip: (packed [4,4,1024], bias [128])."""
+    W = m.query_repeat_embed_2.weight.detach().float().cpu().reshape(128, 128)
+    return (_pack_tiles(W, None, 4, _std_k(4)).reshape(-1).to(device),
+            m.query_repeat_embed_2.bias.detach().float().to(device).contiguous())
+
+
 class RenderEngine:
     """Per-module state of the HIP path: packed weights (re-packed when the parameters change) and the
     channel-last copies of the last feature pyramid."""
@@ -155,6 +162,9 @@ class RenderEngine:
         # 576->288 layer of the fused kernel on the f16 matrix pipe with fp16 hi/lo operand splits (3 products per term,
         # fp32-class accuracy) instead of the fp32 pipe
         self.split_fp16 = True
+        self.fuse_round2 = True        # round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
+        self._round2_key = None
+        self._round2 = None
         self._fused_key = None
         self._fused = None
         self._pose_key = None
@@ -520,13 +530,26 @@ class RenderEngine:
             self.linear(hb, 128, pk["query_repeat_embed.h"], uh, 128, b * R)
             if not ug_ready:
                 self.linear(g_or_ug, 16, pk["query_repeat_embed.g"], k1, 128, S)
-            if key is None:
-                key = torch.empty(S, 128, **f32)
-            _lib.check(lib.car_add_ray_bias_relu(_ptr(k1), _ptr(uh), b, V, R, P, 128, st), "car_add_ray_bias_relu")
-            self.linear(k1, 128, pk["query_repeat_embed_2"], key, 128, S)
             at_wt2 = torch.empty(n, R, P, **f32)
-            _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt2),
-                                      _ptr(ebar), Ce, 1, None, None, None, None, st), "car_attend")
+            if self.fuse_round2:
+                # q2 = Wr2 relu(ug + uh) + b and <q2, qry>/16 in one kernel: q2 is never written
+                w = m.query_repeat_embed_2.weight
+                rk = (w.data_ptr(), w._version, m.query_repeat_embed_2.bias._version, str(dev))
+                if rk != self._round2_key:
+                    self._round2 = pack_round2_weights(m, dev)
+                    self._round2_key = rk
+                logit2 = torch.empty(S, **f32)
+                _lib.check(lib.car_round2_logits(_ptr(k1), _ptr(uh), _ptr(q), _ptr(self._round2[0]), _ptr(self._round2[1]),
+                                                 b, V, R, P, _ptr(logit2), st), "car_round2_logits")
+                _lib.check(lib.car_attend(_ptr(logit2), None, 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt2),
+                                          _ptr(ebar), Ce, 1, None, None, None, None, st), "car_attend")
+            else:
+                if key is None:
+                    key = torch.empty(S, 128, **f32)
+                _lib.check(lib.car_add_ray_bias_relu(_ptr(k1), _ptr(uh), b, V, R, P, 128, st), "car_add_ray_bias_relu")
+                self.linear(k1, 128, pk["query_repeat_embed_2"], key, 128, S)
+                _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt2),
+                                          _ptr(ebar), Ce, 1, None, None, None, None, st), "car_attend")
             # z = (Wv ebar2 + bv) + V * z1   (models.py:561-565: "+ z_local" per view, then the view sum)
             zv = zrep.view(b * R, V, Dl)
             zv[:, 0] = z1 * float(V)

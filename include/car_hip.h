@@ -151,6 +151,13 @@ int car_attend(const float* qa, const float* qb, int dq, const float* val, int D
                const float* zprev, float zprev_scale, float* w_out, float* z_out, int ld_z, int reps,
                const float* pt, const float* poses, float* depth, int32_t* w_argmax, void* stream);
 
+/* ---- a15, per-sample half in one kernel: logit[row] = <Wr2 relu(ug[row] + uh[ray(row)]) + br2, qry[row]> / 16
+ * (models.py:552-555).  ug, qry [b*V,R,P,128]; uh [b,R,128]; wpacked: query_repeat_embed_2.weight (128x128) in MFMA
+ * operand order, 4 chunks x 4 tiles x 1024 floats, standard K mapping, no folded bias (engine.pack_round2_weights);
+ * bias [128].  The second-round query q2 is never written. */
+int car_round2_logits(const float* ug, const float* uh, const float* qry, const float* wpacked, const float* bias,
+                      int b, int V, int R, int P, float* logit, void* stream);
+
 /* r[row, c] = relu(r[row, c] + u[ray(row), c]) with ray(row) = scene b, ray r of the sample row (models.py:549-553:
  * the z_embed half of query_repeat_embed is constant along the samples of a ray). r [b*V,R,P,C], u [b,R,C]. */
 int car_add_ray_bias_relu(float* r, const float* u, int b, int V, int R, int P, int C, void* stream);

@@ -208,6 +208,17 @@ def test_split_fp16_layer_is_fp32_class(name):
     _check_outputs(b_, lambda k: ora[k], "fp32 pipe vs oracle")
 
 
+@pytest.mark.parametrize("name", ["t0_default", "t0_p5", "t0_nview1", "t0_nview3", "t1_c1", "t2_c3"])
+def test_round2_logit_kernel_matches_stage_kernels(name):
+    """csrc/car_round2.hip (second-round query layer + logits, q2 never stored) against add_ray_bias_relu + car_linear +
+    the logits phase of car_attend."""
+    c, fx, ora, a = run_case(name, fuse_round2=True)
+    _, _, _, b_ = run_case(name, fuse_round2=False)
+    assert rel_err(a["stages"]["at_wt2"], b_["stages"]["at_wt2"]) < 1e-5
+    assert rel_err(a["rgb"], b_["rgb"]) < 1e-5
+    _check_outputs(a, lambda k: ora[k], "fused round 2 vs oracle")
+
+
 def test_register_staged_weights_agree_with_lds_dma():
     """A/B of the two weight-staging variants of the MFMA kernel on a whole forward."""
     _, _, _, a = run_case("t1_c1", fuse_samples=False)
