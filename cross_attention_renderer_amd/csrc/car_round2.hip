@@ -4,7 +4,8 @@
 //                                                  uh = Wr1[:,:128] encode_latent(z1)   (per ray)
 //     logit = <q2, qry> / 16
 // q2 never exists in memory: it is produced in the MFMA accumulators (weights as A operand, samples as B operand, see
-// car_linear.hip) and immediately dotted with the sample's qry row.  The 128x128 layer (64 KB packed) is loaded into LDS
+// car_linear.hip; f16 matrix pipe with fp16 hi/lo operand splits as in car_fused.hip) and immediately dotted with the
+// sample's qry row.  The 128x128 layer (64 KB packed) is loaded into LDS
 // once per workgroup, so there is no weight stream and no barrier in the main loop.  HBM-bound: it reads ug and qry
 // (2 x 512 B per sample) and writes 4 B per sample.
 #include "car_common.h"
@@ -12,6 +13,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr int kWShift = 8;          // the packed fp16 hi/lo weights carry 2^8 (see car_fused.hip, PREC = 1)
 constexpr int kD = 128, kNT = 4, kTile = 1024, kChunks = 4;
 constexpr size_t kLdsBytes = (size_t)(kChunks * kNT * kTile + kD) * sizeof(float);
 
@@ -34,31 +37,48 @@ __global__ void __launch_bounds__(256, 2) round2_kernel(const float* __restrict_
         const long ray = ((nr / R) / V) * R + nr % R;              // (scene, ray): uh is shared by the views
         const float* xrow = ug + row * kD;
         const float* urow = uh + ray * kD;
+        // all inputs of the row first (8 x 16-byte loads of ug, 8 of uh): the layer itself is short on the f16 pipe
+        float4 xs[kChunks * 4], us[kChunks * 4];
+#pragma unroll
+        for (int k = 0; k < kChunks * 4; ++k) {
+            xs[k] = *reinterpret_cast<const float4*>(xrow + 32 * (k / 4) + 16 * h + 4 * (k % 4));
+            us[k] = *reinterpret_cast<const float4*>(urow + 32 * (k / 4) + 16 * h + 4 * (k % 4));
+        }
         f32x16 acc[kNT];
 #pragma unroll
         for (int t = 0; t < kNT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = lbias[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
+            for (int r = 0; r < 16; ++r) acc[t][r] = lbias[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h] * (float)(1 << kWShift);
 #pragma unroll
         for (int c = 0; c < kChunks; ++c) {
             float bv[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 x = *reinterpret_cast<const float4*>(xrow + 32 * c + 16 * h + 4 * q);
-                const float4 u = *reinterpret_cast<const float4*>(urow + 32 * c + 16 * h + 4 * q);
+                const float4 x = xs[4 * c + q], u = us[4 * c + q];
                 bv[4 * q + 0] = fmaxf(x.x + u.x, 0.f); bv[4 * q + 1] = fmaxf(x.y + u.y, 0.f);
                 bv[4 * q + 2] = fmaxf(x.z + u.z, 0.f); bv[4 * q + 3] = fmaxf(x.w + u.w, 0.f);
             }
+            // fp16 hi/lo split of the activations, three exact products per term on the f16 matrix pipe
+            half8 bhi[2], blo[2];
+#pragma unroll
+            for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const float x = bv[8 * kg + e8];
+                    const _Float16 hi = (_Float16)x;
+                    bhi[kg][e8] = hi;
+                    blo[kg][e8] = (_Float16)(x - (float)hi);
+                }
             const float* wl = lds + c * kNT * kTile + 4 * lane;
 #pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4)
+            for (int t = 0; t < kNT; ++t)
 #pragma unroll
-                for (int t = 0; t < kNT; ++t) {
-                    const float4 a = *reinterpret_cast<const float4*>(wl + (t * 4 + j4) * 256);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv[4 * j4 + 0], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv[4 * j4 + 1], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv[4 * j4 + 2], acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv[4 * j4 + 3], acc[t], 0, 0, 0);
+                for (int kg = 0; kg < 2; ++kg) {
+                    const half8 ah = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wl + t * kTile + ((kg * 2 + 0) * 64) * 4));
+                    const half8 al = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wl + t * kTile + ((kg * 2 + 1) * 64) * 4));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[kg], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[kg], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[kg], acc[t], 0, 0, 0);
                 }
         }
         // <q2, qry>: lane (s, h) holds channels 32 t + 8 g + 4 h + (0..3) of its sample in acc[t][4g..4g+3]
@@ -73,7 +93,7 @@ __global__ void __launch_bounds__(256, 2) round2_kernel(const float* __restrict_
                 dot = fmaf(acc[t][4 * g + 2], qv.z, dot); dot = fmaf(acc[t][4 * g + 3], qv.w, dot);
             }
         dot += __shfl_xor(dot, 32, 64);
-        if (h == 0 && row0 + s < S) logit[row0 + s] = dot / 16.0f;
+        if (h == 0 && row0 + s < S) logit[row0 + s] = dot * (1.0f / (float)(1 << kWShift)) / 16.0f;
     }
 }
 

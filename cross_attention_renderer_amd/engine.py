@@ -134,7 +134,7 @@ def pack_fused_weights(m, device, split_fp16: bool = False):
 def pack_round2_weights(m, device):
     """query_repeat_embed_2 (128 -> 128) in the operand order of csrc/car_round2.hip: (packed [4,4,1024], bias [128])."""
     W = m.query_repeat_embed_2.weight.detach().float().cpu().reshape(128, 128)
-    return (_pack_tiles(W, None, 4, _std_k(4)).reshape(-1).to(device),
+    return (_pack_tiles_f16_split(W, 4, _std_k(4)).reshape(-1).to(device),
             m.query_repeat_embed_2.bias.detach().float().to(device).contiguous())
 
 

@@ -153,7 +153,7 @@ int car_attend(const float* qa, const float* qb, int dq, const float* val, int D
 
 /* ---- a15, per-sample half in one kernel: logit[row] = <Wr2 relu(ug[row] + uh[ray(row)]) + br2, qry[row]> / 16
  * (models.py:552-555).  ug, qry [b*V,R,P,128]; uh [b,R,128]; wpacked: query_repeat_embed_2.weight (128x128) in MFMA
- * operand order, 4 chunks x 4 tiles x 1024 floats, standard K mapping, no folded bias (engine.pack_round2_weights);
+ * operand order, 4 chunks x 4 tiles, fp16 hi/lo halves scaled by 2^8 (engine.pack_round2_weights), no folded bias;
  * bias [128].  The second-round query q2 is never written. */
 int car_round2_logits(const float* ug, const float* uh, const float* qry, const float* wpacked, const float* bias,
                       int b, int V, int R, int P, float* logit, void* stream);
