@@ -1,0 +1,492 @@
+// car_fused2.hip — second generation of the fused per-sample kernel (car_fused.hip has the algorithm and the reference
+// line numbers; this file changes only the CDNA4 mapping).
+//
+// PMC counters of car_fused.hip (profiles/r06): one wave per SIMD, matrix pipe busy 25 % of the wave's cycles, 29 % parked
+// in s_waitcnt/barriers, 26 % issuing VALU (gather FMAs, fp16 splits) that a single in-order wave cannot overlap with its
+// own MFMAs.  The cure is a second wave per SIMD, i.e. at most 256 registers per wave instead of 464:
+//   * one workgroup = 8 waves = 128 consecutive samples (same weight stream, same LDS budget), each wave owns 16 samples;
+//   * v_mfma_f32_16x16x32_f16 (K = 32 = one whole weight chunk per instruction): weights are the A operand (16 output
+//     channels per tile), samples the B operand; a 288-wide accumulator set is 18 tiles x 4 registers = 72 registers,
+//     the 128-wide ones 32;
+//   * all layers run split-fp16 (x = hi + lo, three products per term, weights pre-scaled by 2^kWShift; see
+//     car_fused.hip), including the two K = 16 layers fed by the geometric query;
+//   * chained layers: the C/D layout of a 16x16 tile is  channel = 16 t + 4 (lane >> 4) + r , so two source tiles give a
+//     lane its 8 B values of one K = 32 step; the host bakes  k = 16 (2 m + e/4) + 4 (lane >> 4) + e%4  into the packed
+//     weights (engine.pack_fused2_weights, tests/test_fused_pack.py).
+#include "car_common.h"
+#include "car_geom.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int kWShift = 8;
+
+constexpr int kC = 576;            // feature channels = width of h
+constexpr int kE = 288;            // per-source width of e
+constexpr int kD = 128;            // hidden width of the key / query MLPs
+constexpr int kKS = kC / 32;       // 18 K steps (= weight chunks) of the 576 -> 288 layer
+constexpr int kTE = kE / 16;       // 18 output tiles of 16 channels
+constexpr int kTD = kD / 16;       // 8 output tiles
+constexpr int kTile = 512;         // packed floats per (K step, tile): [hi|lo][64 lanes][8 halves] = 2 KB
+constexpr int kStageLd = 36;       // row stride of the wave-private h tile (floats)
+constexpr int kWaves = 8, kRows = 16, kGroup = kWaves * kRows;       // 128 samples per workgroup
+
+// ---- packed-weight blob: offsets in tiles, layer by layer, [K step][tile] inside a layer ---------------------------
+constexpr int kOffW2 = 0;                          // 18 steps x 18 tiles, standard K mapping
+constexpr int kOffQ1 = kOffW2 + kKS * kTE;         // 1 x 8, standard, bias folded at k = 16
+constexpr int kOffQ2 = kOffQ1 + kTD;               // 4 x 8, chained
+constexpr int kOffUG = kOffQ2 + 4 * kTD;           // 1 x 8, standard, bias folded
+constexpr int kOffK1 = kOffUG + kTD;               // 18 x 8, chained over [e_0 ; e_1] (9 steps per source)
+constexpr int kOffK2 = kOffK1 + 18 * kTD;          // 4 x 8, chained
+constexpr int kBlobTiles = kOffK2 + 4 * kTD;
+constexpr int kNumChunks = 2 * kKS + 2 * 5 + 2 + 1 + 2 + 1;           // 52 weight chunks per pass, same order as car_fused.hip
+constexpr int kChunkTiles = kTE;                   // largest chunk: 18 tiles = 36 KB
+constexpr int kPieces = 5;                         // LDS-DMA pieces per chunk: 8 waves x 1 KB each
+
+constexpr int kBiasE = 0, kBiasQ2 = kE, kBiasK1 = kE + kD, kBiasK2 = kE + 2 * kD, kBiasFloats = kE + 3 * kD;
+
+// ---- dynamic LDS carve-up (floats) --------------------------------------------------------------------------------
+constexpr int kLdsW = 0;                                        // [2][18][512]           weight chunks          72 KB
+constexpr int kLdsStage = kLdsW + 2 * kChunkTiles * kTile;      // [8][16][36]            h tiles, wave private   18 KB
+constexpr int kLdsTapI = kLdsStage + kGroup * kStageLd;         // [128][2][3][4] int     tap texel indices       12 KB
+constexpr int kLdsTapW = kLdsTapI + kGroup * 24;                // [128][2][3][4]         tap weights             12 KB
+constexpr int kLdsPe = kLdsTapW + kGroup * 24;                  // [128][2][4]            tanh(pt_s/5)             4 KB
+constexpr int kLdsWpt = kLdsPe + kGroup * 8;                    // [576][4]               (W1[:,C:C+3], b1)        9 KB
+constexpr int kLdsBias = kLdsWpt + kC * 4;                      // [672]
+constexpr int kLdsFloats = kLdsBias + kBiasFloats;
+constexpr size_t kLdsBytes = (size_t)kLdsFloats * sizeof(float);
+
+struct Fused2Args {
+    const CarPose* poses;
+    const CarRay* rays;
+    const float* steps;
+    const float* gmap[3];
+    int gh[3], gw[3];
+    const float* wpt;
+    const float* blob;
+    const float* bias;
+    int b, V, R, P, H, W;
+    int xcd_bands;
+    int ray_major;
+    long S;
+    float* e;
+    float* qry;
+    float* ug;
+    float* logit;
+    float* pt;
+    float* pixel_val;
+};
+
+// chunk order:  W2 x18 (source 0) | K1 over e_0 x5 (2,2,2,2,1 K steps) | W2 x18 (source 1) | K1 over e_1 x5 | K2 x2 | Q1 | Q2 x2 | UG
+constexpr int kChK1 = 5;
+constexpr int kG_K1a = kKS, kG_W2b = kG_K1a + kChK1, kG_K1b = kG_W2b + kKS, kG_K2 = kG_K1b + kChK1, kG_Q1 = kG_K2 + 2,
+              kG_Q2 = kG_Q1 + 1, kG_UG = kG_Q2 + 2;
+__device__ __forceinline__ int chunk_tile_offset(int g) {
+    if (g < kG_K1a) return kOffW2 + g * kTE;
+    if (g < kG_W2b) return kOffK1 + (g - kG_K1a) * 2 * kTD;
+    if (g < kG_K1b) return kOffW2 + (g - kG_W2b) * kTE;
+    if (g < kG_K2) return kOffK1 + 9 * kTD + (g - kG_K1b) * 2 * kTD;
+    if (g < kG_Q1) return kOffK2 + (g - kG_K2) * 2 * kTD;
+    if (g < kG_Q2) return kOffQ1;
+    if (g < kG_UG) return kOffQ2 + (g - kG_Q2) * 2 * kTD;
+    return kOffUG;
+}
+__device__ __forceinline__ int chunk_tiles(int g) {
+    if (g < kG_K1a || (g >= kG_W2b && g < kG_K1b)) return kTE;
+    if (g == kG_W2b - 1 || g == kG_K2 - 1 || g == kG_Q1 || g == kG_UG) return kTD;       // odd last K1 step, Q1, UG
+    return 2 * kTD;
+}
+
+// Descriptor of the chunk to prefetch, resolved once per chunk with scalar branches so the per-piece issue is straight-line
+struct NextChunk { const float* src; float* dst; int nkb; };
+__device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, float* lds, int g) {
+    const int ge = g < kNumChunks ? g : kNumChunks - 1;            // past the end: re-copy the last chunk onto itself
+    NextChunk n;
+    n.src = blob + (long)chunk_tile_offset(ge) * kTile;
+    n.dst = lds + kLdsW + (ge & 1) * kChunkTiles * kTile;
+    n.nkb = 2 * chunk_tiles(ge);
+    return n;
+}
+// piece p of the next chunk: wave w copies KB number 8 p + w (wrapped into the chunk: re-copying identical bytes is harmless).
+// LDS-DMA in inline asm, see car_linear.hip.  Must only run after the barrier that retired the buffer's previous chunk.
+template <int ABL = 0>
+__device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, int lane, int wave) {
+    if constexpr (ABL == 3) return;
+    int kb = 8 * p + wave;
+    kb = kb < n.nkb ? kb : kb - n.nkb;
+    kb = kb < n.nkb ? kb : kb - n.nkb;
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(n.dst + kb * 256));
+    const float* gsrc = n.src + kb * 256 + 4 * lane;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int ABL = 0>
+__device__ __forceinline__ void stream_issue_all(const float* __restrict__ blob, float* lds, int g, int lane, int wave) {
+    if (g >= kNumChunks) return;
+    const NextChunk n = next_chunk(blob, lds, g);
+#pragma unroll
+    for (int p = 0; p < kPieces; ++p) stream_issue_piece<ABL>(n, p, lane, wave);
+}
+template <int ABL = 0>
+__device__ __forceinline__ void stream_sync() {
+    if constexpr (ABL == 3) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+__device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const _Float16 hh = (_Float16)x[e];
+        hi[e] = hh;
+        lo[e] = (_Float16)(x[e] - (float)hh);
+    }
+}
+
+// two output tiles x three split products, interleaved so consecutive MFMAs never share an accumulator
+__device__ __forceinline__ void mfma_pair(f32x4& c0, f32x4& c1, const float* w0, const float* w1, const half8& bhi, const half8& blo) {
+    const half8 ah0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0));
+    const half8 ah1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1));
+    const half8 al0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0 + 256));
+    const half8 al1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1 + 256));
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhi, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhi, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blo, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blo, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bhi, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bhi, c1, 0, 0, 0);
+}
+
+// accumulators start at bias * scale: lane (s, q) register r of tile t holds channel 16 t + 4 q + r
+template <int NT>
+__device__ __forceinline__ void init_bias(f32x4 (&acc)[NT], const float* lbias, int q, float scale) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float4 b4 = *reinterpret_cast<const float4*>(lbias + 16 * t + 4 * q);
+        acc[t][0] = b4.x * scale; acc[t][1] = b4.y * scale; acc[t][2] = b4.z * scale; acc[t][3] = b4.w * scale;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void scale_acc(f32x4 (&acc)[NT], float f) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] *= f;
+}
+template <int NT>
+__device__ __forceinline__ void store_rows(const f32x4 (&acc)[NT], float* row, int q) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        *reinterpret_cast<float4*>(row + 16 * t + 4 * q) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+}
+
+// one chained layer with 128 outputs over NSRC source tiles (two per K step), weight chunks of two K steps
+template <int NSRC, bool RELU, int ABL>
+__device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&src)[NSRC], const float* __restrict__ blob,
+                                              float* lds, int& g, int lane, int wave) {
+    constexpr int kSteps = NSRC / 2;
+#pragma unroll
+    for (int m0 = 0; m0 < kSteps; m0 += 2) {
+        const int nks = m0 + 1 < kSteps ? 2 : 1;
+        const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
+        const NextChunk nx = next_chunk(blob, lds, g + 1);
+#pragma unroll
+        for (int kl = 0; kl < 2; ++kl) {
+            if (kl < nks) {
+                const int m = m0 + kl < kSteps ? m0 + kl : kSteps - 1;
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    x[e] = src[2 * m + (e >> 2)][e & 3];
+                    if (RELU) x[e] = fmaxf(x[e], 0.f);
+                }
+                half8 bhi, blo;
+                split8(x, bhi, blo);
+#pragma unroll
+                for (int q = 0; q < kTD / 2; ++q) {
+                    const float* w0 = wl + ((kl * kTD + 2 * q) * 2) * 256;
+                    mfma_pair(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, bhi, blo);
+                    if (kl * 4 + q < kPieces) stream_issue_piece<ABL>(nx, kl * 4 + q, lane, wave);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // a single-step chunk has only 4 slots: issue the remaining pieces of its successor here
+#pragma unroll
+        for (int p = nks * 4; p < kPieces; ++p) stream_issue_piece<ABL>(nx, p, lane, wave);
+        stream_sync<ABL>();
+        ++g;
+    }
+}
+
+// a K = 16 (+ folded bias) layer with 128 outputs: one K step, B operand (ghi, glo) prepared by the caller
+__device__ __forceinline__ void small_layer(f32x4 (&acc)[kTD], const half8& ghi, const half8& glo, const float* wl) {
+#pragma unroll
+    for (int q = 0; q < kTD / 2; ++q) {
+        const float* w0 = wl + (2 * q * 2) * 256;
+        mfma_pair(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, ghi, glo);
+    }
+}
+
+// ABL > 0: timing-only ablations (wrong results): 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers,
+// 4 no MFMAs in the e path (gather, DMA and barriers only)
+template <int ABL>
+__global__ void __launch_bounds__(512) fused2_kernel(const Fused2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane & 15, q4 = lane >> 4;
+    const int nblk = gridDim.x;
+    int blk = blockIdx.x;
+    if (a.xcd_bands) {                                                 // contiguous band of sample groups per XCD, see car_fused.hip
+        const int q8 = nblk / 8, r8 = nblk % 8, xcd = blk % 8, idx = blk / 8;
+        blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    // Which 128 samples: with ray_major a workgroup takes 16 consecutive rays x 8 consecutive steps, wave = step, lane = ray, so
+    // the 16 rows a wave gathers together are the SAME step of neighbouring rays: their taps fall on neighbouring texels
+    // (shared 128-byte rows -> L1 hits instead of 16 unrelated misses spread along one epipolar line).
+    long i;
+    bool live;
+    if (a.ray_major) {
+        const int pgs = (a.P + kWaves - 1) / kWaves, bundles = (a.R + kRows - 1) / kRows;
+        const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
+        const int ray = bun * kRows + s, pp = pg * kWaves + wave;
+        live = ray < a.R && pp < a.P;
+        i = ((long)nn * a.R + (ray < a.R ? ray : a.R - 1)) * a.P + (pp < a.P ? pp : a.P - 1);
+    } else {
+        const long i_raw = (long)blk * kGroup + wave * kRows + s;
+        live = i_raw < a.S;
+        i = live ? i_raw : a.S - 1;
+    }
+
+    for (int k = tid; k < kC; k += 512) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
+    for (int k = tid; k < kBiasFloats; k += 512) lds[kLdsBias + k] = a.bias[k];
+    int g = 0;
+    stream_issue_all<ABL>(a.blob, lds, 0, lane, wave);
+
+    // ---- geometry of this lane's sample (the four lane groups repeat it); lane group 0 / 1 prepares source view 0 / 1 ----
+    const int P = a.P, V = a.V;
+    const int p = (int)(i % P);
+    const long nr = i / P;
+    const int n = (int)(nr / a.R);
+    const int v = n % V, sc = n / V;
+    half8 ghi, glo;                                                    // B operand of the two layers fed by g (k = 16: folded bias)
+    {
+        const CarPose& Ps = a.poses[n];
+        const CarRay ray = a.rays[nr];
+        CarSample smp;
+        for (int k = 0; k < 2; ++k) smp.grid[k] = ray.start[k] + (ray.end[k] - ray.start[k]) * a.steps[p];
+        car_sample_setup(Ps, a.poses + sc * 2, ray, 2, a.H, a.W, &smp);
+        if (q4 < 2) {
+            const int sv = q4;
+            float gx, gy;
+            int mode, m;
+            if (sv == v) { gx = smp.grid[0]; gy = smp.grid[1]; mode = 0; m = n; }
+            else { gx = sv == 0 ? smp.grid_in[0][0] : smp.grid_in[1][0]; gy = sv == 0 ? smp.grid_in[0][1] : smp.grid_in[1][1]; mode = 1; m = sc * V + sv; }
+            int* ti = reinterpret_cast<int*>(lds + kLdsTapI) + ((wave * kRows + s) * 2 + sv) * 12;
+            float* tw = lds + kLdsTapW + ((wave * kRows + s) * 2 + sv) * 12;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                int idx[4];
+                float w[4];
+                car_bilinear_taps(gx, gy, a.gw[l], a.gh[l], mode, idx, w);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { ti[4 * l + t] = m * a.gh[l] * a.gw[l] + idx[t]; tw[4 * l + t] = w[t]; }
+            }
+            float* pe = lds + kLdsPe + ((wave * kRows + s) * 2 + sv) * 4;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pe[k] = tanhf((sv == 0 ? smp.pt_in[0][k] : smp.pt_in[1][k]) / 5.0f);
+            pe[3] = 0.0f;
+        }
+        if (live && q4 == 0) {
+            a.pixel_val[2 * i] = smp.grid[0]; a.pixel_val[2 * i + 1] = smp.grid[1];
+            a.pt[3 * i + 0] = smp.pt[0]; a.pt[3 * i + 1] = smp.pt[1]; a.pt[3 * i + 2] = smp.pt[2];
+        }
+        float gx8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gx8[k] = q4 == 0 ? smp.g[k] : q4 == 1 ? smp.g[8 + k] : (q4 == 2 && k == 0) ? 1.0f : 0.0f;
+        split8(gx8, ghi, glo);
+    }
+    __syncthreads();                                                   // tables and tap records visible
+
+    // ---- gather machinery: lane owns rows rr = (lane>>3) + 8*it (it = 0, 1) and channel quad qd = lane & 7 of a chunk ----
+    const int qd = lane & 7, r0 = lane >> 3;
+    float* stage = lds + kLdsStage + wave * kRows * kStageLd;
+    float4 hacc[2];
+    float4 tapA[8], tapB[8];
+
+    auto issue_row = [&](float4 (&tap)[8], int sv, int c, int l, int it) {
+        if constexpr (ABL == 1 || ABL == 2 || ABL == 3) return;
+        const float* base = a.gmap[l] + 32 * c + 4 * qd;
+        const int* ti = reinterpret_cast<const int*>(lds + kLdsTapI) + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 12 + 4 * l;
+        const int4 id = *reinterpret_cast<const int4*>(ti);
+        tap[4 * it + 0] = *reinterpret_cast<const float4*>(base + (long)id.x * kC);
+        tap[4 * it + 1] = *reinterpret_cast<const float4*>(base + (long)id.y * kC);
+        tap[4 * it + 2] = *reinterpret_cast<const float4*>(base + (long)id.z * kC);
+        tap[4 * it + 3] = *reinterpret_cast<const float4*>(base + (long)id.w * kC);
+    };
+    auto blend_row = [&](const float4 (&tap)[8], int sv, int l, int it) {
+        if constexpr (ABL == 2 || ABL == 3) return;
+        const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 12 + 4 * l);
+        const float ww[4] = {w.x, w.y, w.z, w.w};
+        float4 acc4 = hacc[it];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 gq = tap[4 * it + t];
+            acc4.x = fmaf(ww[t], gq.x, acc4.x); acc4.y = fmaf(ww[t], gq.y, acc4.y);
+            acc4.z = fmaf(ww[t], gq.z, acc4.z); acc4.w = fmaf(ww[t], gq.w, acc4.w);
+        }
+        hacc[it] = acc4;
+    };
+    auto affine_row = [&](int sv, int c, int it) {
+        if constexpr (ABL == 2 || ABL == 3) return;
+        const int rr = r0 + 8 * it;
+        const float4 pe = *reinterpret_cast<const float4*>(lds + kLdsPe + ((wave * kRows + rr) * 2 + sv) * 4);
+        const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 4 * (32 * c + 4 * qd));
+        const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+        hacc[it] = make_float4(fmaf(w0.z, pe.z, fmaf(w0.y, pe.y, w0.x * pe.x)) + w0.w,
+                               fmaf(w1.z, pe.z, fmaf(w1.y, pe.y, w1.x * pe.x)) + w1.w,
+                               fmaf(w2.z, pe.z, fmaf(w2.y, pe.y, w2.x * pe.x)) + w2.w,
+                               fmaf(w3.z, pe.z, fmaf(w3.y, pe.y, w3.x * pe.x)) + w3.w);
+    };
+    auto finish_row = [&](int it) {
+        if constexpr (ABL == 2 || ABL == 3) return;
+        const float4 o = hacc[it];
+        *reinterpret_cast<float4*>(stage + (r0 + 8 * it) * kStageLd + 4 * qd) =
+            make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    };
+    auto read_b = [&](half8& bhi, half8& blo) {                        // this lane's 8 channels of the wave's h tile, split
+        const float4 x0 = *reinterpret_cast<const float4*>(stage + s * kStageLd + 8 * q4);
+        const float4 x1 = *reinterpret_cast<const float4*>(stage + s * kStageLd + 8 * q4 + 4);
+        const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        split8(x, bhi, blo);
+    };
+
+    // first chunk of source 0: nothing to hide it under
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        affine_row(0, 0, it);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) { issue_row(tapA, 0, 0, l, it); blend_row(tapA, 0, l, it); }
+        finish_row(it);
+    }
+    stream_sync();                                                     // weight chunk 0 landed
+
+    const float up = (float)(1 << kWShift), down = 1.0f / (float)(1 << kWShift);
+    f32x4 k1[kTD];
+    init_bias<kTD>(k1, lds + kLdsBias + kBiasK1, q4, up);
+    f32x4 acc[kTE];
+    half8 bhi, blo;
+    read_b(bhi, blo);
+#pragma unroll 1
+    for (int sv = 0; sv < 2; ++sv) {
+        init_bias<kTE>(acc, lds + kLdsBias + kBiasE, q4, up);
+#pragma unroll 1
+        for (int c = 0; c < kKS; ++c) {
+            const int nsv = (c + 1 < kKS) ? sv : 1;                    // branch-free: after the very last chunk re-gather (1, 0)
+            const int nc = (c + 1 < kKS) ? c + 1 : 0;
+            const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
+            const NextChunk nx = next_chunk(a.blob, lds, g + 1);
+            // 9 slots of (4 ds_read_b128 + 6 MFMAs of 16 cycles); between them one piece of the next chunk's gather / DMA issue:
+            //   0 issue L2 -> tapA   1 issue L1 -> tapB   1-5 DMA pieces   2 affine start   4 blend L2   5 issue L0 -> tapA
+            //   6 blend L1           8 blend L0, ReLU, LDS write
+            auto piece = [&](int qs) {
+                if (qs >= 1 && qs < 1 + kPieces) stream_issue_piece<ABL>(nx, qs - 1, lane, wave);
+                if (qs == 0) { issue_row(tapA, nsv, nc, 2, 0); issue_row(tapA, nsv, nc, 2, 1); }
+                else if (qs == 1) { issue_row(tapB, nsv, nc, 1, 0); issue_row(tapB, nsv, nc, 1, 1); }
+                else if (qs == 2) { affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); }
+                else if (qs == 4) { blend_row(tapA, nsv, 2, 0); blend_row(tapA, nsv, 2, 1); }
+                else if (qs == 5) { issue_row(tapA, nsv, nc, 0, 0); issue_row(tapA, nsv, nc, 0, 1); }
+                else if (qs == 6) { blend_row(tapB, nsv, 1, 0); blend_row(tapB, nsv, 1, 1); }
+                else if (qs == 8) { blend_row(tapA, nsv, 0, 0); blend_row(tapA, nsv, 0, 1); finish_row(0); finish_row(1); }
+            };
+#pragma unroll
+            for (int qs = 0; qs < kTE / 2; ++qs) {
+                const float* w0 = wl + (2 * qs * 2) * 256;
+                if constexpr (ABL != 4) mfma_pair(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
+                piece(qs);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            read_b(bhi, blo);                                          // next chunk's B operand (own LDS tile, in-order LDS)
+            stream_sync<ABL>();
+            ++g;
+        }
+        scale_acc<kTE>(acc, down);
+        chained_layer<kTE, false, ABL>(k1, acc, a.blob, lds, g, lane, wave);
+        if (live) store_rows<kTE>(acc, a.e + i * (2 * kE) + sv * kE, q4);
+    }
+    scale_acc<kTD>(k1, down);
+    f32x4 key[kTD];
+    init_bias<kTD>(key, lds + kLdsBias + kBiasK2, q4, up);
+    chained_layer<kTD, true, ABL>(key, k1, a.blob, lds, g, lane, wave);
+    scale_acc<kTD>(key, down);
+
+    // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ;  ug = Wr1[:,128:] g + br1 ---------------------
+    f32x4 t1[kTD], qv[kTD];
+#pragma unroll
+    for (int t = 0; t < kTD; ++t) t1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stream_issue_all<ABL>(a.blob, lds, g + 1, lane, wave);
+    small_layer(t1, ghi, glo, lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane);          // q1
+    stream_sync<ABL>();
+    ++g;
+    scale_acc<kTD>(t1, down);
+    init_bias<kTD>(qv, lds + kLdsBias + kBiasQ2, q4, up);
+    chained_layer<kTD, true, ABL>(qv, t1, a.blob, lds, g, lane, wave);
+    scale_acc<kTD>(qv, down);
+    float dot = 0.0f;
+#pragma unroll
+    for (int t = 0; t < kTD; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dot = fmaf(key[t][r], qv[t][r], dot);
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    if (live) {
+        store_rows<kTD>(qv, a.qry + i * kD, q4);
+        if (q4 == 0) a.logit[i] = dot / 16.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < kTD; ++t) t1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    small_layer(t1, ghi, glo, lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane);          // ug
+    scale_acc<kTD>(t1, down);
+    if (live) store_rows<kTD>(t1, a.ug + i * kD, q4);
+}
+
+}  // namespace
+
+extern "C" size_t car_fused2_blob_floats(void) { return (size_t)kBlobTiles * kTile; }
+
+extern "C" int car_fused_samples_v2(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                                    const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
+                                    const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                                    float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, void* stream) {
+    CAR_REQUIRE(poses && rays && steps && gmaps && level_h && level_w && wpt && blob && bias, "car_fused_samples_v2: null input");
+    CAR_REQUIRE(e && qry && ug && logit && pt && pixel_val, "car_fused_samples_v2: null output");
+    CAR_REQUIRE(n_levels == 3 && C == kC && V == 2, "car_fused_samples_v2: built for 3 pyramid levels, C = %d, V = 2 (got %d, %d, %d)", kC, n_levels, C, V);
+    CAR_REQUIRE(b > 0 && R > 0 && P > 0 && H > 1 && W > 1, "car_fused_samples_v2: bad sizes");
+    Fused2Args a;
+    a.poses = (const CarPose*)poses; a.rays = (const CarRay*)rays; a.steps = steps;
+    for (int l = 0; l < 3; ++l) {
+        a.gmap[l] = gmaps[l]; a.gh[l] = level_h[l]; a.gw[l] = level_w[l];
+        CAR_REQUIRE(a.gmap[l] && a.gh[l] > 0 && a.gw[l] > 0 && (long)b * V * a.gh[l] * a.gw[l] < 2147483647L, "car_fused_samples_v2: bad level %d", l);
+    }
+    a.wpt = wpt; a.blob = blob; a.bias = bias;
+    a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
+    a.S = (long)b * V * R * P;
+    const char* xb = getenv("CAR_FUSED_XCD_BANDS");
+    a.xcd_bands = xb ? atoi(xb) : 1;
+    const char* rm = getenv("CAR_FUSED_RAY_MAJOR");
+    a.ray_major = rm ? atoi(rm) : 1;
+    const long groups = a.ray_major ? (long)b * V * car_div_up(R, kRows) * car_div_up(P, kWaves) : car_div_up(a.S, kGroup);
+    a.e = e; a.qry = qry; a.ug = ug; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
+    const char* abl_env = getenv("CAR_FUSED_ABLATE");
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    void (*kern)(const Fused2Args) = abl == 1 ? fused2_kernel<1> : abl == 2 ? fused2_kernel<2> : abl == 3 ? fused2_kernel<3> : abl == 4 ? fused2_kernel<4> : fused2_kernel<0>;
+    hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e1 != hipSuccess) { car_set_error("car_fused_samples_v2: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(512), kLdsBytes, (hipStream_t)stream, a);
+    CAR_CHECK_LAUNCH("car_fused_samples_v2");
+    return CAR_OK;
+}

@@ -131,6 +131,64 @@ def pack_fused_weights(m, device, split_fp16: bool = False):
     return blob, bias
 
 
+def _std16_k(ksteps: int) -> Tensor:
+    """16x16x32 tiles, standard mapping: K step m, lane l, element e -> k = 32 m + 8 (l >> 4) + e"""
+    m = torch.arange(ksteps)[:, None, None]
+    lane = torch.arange(64)[None, :, None]
+    e = torch.arange(8)[None, None, :]
+    return 32 * m + 8 * (lane // 16) + e
+
+
+def _chained16_k(ksteps: int, base: int = 0) -> Tensor:
+    """16x16x32 tiles chained over the accumulators of 16-row source tiles (channel 16 T + 4 (l >> 4) + r): K step m takes
+    source tiles 2m and 2m+1, so  k = base + 16 (2 m + e // 4) + 4 (l >> 4) + e % 4"""
+    m = torch.arange(ksteps)[:, None, None]
+    lane = torch.arange(64)[None, :, None]
+    e = torch.arange(8)[None, None, :]
+    return base + 16 * (2 * m + e // 4) + 4 * (lane // 16) + e % 4
+
+
+def _pack_tiles16_f16_split(W: Tensor, bias: Optional[Tensor], n_tiles: int, kmap: Tensor) -> Tensor:
+    """Split-fp16 A-operand tiles of v_mfma_f32_16x16x32_f16: per (K step, tile) [hi | lo][lane (64)][8 halves] = 512 float32
+    words; lane l carries output channel 16 tile + l % 16 and the eight k of ``kmap[step, l]`` (k == K: the bias, k > K: zero).
+    Weights carry 2^W_SHIFT like _pack_tiles_f16_split."""
+    N, K = W.shape
+    Wext = torch.zeros(16 * n_tiles, K + 2, dtype=torch.float32)
+    Wext[:N, :K] = W * float(1 << W_SHIFT)
+    if bias is not None:
+        Wext[:N, K] = bias * float(1 << W_SHIFT)
+    ks = kmap.shape[0]
+    k = kmap.clamp(max=K + 1)                                                # (ks, 64, 8)
+    lane = torch.arange(64)
+    n = 16 * torch.arange(n_tiles)[:, None] + (lane % 16)[None, :]           # (tiles, 64)
+    w = Wext[n[None, :, :, None].expand(ks, -1, -1, 8), k[:, None, :, :].expand(-1, n_tiles, -1, -1)]      # (ks, tiles, 64, 8)
+    hi = w.half()
+    lo = (w - hi.float()).half()
+    both = torch.stack([hi, lo], dim=2).contiguous()                         # (ks, tiles, hl, 64, 8)
+    return both.view(torch.float32).reshape(ks, n_tiles, 512)
+
+
+def pack_fused2_weights(m, device):
+    """Weights of csrc/car_fused2.hip (16x16x32 f16 tiles, every layer split-fp16) in its operand order: (blob, bias table)."""
+    f = lambda t: t.detach().float().cpu().reshape(t.shape[0], -1)
+    v = lambda t: t.detach().float().cpu()
+    C = m.query_encode_latent.weight.shape[0]
+    E2 = C // 2
+    wr = f(m.query_repeat_embed.weight)
+    pk = _pack_tiles16_f16_split
+    parts = [
+        pk(f(m.query_encode_latent_2.weight), None, E2 // 16, _std16_k(C // 32)),                             # W2
+        pk(f(m.query_embed.weight), v(m.query_embed.bias), 8, _std16_k(1)),                                   # Q1 (bias folded)
+        pk(f(m.query_embed_2.weight), None, 8, _chained16_k(4)),                                              # Q2
+        pk(wr[:, 128:].contiguous(), v(m.query_repeat_embed.bias), 8, _std16_k(1)),                           # UG (bias folded)
+        torch.cat([pk(f(m.key_map.weight), None, 8, _chained16_k(E2 // 32, base=E2 * sv)) for sv in range(2)]),   # K1
+        pk(f(m.key_map_2.weight), None, 8, _chained16_k(4)),                                                  # K2
+    ]
+    blob = torch.cat([p_.reshape(-1) for p_ in parts]).to(device)
+    bias = torch.cat([v(m.query_encode_latent_2.bias), v(m.query_embed_2.bias), v(m.key_map.bias), v(m.key_map_2.bias)]).to(device)
+    return blob, bias
+
+
 def pack_round2_weights(m, device):
     """query_repeat_embed_2 (128 -> 128) in the operand order of csrc/car_round2.hip: (packed [4,4,1024], bias [128])."""
     W = m.query_repeat_embed_2.weight.detach().float().cpu().reshape(128, 128)
@@ -162,6 +220,9 @@ class RenderEngine:
         # 576->288 layer of the fused kernel on the f16 matrix pipe with fp16 hi/lo operand splits (3 products per term,
         # fp32-class accuracy) instead of the fp32 pipe
         self.split_fp16 = True
+        # 2: csrc/car_fused2.hip (8 waves x 16 samples, 16x16x32 f16 tiles, two waves per SIMD; always split-fp16);
+        # 1: csrc/car_fused.hip (4 waves x 32 samples, one wave per SIMD; fp32 or split-fp16 per ``split_fp16``)
+        self.fused_version = 2
         self.fuse_round2 = True        # round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
         self._round2_key = None
         self._round2 = None
@@ -462,10 +523,12 @@ class RenderEngine:
         key = tuple((p_.data_ptr(), p_._version) for p_ in (
             m.query_encode_latent_2.weight, m.query_encode_latent_2.bias, m.query_embed.weight, m.query_embed.bias,
             m.query_embed_2.weight, m.query_embed_2.bias, m.query_repeat_embed.weight, m.query_repeat_embed.bias,
-            m.key_map.weight, m.key_map.bias, m.key_map_2.weight, m.key_map_2.bias)) + (str(dev), self.split_fp16)
+            m.key_map.weight, m.key_map.bias, m.key_map_2.weight, m.key_map_2.bias)) + (str(dev), self.split_fp16, self.fused_version)
+        v2 = self.fused_version == 2
         if key != self._fused_key:
-            self._fused = pack_fused_weights(m, dev, self.split_fp16)
-            assert self._fused[0].numel() == lib.car_fused_blob_floats() and self._fused[1].numel() == lib.car_fused_bias_floats()
+            self._fused = pack_fused2_weights(m, dev) if v2 else pack_fused_weights(m, dev, self.split_fp16)
+            assert self._fused[0].numel() == (lib.car_fused2_blob_floats() if v2 else lib.car_fused_blob_floats())
+            assert self._fused[1].numel() == lib.car_fused_bias_floats()
             self._fused_key = key
         blob, bias = self._fused
         e = torch.empty(S, 576, **f32)
@@ -482,17 +545,23 @@ class RenderEngine:
         if self.timing is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        _lib.check(lib.car_fused_samples(_ptr(poses), _ptr(rays), _ptr(steps), ptrs, hs, ws, L, 576, _ptr(wpt), _ptr(blob),
-                                         _ptr(bias), b, V, R, P, H, W, _ptr(e), _ptr(q), _ptr(ug), _ptr(logit), _ptr(pt),
-                                         _ptr(pixel_val), int(self.split_fp16), _stream()), "car_fused_samples")
+        if v2:
+            _lib.check(lib.car_fused_samples_v2(_ptr(poses), _ptr(rays), _ptr(steps), ptrs, hs, ws, L, 576, _ptr(wpt), _ptr(blob),
+                                                _ptr(bias), b, V, R, P, H, W, _ptr(e), _ptr(q), _ptr(ug), _ptr(logit), _ptr(pt),
+                                                _ptr(pixel_val), _stream()), "car_fused_samples_v2")
+        else:
+            _lib.check(lib.car_fused_samples(_ptr(poses), _ptr(rays), _ptr(steps), ptrs, hs, ws, L, 576, _ptr(wpt), _ptr(blob),
+                                             _ptr(bias), b, V, R, P, H, W, _ptr(e), _ptr(q), _ptr(ug), _ptr(logit), _ptr(pt),
+                                             _ptr(pixel_val), int(self.split_fp16), _stream()), "car_fused_samples")
         if ev is not None:
             ev[1].record()
             # algorithmic MACs per sample on the matrix pipe: 2 x 576x288 (e), 576x128 + 128x128 (key), 16x128 + 128x128 (qry),
             # 16x128 (ug); the gather FMAs and the geometry are not counted
             macs = 2 * 576 * 288 + 576 * 128 + 128 * 128 + 16 * 128 + 128 * 128 + 16 * 128
-            pipe = "f16 matrix pipe, fp16 hi/lo split x3" if self.split_fp16 else "fp32 matrix pipe"
+            pipe = "f16 matrix pipe, fp16 hi/lo split x3" if (self.split_fp16 or v2) else "fp32 matrix pipe"
+            kname = "fused2_kernel" if v2 else "fused_sample_kernel"
             self.timing.setdefault("fused_samples", []).append(
-                (ev[0], ev[1], 2.0 * S * macs, f"fused_sample_kernel on {S} samples (e, key, qry, ug, logits; {pipe})"))
+                (ev[0], ev[1], 2.0 * S * macs, f"{kname} on {S} samples (e, key, qry, ug, logits; {pipe})"))
         return self._finish(inp, z, b, V, R, P, 576, m.latent_dim, e, None, q, logit, ug, pt, pixel_val, poses, rays, coords9,
                             phi_x, ld_phi, debug, ug_ready=True)
 

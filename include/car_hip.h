@@ -131,6 +131,15 @@ int car_fused_samples(const float* poses, const float* rays, const float* steps,
                       const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
                       float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, int prec, void* stream);
 
+/* Same stage, same inputs/outputs, second-generation CDNA4 mapping (csrc/car_fused2.hip): 8 waves x 16 samples per workgroup,
+ * v_mfma_f32_16x16x32_f16 with fp16 hi/lo operand splits for every layer, two waves per SIMD.  `blob` is packed by
+ * engine.pack_fused2_weights (car_fused2_blob_floats() floats); `bias` is the table of car_fused_bias_floats(). */
+size_t car_fused2_blob_floats(void);
+int car_fused_samples_v2(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                         const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
+                         const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                         float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, void* stream);
+
 /* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
  *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).
  * Weights are re-laid out once into the MFMA operand order by car_linear_pack (bias folded in as column K). */

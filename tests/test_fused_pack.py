@@ -79,3 +79,55 @@ def test_split_fp16_packing_reconstructs_the_weights():
             k_idx = 32 * c + 16 * (torch.arange(64) // 32)[:, None] + 8 * kg + torch.arange(8)[None, :]      # (lane, e)
             want = W[n_idx[:, :, None].expand(9, 64, 8), k_idx[None].expand(9, 64, 8)]
             assert (rec[c, :, kg] - want).abs().max() <= 4e-7 * W.abs().max()
+
+
+def _walk16(tiles, x_of):
+    """tiles (ksteps, n_tiles, 2, 64, 8) fp16 halves as floats; x_of(step, lane group q, e) -> B value of that K slot.  Evaluates the
+    layer the way v_mfma_f32_16x16x32_f16 contracts it: lane l = 16 q + i holds A[i][8 q + e] and B[8 q + e][.]."""
+    ks, nt = tiles.shape[:2]
+    y = torch.zeros(16 * nt, dtype=torch.float64)
+    w = (tiles[:, :, 0].double() + tiles[:, :, 1].double())                   # hi + lo: (ks, nt, 64, 8)
+    for m in range(ks):
+        for q in range(4):
+            for e in range(8):
+                y += w[m, :, 16 * q:16 * q + 16, e].reshape(-1) * x_of(m, q, e)
+    return y
+
+
+def test_fused2_blob_layout():
+    """Operand packing of csrc/car_fused2.hip: standard, bias-folded and chained K mappings of the 16x16x32 tiles."""
+    from cross_attention_renderer_amd import _lib
+    from cross_attention_renderer_amd.engine import W_SHIFT, pack_fused2_weights
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=8).eval()
+    S.perturb_parameters(m, seed=1)
+    blob, bias = pack_fused2_weights(m, "cpu")
+    lib = _lib.load()
+    assert blob.numel() == lib.car_fused2_blob_floats() and bias.numel() == lib.car_fused_bias_floats()
+    T = 512
+    sc = float(1 << W_SHIFT)
+    g = torch.Generator().manual_seed(0)
+    halves = lambda a, b_, ks, nt: blob[a * T:b_ * T].view(torch.float16).reshape(ks, nt, 2, 64, 8).float()
+    chained = lambda x, base=0: (lambda m_, q, e: x[base + 16 * (2 * m_ + e // 4) + 4 * q + e % 4])
+    # W2: 18 K steps x 18 tiles, standard
+    x = torch.randn(576, generator=g).double()
+    y = _walk16(halves(0, 324, 18, 18), lambda m_, q, e: x[32 * m_ + 8 * q + e]) / sc
+    want = m.query_encode_latent_2.weight.detach().reshape(288, 576).double() @ x
+    assert (y - want).abs().max() < 1e-5
+    # Q1 / UG: one K step, lane group 2 element 0 carries the constant 1 of the folded bias
+    gq = torch.randn(16, generator=g).double()
+    gin = lambda m_, q, e: gq[8 * q + e] if q < 2 else (1.0 if (q == 2 and e == 0) else 0.0)
+    y = _walk16(halves(324, 332, 1, 8), gin) / sc
+    want = m.query_embed.weight.detach().reshape(128, 16).double() @ gq + m.query_embed.bias.detach().double()
+    assert (y - want).abs().max() < 1e-5
+    wr = m.query_repeat_embed.weight.detach().reshape(128, 144).double()
+    y = _walk16(halves(364, 372, 1, 8), gin) / sc
+    assert (y - (wr[:, 128:] @ gq + m.query_repeat_embed.bias.detach().double())).abs().max() < 1e-5
+    # Q2 / K2: chained over a 128-wide accumulator set (8 source tiles, 4 K steps)
+    for off, layer in ((332, m.query_embed_2), (516, m.key_map_2)):
+        x = torch.randn(128, generator=g).double()
+        y = _walk16(halves(off, off + 32, 4, 8), chained(x)) / sc
+        assert (y - layer.weight.detach().reshape(128, 128).double() @ x).abs().max() < 1e-5
+    # K1: chained over [e_0 ; e_1], 9 K steps per source
+    x = torch.randn(576, generator=g).double()
+    y = sum(_walk16(halves(372 + 72 * sv, 372 + 72 * (sv + 1), 9, 8), chained(x, 288 * sv)) for sv in range(2)) / sc
+    assert (y - m.key_map.weight.detach().reshape(128, 576).double() @ x).abs().max() < 1e-5

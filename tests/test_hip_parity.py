@@ -180,11 +180,12 @@ def test_literal_gather_gemm_pipeline_matches_oracle(name):
     assert err_stats(out["stages"]["interp_val"], out2["stages"]["interp_val"])["max"] < 5e-5
 
 
+@pytest.mark.parametrize("version", [2, 1])
 @pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c3", "t2_c5"])
-def test_fused_sample_kernel_matches_stage_pipeline(name):
-    """A/B of csrc/car_fused.hip (geometry + encode + e + key/query MLPs + logits in one kernel, everything chained through
-    the MFMA accumulators) against the stage-by-stage kernels; both against the oracle at 1e-4."""
-    c, fx, ora, fused = run_case(name, fuse_samples=True)
+def test_fused_sample_kernel_matches_stage_pipeline(name, version):
+    """A/B of csrc/car_fused2.hip / car_fused.hip (geometry + encode + e + key/query MLPs + logits in one kernel, everything
+    chained through the MFMA accumulators) against the stage-by-stage kernels; both against the oracle at 1e-4."""
+    c, fx, ora, fused = run_case(name, fuse_samples=True, fused_version=version)
     assert fused["stages"]["local_coords"] is None, "the fused kernel was not selected"
     _, _, _, staged = run_case(name, fuse_samples=False)
     assert rel_err(fused["stages"]["pt"], staged["stages"]["pt"]) < 1e-6
@@ -199,13 +200,27 @@ def test_fused_sample_kernel_matches_stage_pipeline(name):
 def test_split_fp16_layer_is_fp32_class(name):
     """The 576->288 layer on the f16 matrix pipe with fp16 hi/lo operand splits (three exact products per term) against the
     same kernel on the fp32 pipe: the per-sample features must agree to ~1e-6, i.e. far inside the 1e-4 contract."""
-    c, fx, ora, a = run_case(name, split_fp16=True)
-    _, _, _, b_ = run_case(name, split_fp16=False)
+    c, fx, ora, a = run_case(name, split_fp16=True, fused_version=1)
+    _, _, _, b_ = run_case(name, split_fp16=False, fused_version=1)
     e = err_stats(a["stages"]["interp_val"], b_["stages"]["interp_val"])
     assert e["max"] < 5e-6, e
     assert rel_err(a["rgb"], b_["rgb"]) < 1e-5
     _check_outputs(a, lambda k: ora[k], "split-fp16 vs oracle")
     _check_outputs(b_, lambda k: ora[k], "fp32 pipe vs oracle")
+
+
+@pytest.mark.parametrize("name", ["t1_c1", "t2_c2", "t2_c4"])
+def test_fused_v2_matches_fp32_pipe_v1(name):
+    """The two-waves-per-SIMD kernel (16x16x32 f16 tiles, every layer split-fp16) against the first-generation kernel on the
+    fp32 matrix pipe: per-sample features to ~1e-6, attention weights and colours to 1e-5."""
+    c, fx, ora, a = run_case(name, fused_version=2)
+    _, _, _, b_ = run_case(name, fused_version=1, split_fp16=False)
+    assert rel_err(a["stages"]["pt"], b_["stages"]["pt"]) == 0
+    e = err_stats(a["stages"]["interp_val"], b_["stages"]["interp_val"])
+    assert e["max"] < 5e-6, e
+    assert rel_err(a["at_wt"], b_["at_wt"]) < 1e-5
+    assert rel_err(a["rgb"], b_["rgb"]) < 1e-5
+    _check_outputs(a, lambda k: ora[k], "fused v2 vs oracle")
 
 
 @pytest.mark.parametrize("name", ["t0_default", "t0_p5", "t0_nview1", "t0_nview3", "t1_c1", "t2_c3"])
