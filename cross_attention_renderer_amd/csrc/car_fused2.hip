@@ -52,12 +52,13 @@ constexpr int kBiasE = 0, kBiasQ2 = kE, kBiasK1 = kE + kD, kBiasK2 = kE + 2 * kD
 // ---- dynamic LDS carve-up (floats) --------------------------------------------------------------------------------
 constexpr int kLdsW = 0;                                        // [2][18][512]           weight chunks          72 KB
 constexpr int kLdsStage = kLdsW + 2 * kChunkTiles * kTile;      // [8][16][36]            h tiles, wave private   18 KB
-constexpr int kLdsTapI = kLdsStage + kGroup * kStageLd;         // [128][2][3][4] int     tap texel indices       12 KB
+constexpr int kLdsTapI = kLdsStage + kGroup * kStageLd;         // [128][2][3][4] uint    tap byte offsets into a level's map   12 KB
 constexpr int kLdsTapW = kLdsTapI + kGroup * 24;                // [128][2][3][4]         tap weights             12 KB
 constexpr int kLdsPe = kLdsTapW + kGroup * 24;                  // [128][2][4]            tanh(pt_s/5)             4 KB
 constexpr int kLdsWpt = kLdsPe + kGroup * 8;                    // [576][4]               (W1[:,C:C+3], b1)        9 KB
 constexpr int kLdsBias = kLdsWpt + kC * 4;                      // [672]
-constexpr int kLdsFloats = kLdsBias + kBiasFloats;
+constexpr int kLdsG = kLdsBias + kBiasFloats;                   // [128][16]              geometric query g per sample 8 KB
+constexpr int kLdsFloats = kLdsG + kGroup * 16;
 constexpr size_t kLdsBytes = (size_t)kLdsFloats * sizeof(float);
 
 struct Fused2Args {
@@ -132,19 +133,28 @@ __device__ __forceinline__ void stream_issue_all(const float* __restrict__ blob,
 #pragma unroll
     for (int p = 0; p < kPieces; ++p) stream_issue_piece<ABL>(n, p, lane, wave);
 }
-template <int ABL = 0>
+// end of a chunk: the DMA of the next chunk has landed and every wave is done reading the current one.  KEEP = number of
+// vector loads this wave issued AFTER its last DMA piece and wants to leave in flight across the barrier (loads return in
+// order, so "at most KEEP outstanding" still means every DMA piece has landed).
+template <int ABL = 0, int KEEP = 0>
 __device__ __forceinline__ void stream_sync() {
     if constexpr (ABL == 3) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (KEEP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
 
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// x = hi + lo in fp16 halves.  The halves are rounded toward zero (v_cvt_pkrtz_f16_f32 converts two values per instruction):
+// x - hi is exact in fp32 and |x - hi - lo| < 2^-20 |x|, still fp32-class after the three-product MFMA.
 __device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const _Float16 hh = (_Float16)x[e];
-        hi[e] = hh;
-        lo[e] = (_Float16)(x[e] - (float)hh);
+    for (int e = 0; e < 8; e += 2) {
+        const fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(x[e], x[e + 1]);
+        const fp16x2 l2 = __builtin_amdgcn_cvt_pkrtz(x[e] - (float)h2[0], x[e + 1] - (float)h2[1]);
+        hi[e] = (_Float16)h2[0]; hi[e + 1] = (_Float16)h2[1];
+        lo[e] = (_Float16)l2[0]; lo[e + 1] = (_Float16)l2[1];
     }
 }
 
@@ -233,7 +243,11 @@ __device__ __forceinline__ void small_layer(f32x4 (&acc)[kTD], const half8& ghi,
 
 // ABL > 0: timing-only ablations (wrong results): 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers,
 // 4 no MFMAs in the e path (gather, DMA and barriers only)
-template <int ABL>
+// SCHED 1: the tap loads run as a continuous two-buffer pipeline across chunk boundaries (16 loads per wave always in
+// flight, also over the barrier); SCHED 0: every chunk's gather is issued and consumed inside the previous chunk.
+// (Hand-counted s_waitcnt for the taps, so that a tap wait does not also wait for the LDS-DMA pieces the compiler cannot
+// see, was measured too: 4.9 vs 4.9 ms, no gain — the waves are not held up there.)
+template <int ABL, int SCHED = 1>
 __global__ void __launch_bounds__(512) fused2_kernel(const Fused2Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -272,7 +286,6 @@ __global__ void __launch_bounds__(512) fused2_kernel(const Fused2Args a) {
     const long nr = i / P;
     const int n = (int)(nr / a.R);
     const int v = n % V, sc = n / V;
-    half8 ghi, glo;                                                    // B operand of the two layers fed by g (k = 16: folded bias)
     {
         const CarPose& Ps = a.poses[n];
         const CarRay ray = a.rays[nr];
@@ -293,7 +306,7 @@ __global__ void __launch_bounds__(512) fused2_kernel(const Fused2Args a) {
                 float w[4];
                 car_bilinear_taps(gx, gy, a.gw[l], a.gh[l], mode, idx, w);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { ti[4 * l + t] = m * a.gh[l] * a.gw[l] + idx[t]; tw[4 * l + t] = w[t]; }
+                for (int t = 0; t < 4; ++t) { ti[4 * l + t] = (int)((unsigned)(m * a.gh[l] * a.gw[l] + idx[t]) * (unsigned)(kC * 4)); tw[4 * l + t] = w[t]; }
             }
             float* pe = lds + kLdsPe + ((wave * kRows + s) * 2 + sv) * 4;
 #pragma unroll
@@ -304,10 +317,12 @@ __global__ void __launch_bounds__(512) fused2_kernel(const Fused2Args a) {
             a.pixel_val[2 * i] = smp.grid[0]; a.pixel_val[2 * i + 1] = smp.grid[1];
             a.pt[3 * i + 0] = smp.pt[0]; a.pt[3 * i + 1] = smp.pt[1]; a.pt[3 * i + 2] = smp.pt[2];
         }
-        float gx8[8];
+        // g is needed again only after the e path: parked in LDS instead of eight registers
+        if (q4 < 2) {
+            float* gl = lds + kLdsG + (wave * kRows + s) * 16 + 8 * q4;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) gx8[k] = q4 == 0 ? smp.g[k] : q4 == 1 ? smp.g[8 + k] : (q4 == 2 && k == 0) ? 1.0f : 0.0f;
-        split8(gx8, ghi, glo);
+            for (int k = 0; k < 8; ++k) gl[k] = q4 == 0 ? smp.g[k] : smp.g[8 + k];
+        }
     }
     __syncthreads();                                                   // tables and tap records visible
 
@@ -315,30 +330,33 @@ __global__ void __launch_bounds__(512) fused2_kernel(const Fused2Args a) {
     const int qd = lane & 7, r0 = lane >> 3;
     float* stage = lds + kLdsStage + wave * kRows * kStageLd;
     float4 hacc[2];
-    float4 tapA[8], tapB[8];
+    f32x4 tapA[8], tapB[8];
 
-    auto issue_row = [&](float4 (&tap)[8], int sv, int c, int l, int it) {
+    const unsigned qd16 = 16u * qd;
+    auto issue_row = [&](f32x4 (&tap)[8], int sv, int c, int l, int it) {
         if constexpr (ABL == 1 || ABL == 2 || ABL == 3) return;
-        const float* base = a.gmap[l] + 32 * c + 4 * qd;
-        const int* ti = reinterpret_cast<const int*>(lds + kLdsTapI) + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 12 + 4 * l;
-        const int4 id = *reinterpret_cast<const int4*>(ti);
-        tap[4 * it + 0] = *reinterpret_cast<const float4*>(base + (long)id.x * kC);
-        tap[4 * it + 1] = *reinterpret_cast<const float4*>(base + (long)id.y * kC);
-        tap[4 * it + 2] = *reinterpret_cast<const float4*>(base + (long)id.z * kC);
-        tap[4 * it + 3] = *reinterpret_cast<const float4*>(base + (long)id.w * kC);
+        // wave-uniform base + 32-bit per-lane byte offset: one v_add per load instead of a 64-bit multiply-add
+        const char* base = reinterpret_cast<const char*>(a.gmap[l] + 32 * c);
+        const unsigned* ti = reinterpret_cast<const unsigned*>(lds + kLdsTapI) + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 12 + 4 * l;
+        const uint4 id = *reinterpret_cast<const uint4*>(ti);
+        tap[4 * it + 0] = *reinterpret_cast<const f32x4*>(base + (id.x + qd16));
+        tap[4 * it + 1] = *reinterpret_cast<const f32x4*>(base + (id.y + qd16));
+        tap[4 * it + 2] = *reinterpret_cast<const f32x4*>(base + (id.z + qd16));
+        tap[4 * it + 3] = *reinterpret_cast<const f32x4*>(base + (id.w + qd16));
     };
-    auto blend_row = [&](const float4 (&tap)[8], int sv, int l, int it) {
+    auto blend_row = [&](const f32x4 (&tap)[8], int sv, int l, int it) {
         if constexpr (ABL == 2 || ABL == 3) return;
         const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 12 + 4 * l);
         const float ww[4] = {w.x, w.y, w.z, w.w};
-        float4 acc4 = hacc[it];
+        f32x2 lo2 = {hacc[it].x, hacc[it].y}, hi2 = {hacc[it].z, hacc[it].w};          // v_pk_fma_f32: two FMAs per instruction
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float4 gq = tap[4 * it + t];
-            acc4.x = fmaf(ww[t], gq.x, acc4.x); acc4.y = fmaf(ww[t], gq.y, acc4.y);
-            acc4.z = fmaf(ww[t], gq.z, acc4.z); acc4.w = fmaf(ww[t], gq.w, acc4.w);
+            const f32x4 gq = tap[4 * it + t];
+            const f32x2 w2 = {ww[t], ww[t]};
+            lo2 = __builtin_elementwise_fma(w2, f32x2{gq[0], gq[1]}, lo2);
+            hi2 = __builtin_elementwise_fma(w2, f32x2{gq[2], gq[3]}, hi2);
         }
-        hacc[it] = acc4;
+        hacc[it] = make_float4(lo2[0], lo2[1], hi2[0], hi2[1]);
     };
     auto affine_row = [&](int sv, int c, int it) {
         if constexpr (ABL == 2 || ABL == 3) return;
@@ -369,10 +387,18 @@ __global__ void __launch_bounds__(512) fused2_kernel(const Fused2Args a) {
     for (int it = 0; it < 2; ++it) {
         affine_row(0, 0, it);
 #pragma unroll
-        for (int l = 0; l < 3; ++l) { issue_row(tapA, 0, 0, l, it); blend_row(tapA, 0, l, it); }
+        for (int l = 0; l < 3; ++l) {
+            issue_row(tapA, 0, 0, l, it);
+            blend_row(tapA, 0, l, it);
+        }
         finish_row(it);
     }
     stream_sync();                                                     // weight chunk 0 landed
+    constexpr bool kTapsLive = (ABL == 0 || ABL == 4);
+    if constexpr (SCHED >= 1) {                                        // pipeline prologue: the two big levels of chunk (0, 1),
+        issue_row(tapB, 0, 1, 1, 0); issue_row(tapB, 0, 1, 1, 1);      // in the steady-state order (tapB older than tapA)
+        issue_row(tapA, 0, 1, 2, 0); issue_row(tapA, 0, 1, 2, 1);
+    }
 
     const float up = (float)(1 << kWShift), down = 1.0f / (float)(1 << kWShift);
     f32x4 k1[kTD];
@@ -385,22 +411,45 @@ __global__ void __launch_bounds__(512) fused2_kernel(const Fused2Args a) {
         init_bias<kTE>(acc, lds + kLdsBias + kBiasE, q4, up);
 #pragma unroll 1
         for (int c = 0; c < kKS; ++c) {
-            const int nsv = (c + 1 < kKS) ? sv : 1;                    // branch-free: after the very last chunk re-gather (1, 0)
+            // chunk being gathered: m+1 = (nsv, nc); in the pipelined schedule also m+2 = (n2sv, n2c).  Branch-free on purpose:
+            // past the last chunk the gather harmlessly re-reads chunks of source 1.
+            const int nsv = (c + 1 < kKS) ? sv : 1;
             const int nc = (c + 1 < kKS) ? c + 1 : 0;
+            const int n2sv = (c + 2 < kKS) ? sv : 1;
+            const int n2c = (c + 2 < kKS) ? c + 2 : c + 2 - kKS;
             const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
             const NextChunk nx = next_chunk(a.blob, lds, g + 1);
-            // 9 slots of (4 ds_read_b128 + 6 MFMAs of 16 cycles); between them one piece of the next chunk's gather / DMA issue:
+            // 9 slots of (4 ds_read_b128 + 6 MFMAs of 16 cycles); between them one piece of the gather / DMA issue.
+            // SCHED 1 (levels: 2 = full resolution):
+            //   0-4 DMA pieces   0 affine start (m+1)   2 blend L2(m+1), issue L0(m+1) -> tapA   4 blend L1(m+1), issue L1(m+2) -> tapB
+            //   6 blend L0(m+1), ReLU, LDS write, issue L2(m+2) -> tapA
+            // SCHED 0:
             //   0 issue L2 -> tapA   1 issue L1 -> tapB   1-5 DMA pieces   2 affine start   4 blend L2   5 issue L0 -> tapA
             //   6 blend L1           8 blend L0, ReLU, LDS write
             auto piece = [&](int qs) {
-                if (qs >= 1 && qs < 1 + kPieces) stream_issue_piece<ABL>(nx, qs - 1, lane, wave);
-                if (qs == 0) { issue_row(tapA, nsv, nc, 2, 0); issue_row(tapA, nsv, nc, 2, 1); }
-                else if (qs == 1) { issue_row(tapB, nsv, nc, 1, 0); issue_row(tapB, nsv, nc, 1, 1); }
-                else if (qs == 2) { affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); }
-                else if (qs == 4) { blend_row(tapA, nsv, 2, 0); blend_row(tapA, nsv, 2, 1); }
-                else if (qs == 5) { issue_row(tapA, nsv, nc, 0, 0); issue_row(tapA, nsv, nc, 0, 1); }
-                else if (qs == 6) { blend_row(tapB, nsv, 1, 0); blend_row(tapB, nsv, 1, 1); }
-                else if (qs == 8) { blend_row(tapA, nsv, 0, 0); blend_row(tapA, nsv, 0, 1); finish_row(0); finish_row(1); }
+                if constexpr (SCHED == 1) {
+                    if (qs < kPieces) stream_issue_piece<ABL>(nx, qs, lane, wave);
+                    if (qs == 0) { affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); }
+                    else if (qs == 2) {
+                        blend_row(tapA, nsv, 2, 0); blend_row(tapA, nsv, 2, 1);
+                        issue_row(tapA, nsv, nc, 0, 0); issue_row(tapA, nsv, nc, 0, 1);
+                    } else if (qs == 4) {
+                        blend_row(tapB, nsv, 1, 0); blend_row(tapB, nsv, 1, 1);
+                        issue_row(tapB, n2sv, n2c, 1, 0); issue_row(tapB, n2sv, n2c, 1, 1);
+                    } else if (qs == 6) {
+                        blend_row(tapA, nsv, 0, 0); blend_row(tapA, nsv, 0, 1); finish_row(0); finish_row(1);
+                        issue_row(tapA, n2sv, n2c, 2, 0); issue_row(tapA, n2sv, n2c, 2, 1);
+                    }
+                } else {
+                    if (qs >= 1 && qs < 1 + kPieces) stream_issue_piece<ABL>(nx, qs - 1, lane, wave);
+                    if (qs == 0) { issue_row(tapA, nsv, nc, 2, 0); issue_row(tapA, nsv, nc, 2, 1); }
+                    else if (qs == 1) { issue_row(tapB, nsv, nc, 1, 0); issue_row(tapB, nsv, nc, 1, 1); }
+                    else if (qs == 2) { affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); }
+                    else if (qs == 4) { blend_row(tapA, nsv, 2, 0); blend_row(tapA, nsv, 2, 1); }
+                    else if (qs == 5) { issue_row(tapA, nsv, nc, 0, 0); issue_row(tapA, nsv, nc, 0, 1); }
+                    else if (qs == 6) { blend_row(tapB, nsv, 1, 0); blend_row(tapB, nsv, 1, 1); }
+                    else if (qs == 8) { blend_row(tapA, nsv, 0, 0); blend_row(tapA, nsv, 0, 1); finish_row(0); finish_row(1); }
+                }
             };
 #pragma unroll
             for (int qs = 0; qs < kTE / 2; ++qs) {
@@ -410,7 +459,8 @@ __global__ void __launch_bounds__(512) fused2_kernel(const Fused2Args a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             read_b(bhi, blo);                                          // next chunk's B operand (own LDS tile, in-order LDS)
-            stream_sync<ABL>();
+            // pipelined: the 16 tap loads issued in slots 4 and 6 (after the last DMA piece) stay in flight over the barrier
+            stream_sync<ABL, (SCHED >= 1 && kTapsLive) ? 16 : 0>();
             ++g;
         }
         scale_acc<kTE>(acc, down);
@@ -424,6 +474,14 @@ __global__ void __launch_bounds__(512) fused2_kernel(const Fused2Args a) {
     scale_acc<kTD>(key, down);
 
     // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ;  ug = Wr1[:,128:] g + br1 ---------------------
+    half8 ghi, glo;                                                    // B operand of the two layers fed by g (k = 16: folded bias)
+    {
+        const float* gl = lds + kLdsG + (wave * kRows + s) * 16 + 8 * (q4 & 1);
+        float gx8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gx8[k] = q4 < 2 ? gl[k] : (q4 == 2 && k == 0) ? 1.0f : 0.0f;
+        split8(gx8, ghi, glo);
+    }
     f32x4 t1[kTD], qv[kTD];
 #pragma unroll
     for (int t = 0; t < kTD; ++t) t1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -469,7 +527,7 @@ extern "C" int car_fused_samples_v2(const float* poses, const float* rays, const
     a.poses = (const CarPose*)poses; a.rays = (const CarRay*)rays; a.steps = steps;
     for (int l = 0; l < 3; ++l) {
         a.gmap[l] = gmaps[l]; a.gh[l] = level_h[l]; a.gw[l] = level_w[l];
-        CAR_REQUIRE(a.gmap[l] && a.gh[l] > 0 && a.gw[l] > 0 && (long)b * V * a.gh[l] * a.gw[l] < 2147483647L, "car_fused_samples_v2: bad level %d", l);
+        CAR_REQUIRE(a.gmap[l] && a.gh[l] > 0 && a.gw[l] > 0 && (long)b * V * a.gh[l] * a.gw[l] * (kC * 4) < 4294967296L, "car_fused_samples_v2: bad level %d (a level's map must stay below 4 GiB)", l);
     }
     a.wpt = wpt; a.blob = blob; a.bias = bias;
     a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
@@ -482,7 +540,10 @@ extern "C" int car_fused_samples_v2(const float* poses, const float* rays, const
     a.e = e; a.qry = qry; a.ug = ug; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
     const char* abl_env = getenv("CAR_FUSED_ABLATE");
     const int abl = abl_env ? atoi(abl_env) : 0;
-    void (*kern)(const Fused2Args) = abl == 1 ? fused2_kernel<1> : abl == 2 ? fused2_kernel<2> : abl == 3 ? fused2_kernel<3> : abl == 4 ? fused2_kernel<4> : fused2_kernel<0>;
+    const char* sch_env = getenv("CAR_FUSED_SCHED");
+    const int sch = sch_env ? atoi(sch_env) : 1;
+    void (*kern)(const Fused2Args) = abl == 1 ? fused2_kernel<1> : abl == 2 ? fused2_kernel<2> : abl == 3 ? fused2_kernel<3> : abl == 4 ? fused2_kernel<4>
+                                     : sch == 0 ? fused2_kernel<0, 0> : fused2_kernel<0, 1>;
     hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e1 != hipSuccess) { car_set_error("car_fused_samples_v2: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
     (void)hipGetLastError();
