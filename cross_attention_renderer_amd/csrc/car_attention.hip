@@ -10,6 +10,7 @@
 namespace {
 
 constexpr int kMaxSamples = CAR_MAX_VIEWS * 256;
+constexpr int kMaxSeg = 9;                       // widest row of the streaming value reduction: 9 x 64 channels
 
 __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -28,6 +29,7 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
                                                      float* __restrict__ depth, int32_t* __restrict__ w_argmax) {
     __shared__ float s_w[kMaxSamples];
     __shared__ float s_red[8];
+    __shared__ __attribute__((aligned(16))) float s_z[4 * 64 * kMaxSeg];       // per-wave partial sums of the value reduction
     const int sc = blockIdx.x / R, r = blockIdx.x % R;
     const int S = V * P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,6 +75,45 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
     }
     __syncthreads();
     // 3. z = sum_s w_s val[s] (+ scale * zprev), replicated `reps` times
+    if (D % 64 == 0 && D <= 64 * kMaxSeg) {
+        // Streaming form for wide rows: a 16-lane group reads a whole row as D/64 float4 loads (16 B per lane, the row's D*4
+        // bytes contiguous), the 16 groups of the workgroup take samples s = 16 it + group; every load instruction moves
+        // 1 KB and 4 iterations (4 x D/64 float4 per lane) are in flight.  Partial sums meet in LDS.
+        const int nseg = D / 64;
+        float4 part[kMaxSeg];
+#pragma unroll
+        for (int j = 0; j < kMaxSeg; ++j) part[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s0 = 0; s0 < S; s0 += 16) {
+            const int sidx = s0 + grp;
+            const bool on = sidx < S;
+            const float w = on ? s_w[sidx] : 0.0f;
+            const float* rowp = val + row_of(on ? sidx : S - 1) * D + 4 * sub;
+#pragma unroll
+            for (int j = 0; j < kMaxSeg; ++j) {
+                if (j < nseg) {
+                    const float4 x = *reinterpret_cast<const float4*>(rowp + 64 * j);
+                    part[j].x = fmaf(w, x.x, part[j].x); part[j].y = fmaf(w, x.y, part[j].y);
+                    part[j].z = fmaf(w, x.z, part[j].z); part[j].w = fmaf(w, x.w, part[j].w);
+                }
+            }
+        }
+        // the four groups of a wave hold different samples of the same channels: fold them, then the four waves through LDS
+#pragma unroll
+        for (int j = 0; j < kMaxSeg; ++j) {
+            if (j < nseg) {
+                float4 v4 = part[j];
+                v4.x += __shfl_xor(v4.x, 16, 64); v4.y += __shfl_xor(v4.y, 16, 64); v4.z += __shfl_xor(v4.z, 16, 64); v4.w += __shfl_xor(v4.w, 16, 64);
+                v4.x += __shfl_xor(v4.x, 32, 64); v4.y += __shfl_xor(v4.y, 32, 64); v4.z += __shfl_xor(v4.z, 32, 64); v4.w += __shfl_xor(v4.w, 32, 64);
+                if (lane < 16) *reinterpret_cast<float4*>(s_z + wave * (64 * kMaxSeg) + 64 * j + 4 * sub) = v4;
+            }
+        }
+        __syncthreads();
+        for (int d = tid; d < D; d += 256) {
+            float acc = (s_z[d] + s_z[64 * kMaxSeg + d]) + (s_z[2 * 64 * kMaxSeg + d] + s_z[3 * 64 * kMaxSeg + d]);
+            if (zprev) acc += zprev_scale * zprev[((long)sc * R + r) * D + d];
+            for (int k = 0; k < reps; ++k) z_out[((long)sc * R + r) * ld_z + (long)k * D + d] = acc;
+        }
+    } else
     for (int d = tid; d < D; d += 256) {
         float acc = 0.0f;
         for (int s = 0; s < S; ++s) acc += s_w[s] * val[row_of(s) * D + d];
