@@ -3,16 +3,17 @@
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A *step* renders one full 256x256 query frame (65 536 rays, 64 samples per view, 2 context views = config
-"RealEstate10K pair 256x256, 64 samples") as 8 chunks of 8192 rays — the chunking of the reference's render script
-(render_realestate10k_traj.py:96).  Inputs are synthetic (seeded stereo pair, N(0,1) feature pyramid, perturbed
+"RealEstate10K pair 256x256, 64 samples") in ONE forward call (--chunk-rays 8192 reproduces the 8 chunks of the
+reference's render script, render_realestate10k_traj.py:96, which exist only because of its GPU's memory).  Inputs are synthetic (seeded stereo pair, N(0,1) feature pyramid, perturbed
 default-init weights), resident in HBM before the timed region; ``get_z`` (the image encoder) is excluded on both
 sides, as in BASELINE.md.  With N GPUs every rank renders its own frame of the trajectory (weak scaling, rays are
 independent) and the rendered tiles [rgb, depth, valid] are exchanged with one RCCL all-gather per step.
 
 The JSON line also carries
-  roofline     : the dominant kernel (the MFMA kernel with the largest summed launch time) timed live with HIP events on
-                 the launch stream: algorithmic FLOP per launch / mean launch time vs the 157.3 TFLOP/s fp32 matrix peak
-                 of MI355X (/opt/skills/guides/MI355X_MICROARCH.md);
+  roofline     : the dominant kernel (the fused per-sample kernel) timed live with HIP events on the launch stream:
+                 algorithmic fp32-equivalent FLOP per launch / mean launch time vs the roof of the pipe it runs on — the dense
+                 f16 MFMA peak / 3 (every fp32 term costs three f16 products); the fraction of the 157.3 TFLOP/s fp32 matrix
+                 peak is reported next to it (/opt/skills/guides/MI355X_MICROARCH.md);
   cpu_baseline : the CPU oracle (a port of the reference forward, validated against it) timed on this host's cores
                  over a bounded sample of the same workload.
 """

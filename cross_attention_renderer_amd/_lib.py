@@ -15,6 +15,35 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcar_hip.so")
 
 _P = c_void_p
+
+
+class CarDims(ctypes.Structure):          # struct car_dims
+    _fields_ = [("b", c_int), ("V", c_int), ("R", c_int), ("P", c_int), ("H", c_int), ("W", c_int), ("n_levels", c_int),
+                ("level_h", c_int * 4), ("level_w", c_int * 4), ("level_c", c_int * 4), ("repeat_attention", c_int)]
+
+
+# struct car_weights: device pointers in declaration order (attribute path on the module, flattened to [out, in])
+WEIGHT_FIELDS = (
+    ["query_encode_latent", "query_encode_latent_2", "latent_value", "key_map", "key_map_2", "query_embed", "query_embed_2",
+     "query_repeat_embed", "query_repeat_embed_2", "encode_latent", "phi.lin_in", "phi.lin_out"],
+    ["phi.lin_z", "phi.blocks.fc_0", "phi.blocks.fc_1"])
+
+
+class CarWeights(ctypes.Structure):
+    _fields_ = ([(f"{n.replace('.', '_')}_{k}", _P) for n in WEIGHT_FIELDS[0] for k in ("w", "b")]
+                + [("phi_lin_z_w", _P * 3), ("phi_lin_z_b", _P * 3), ("phi_fc_0_w", _P * 3), ("phi_fc_0_b", _P * 3),
+                   ("phi_fc_1_w", _P * 3), ("phi_fc_1_b", _P * 3)])
+
+
+class CarInputs(ctypes.Structure):
+    _fields_ = [("poses", _P), ("uv", _P), ("gmaps", _P), ("steps", _P)]
+
+
+class CarOutputs(ctypes.Structure):
+    _fields_ = [("rgb", _P), ("valid_mask", _P), ("depth_ray", _P), ("at_wt", _P), ("at_wt_max", _P), ("coords", _P),
+                ("pixel_val", _P)]
+
+
 # name -> (restype, argtypes); mirrors include/car_hip.h line by line
 SIGNATURES = {
     "car_version": (c_int, []),
@@ -42,6 +71,14 @@ SIGNATURES = {
     "car_round2_logits": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "car_add_ray_bias_relu": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "car_finalize": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "car_plan_bytes": (c_size_t, [ctypes.POINTER(CarDims)]),
+    "car_plan_build": (c_int, [ctypes.POINTER(CarDims), ctypes.POINTER(CarWeights), _P, _P]),
+    "car_gmaps_floats": (c_size_t, [ctypes.POINTER(CarDims)]),
+    "car_project_maps": (c_int, [ctypes.POINTER(CarDims), _P, _P, _P, _P]),
+    "car_workspace_bytes": (c_size_t, [ctypes.POINTER(CarDims)]),
+    "car_render_forward": (c_int, [ctypes.POINTER(CarDims), _P, ctypes.POINTER(CarInputs), ctypes.POINTER(CarOutputs), _P,
+                                   c_size_t, _P]),
+    "car_linspace": (None, [c_float, c_float, c_int, _P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

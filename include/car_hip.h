@@ -176,6 +176,70 @@ int car_add_ray_bias_relu(float* r, const float* u, int b, int V, int R, int P, 
 int car_finalize(const float* rays, const float* rgb_in, int ld_in, int b, int V, int R, float* rgb, float* valid,
                  void* stream);
 
+/* =====================================================================================================================
+ * One-call forward for hosts without the Python engine: the launch sequence of
+ * cross_attention_renderer_amd/engine.py::RenderEngine for the reference's default configuration
+ * (CrossAttentionRenderer(model="midas_vit", n_view=2), models.py:43-145, forward models.py:190-626).
+ *
+ *   car_plan_bytes / car_plan_build      once per set of weights: re-lays every layer out for the kernels ("plan", device memory)
+ *   car_project_maps                     once per stereo pair: first point-MLP layer applied per texel of the pyramid (§4.3 DESIGN.md)
+ *   car_workspace_bytes / car_render_forward   once per batch of rays
+ *
+ * All pointers are device pointers unless marked host; nothing is allocated, nothing is kept.  car_plan_build synchronises
+ * the stream once (it uploads a small host table); the other calls are asynchronous.  Unsupported configurations
+ * (n_view != 2, other widths, no_sample, no_latent_concat) return CAR_E_ARG: they run through the stage entries above. */
+typedef struct car_dims {
+    int b, V, R, P, H, W;          /* scenes, context views (2), rays per scene, samples per ray and view, image size            */
+    int n_levels;                  /* pyramid levels (3)                                                                      */
+    int level_h[CAR_MAX_LEVELS], level_w[CAR_MAX_LEVELS], level_c[CAR_MAX_LEVELS];   /* e.g. 64x64x256, 128x128x256, 256x256x64 */
+    int repeat_attention;          /* second attention round (models.py:547), the reference's default: 1                          */
+} car_dims;
+
+/* Parameters in the reference's state_dict layout: row-major [out][in] fp32, 1x1 convolutions flattened (models.py:96-144). */
+typedef struct car_weights {
+    const float *query_encode_latent_w, *query_encode_latent_b;         /* (576, 579), (576)  models.py:102 */
+    const float *query_encode_latent_2_w, *query_encode_latent_2_b;     /* (288, 576)         models.py:103 */
+    const float *latent_value_w, *latent_value_b;                       /* (288, 576)         models.py:117 */
+    const float *key_map_w, *key_map_b, *key_map_2_w, *key_map_2_b;     /* (128, 576), (128, 128)   models.py:118-119 */
+    const float *query_embed_w, *query_embed_b, *query_embed_2_w, *query_embed_2_b;                 /* (128, 16), (128, 128)   :126-127 */
+    const float *query_repeat_embed_w, *query_repeat_embed_b, *query_repeat_embed_2_w, *query_repeat_embed_2_b;   /* (128, 144), (128, 128)  :136-137 */
+    const float *encode_latent_w, *encode_latent_b;                     /* (128, 288)         models.py:142 */
+    const float *phi_lin_in_w, *phi_lin_in_b, *phi_lin_out_w, *phi_lin_out_b;                       /* (128, 18), (3, 128)   resnet_block_fc.py:88-99 */
+    const float *phi_lin_z_w[3], *phi_lin_z_b[3];                       /* (128, 576)         resnet_block_fc.py:108-113 */
+    const float *phi_fc_0_w[3], *phi_fc_0_b[3], *phi_fc_1_w[3], *phi_fc_1_b[3];                     /* (128, 128)            resnet_block_fc.py:29-33 */
+} car_weights;
+
+typedef struct car_inputs {
+    const float* poses;            /* [b*V, CAR_POSE_FLOATS]  from car_pose_setup, or filled by the host (poses.py)        */
+    const float* uv;               /* [b, R, 2] pixel coordinates (x = column, y = row)                                     */
+    const float* gmaps;            /* projected maps from car_project_maps: levels back to back, [b*V, Hl, Wl, 576] each     */
+    const float* steps;            /* optional [P]: sample positions along the epipolar segment.  NULL = the plan's linspace(0,1,P)
+                                      (car_linspace).  torch.linspace itself differs in the last ulp between hosts (its vectorised
+                                      kernel depends on the CPU's vector width), so a host that wants torch's exact values passes them. */
+} car_inputs;
+
+typedef struct car_outputs {       /* the tensors of the reference's output dict (models.py:597-626); any may be NULL except rgb */
+    float* rgb;                    /* [b, R, 3]                                                                              */
+    float* valid_mask;             /* [b, R]                                                                                 */
+    float* depth_ray;              /* [b, R]                                                                                 */
+    float* at_wt;                  /* [b*V, R, P]   first-round attention weights                                            */
+    int32_t* at_wt_max;            /* [b*V, R]      argmax_p of at_wt                                                        */
+    float* coords;                 /* [b*V, R, 9]                                                                            */
+    float* pixel_val;              /* [b*V, R, P, 2]                                                                         */
+} car_outputs;
+
+size_t car_plan_bytes(const car_dims* dims);
+int car_plan_build(const car_dims* dims, const car_weights* weights, void* plan, void* stream);
+size_t car_gmaps_floats(const car_dims* dims);
+/* maps[l]: level l of the encoder's pyramid, channel-last [b*V, Hl, Wl, Cl] (`maps` is a host array of device pointers). */
+int car_project_maps(const car_dims* dims, const void* plan, const float* const* maps, float* gmaps, void* stream);
+size_t car_workspace_bytes(const car_dims* dims);
+int car_render_forward(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* host helper: linspace(a, b, n) the way torch's scalar CPU kernel computes it (models.py:261): step = (b-a)/(n-1), first half
+ * a + step*i, second half b - step*(n-1-i); `out` is a HOST array.  Equal to torch.linspace for n < 16, within 1 ulp otherwise. */
+void car_linspace(float a, float b, int n, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,25 @@ def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_pos
     return c, fx, ora, cpu(out)
 
 
+def run_native(name: str, device="cuda:0", fixture_poses=False):
+    """The same case through the one-call C ABI (car_plan_build / car_project_maps / car_render_forward) and through the
+    Python engine: returns (engine output, native output), tensors on the CPU."""
+    from cross_attention_renderer_amd.engine import RenderEngine
+    from cross_attention_renderer_amd.native import NativeRenderer
+    c, inp, z, sd, fx = load_case(name)
+    poses = torch.as_tensor(fx["poses"]) if fixture_poses else None
+    m = build_module(c, sd, device)
+    m._engine = RenderEngine(m)
+    m._engine.pose_records = poses
+    dinp, dz = to_device(inp, device), [t.to(device) for t in z]
+    with torch.no_grad():
+        eng = m(dinp, z=dz)
+        nat = NativeRenderer(m, device).forward(dinp, dz, poses96=poses)
+    torch.cuda.synchronize()
+    keys = ("rgb", "valid_mask", "depth_ray", "at_wt", "at_wt_max", "coords", "pixel_val")
+    return {k: eng[k].detach().cpu() for k in keys}, {k: nat[k].detach().cpu() for k in keys}
+
+
 def err_stats(a, b) -> Dict[str, float]:
     """Relative error |a-b|/max(1,|b|): max, and the fraction of elements above 1e-4 / 1e-3."""
     a = torch.as_tensor(np.asarray(a)).double()

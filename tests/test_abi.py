@@ -76,3 +76,29 @@ def test_module_state_dict_matches_reference_table():
     assert t["phi.lin_in.weight"] == (128, 18) and t["phi.lin_z.2.weight"] == (128, 576)
     assert t["conv_map.weight"] == (64, 3, 7, 7)
     assert sum(int(__import__("math").prod(s)) for s in t.values()) == 1457955
+
+
+
+def test_one_call_abi_host_side(lib):
+    """Host-only parts of the one-call forward (include/car_hip.h): sizes, argument validation, linspace."""
+    import torch
+    from cross_attention_renderer_amd import _lib
+    d = _lib.CarDims()
+    d.b, d.V, d.R, d.P, d.H, d.W, d.n_levels, d.repeat_attention = 1, 2, 8192, 64, 256, 256, 3, 1
+    for l, (c, h) in enumerate(((256, 64), (256, 128), (64, 256))):
+        d.level_c[l], d.level_h[l], d.level_w[l] = c, h, h
+    S = 2 * 8192 * 64
+    assert lib.car_workspace_bytes(ctypes.byref(d)) >= 4 * S * (576 + 128 + 128)          # e, qry, ug dominate
+    assert lib.car_plan_bytes(ctypes.byref(d)) >= 4 * lib.car_fused2_blob_floats()
+    assert lib.car_gmaps_floats(ctypes.byref(d)) == 2 * (64 * 64 + 128 * 128 + 256 * 256) * 576
+    d.V = 3                                                                                 # not covered by the one-call entry
+    assert lib.car_workspace_bytes(ctypes.byref(d)) == 0 and b"n_view = 2" in lib.car_last_error()
+    assert lib.car_render_forward(ctypes.byref(d), None, None, None, None, 0, None) == -1
+    # car_linspace: torch's scalar formula; torch's vectorised CPU kernel may differ in the last ulp for n >= 16
+    for n in (2, 5, 8, 15, 16, 32, 64, 128):
+        buf = (ctypes.c_float * n)()
+        lib.car_linspace(0.0, 1.0, n, buf)
+        got, want = torch.tensor(list(buf)), torch.linspace(0, 1, n)
+        assert (got - want).abs().max() <= 6e-8, n
+        if n < 8:
+            assert torch.equal(got, want)
