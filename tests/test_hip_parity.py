@@ -327,3 +327,34 @@ def test_one_call_c_abi_equals_python_engine(name):
     for k in eng:
         assert eng[k].shape == nat[k].shape, k
         assert torch.equal(eng[k], nat[k]), f"{name} {k}: max abs diff {(eng[k].double() - nat[k].double()).abs().max().item()}"
+
+
+
+@pytest.mark.parametrize("R,P,b", [(37, 13, 1), (16, 8, 2), (131, 70, 1)])
+def test_fused_path_ragged_sizes_against_the_oracle(R, P, b):
+    """Ray counts that are no multiple of 16 and sample counts that are no multiple of 8 (the fused kernel works on groups of
+    16 rays x 8 steps, the round-2 kernel on blocks of 32 samples): real widths, H = 64, rays picked across the frame."""
+    from cross_attention_renderer_amd import synthetic as S
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    dev = torch.device("cuda:0")
+    H = 64
+    torch.manual_seed(0)
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P).eval()
+    S.perturb_parameters(m, seed=4)
+    m.H = m.W = H
+    uv = C.select_rays(H, R)
+    inp = S.stereo_scene(H, b=b, uv=uv, seed=7, alpha=0.35)
+    z = S.feature_maps(b, 2, H, seed=2)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ora = O.render_forward(sd, inp, z, O.RenderConfig(n_view=2, npoints=P, H=H, W=H), debug=True)
+        md = m.to(dev)
+        out = md(to_device(inp, dev), z=[t.to(dev) for t in z], debug=True)
+    torch.cuda.synchronize()
+    assert out["stages"]["local_coords"] is None, "the fused kernel was not selected"
+    assert torch.equal(out["stages"]["pt"].cpu(), ora["stages"]["pt"])
+    for k in ("rgb", "depth_ray", "at_wt"):
+        e = err_stats(out[k].cpu(), ora[k])
+        assert e["max"] <= TOL, (k, e)
+    assert torch.equal(out["valid_mask"].cpu(), ora["valid_mask"])
+    assert (out["at_wt_max"].cpu() == ora["at_wt_max"]).float().mean() > 0.99
