@@ -207,7 +207,8 @@ def main():
             "config": {"workload": f"256x256 query frame, 64 samples/view, 2 context views (config 2), {-(-65536 // args.chunk_rays)} forward calls x {args.chunk_rays} rays",
                        "rays_per_step_per_gpu": R, "parallelism": f"ray-sharded frames x{world}, RCCL all-gather of tiles"},
             "roofline": roof,
-            "cpu_baseline": cpu_baseline(args.cpu_rays) if args.cpu_rays > 0 else None,
+            # the CPU leg runs on rank 0 of a single-GPU job only (it is a per-host figure and would stall the other ranks)
+            "cpu_baseline": cpu_baseline(args.cpu_rays) if (args.cpu_rays > 0 and world == 1) else None,
         }
         print(json.dumps(line))
     if dist is not None:

@@ -172,6 +172,27 @@ __device__ __forceinline__ void mfma_pair(f32x4& c0, f32x4& c1, const float* w0,
     c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bhi, c1, 0, 0, 0);
 }
 
+// the same with the A operands (two tiles, hi and lo) read one slot ahead: a ds_read_b128 issued right before its MFMAs
+// exposes the LDS latency (~100+ cycles) in every slot, and the scheduling barriers keep hipcc from hoisting it
+struct AHi { float4 h0, h1; };
+__device__ __forceinline__ AHi load_ahi(const float* w0) {
+    AHi a;
+    a.h0 = *reinterpret_cast<const float4*>(w0);
+    a.h1 = *reinterpret_cast<const float4*>(w0 + 512);
+    return a;
+}
+// the hi halves come from the previous slot; the lo halves are read now and first used by the fifth MFMA (64 cycles later)
+__device__ __forceinline__ void mfma_ahead(f32x4& c0, f32x4& c1, const AHi& a, const float* w0, const half8& bhi, const half8& blo) {
+    const float4 l0 = *reinterpret_cast<const float4*>(w0 + 256), l1 = *reinterpret_cast<const float4*>(w0 + 512 + 256);
+    const half8 ah0 = __builtin_bit_cast(half8, a.h0), ah1 = __builtin_bit_cast(half8, a.h1);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhi, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhi, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blo, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blo, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, l0), bhi, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, l1), bhi, c1, 0, 0, 0);
+}
+
 // accumulators start at bias * scale: lane (s, q) register r of tile t holds channel 16 t + 4 q + r
 template <int NT>
 __device__ __forceinline__ void init_bias(f32x4 (&acc)[NT], const float* lbias, int q, float scale) {
@@ -215,10 +236,13 @@ __device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&s
                 }
                 half8 bhi, blo;
                 split8(x, bhi, blo);
+                AHi an = load_ahi(wl + ((kl * kTD) * 2) * 256);
 #pragma unroll
                 for (int q = 0; q < kTD / 2; ++q) {
                     const float* w0 = wl + ((kl * kTD + 2 * q) * 2) * 256;
-                    mfma_pair(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, bhi, blo);
+                    const AHi ac = an;
+                    if (q + 1 < kTD / 2) an = load_ahi(w0 + 4 * 256);                        // next slot's hi halves first
+                    mfma_ahead(acc[2 * q], acc[2 * q + 1], ac, w0, bhi, blo);
                     if (kl * 4 + q < kPieces) stream_issue_piece<ABL>(nx, kl * 4 + q, lane, wave);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -451,10 +475,12 @@ __global__ void __launch_bounds__(512) fused2_kernel(const Fused2Args a) {
                     else if (qs == 8) { blend_row(tapA, nsv, 0, 0); blend_row(tapA, nsv, 0, 1); finish_row(0); finish_row(1); }
                 }
             };
+            AHi an = load_ahi(wl);
 #pragma unroll
             for (int qs = 0; qs < kTE / 2; ++qs) {
-                const float* w0 = wl + (2 * qs * 2) * 256;
-                if constexpr (ABL != 4) mfma_pair(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
+                const AHi ac = an;
+                if (qs + 1 < kTE / 2) an = load_ahi(wl + (2 * (qs + 1) * 2) * 256);          // next slot's hi halves first
+                if constexpr (ABL != 4) mfma_ahead(acc[2 * qs], acc[2 * qs + 1], ac, wl + (2 * qs * 2) * 256, bhi, blo);
                 piece(qs);
                 __builtin_amdgcn_sched_barrier(0);
             }
