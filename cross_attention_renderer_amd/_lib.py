@@ -63,6 +63,8 @@ SIGNATURES = {
     "car_fused2_blob_floats": (c_size_t, []),
     "car_fused_samples_v2": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                      _P, _P, _P, _P, _P, _P, _P]),
+    "car_fused_samples_v4": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                     _P, _P, _P, _P, _P, _P, _P]),
     "car_linear_packed_floats": (c_size_t, [c_int, c_int]),
     "car_linear_pack": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "car_linear": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_long, c_int, _P]),

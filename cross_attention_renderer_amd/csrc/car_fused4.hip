@@ -1,0 +1,541 @@
+// car_fused4.hip — the fused per-sample kernel at THREE waves per SIMD (algorithm and reference line numbers: car_fused.hip;
+// the split-fp16 16x16x32 mapping, packed weights and chained layers are those of car_fused2.hip, same blob).
+//
+// car_fused2.hip is latency bound: two in-order waves per SIMD leave the texture-address path 60 % busy, the matrix pipe 27 %
+// (profiles/r11).  A third wave needs <= 168 registers per wave, which this version reaches by
+//   * keeping the key layer's accumulators (k1, 32 registers) out of the e path: k1 = Wk1 [e_0 ; e_1] is computed after both
+//     sources, chained from the accumulators for e_1 and from e_0 read back from the output tensor it was just stored to (L2);
+//   * half-size tap batches (one level of one row group: 4 float4) in two alternating buffers instead of two whole levels;
+//   * no read-ahead of the weight operands (a third wave hides the LDS latency instead).
+// One workgroup = 12 waves = 192 samples = 48 consecutive rays x 4 consecutive steps (wave = (16-ray bundle, step)); the weight
+// stream is shared by 192 instead of 128 samples.  The tap tables are stored compactly (base offset + two flags, four weights)
+// to fit the LDS budget.
+#include "car_common.h"
+#include "car_geom.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int kWShift = 8;
+
+constexpr int kC = 576;            // feature channels = width of h
+constexpr int kE = 288;            // per-source width of e
+constexpr int kD = 128;            // hidden width of the key / query MLPs
+constexpr int kKS = kC / 32;       // 18 K steps (= weight chunks) of the 576 -> 288 layer
+constexpr int kTE = kE / 16;       // 18 output tiles of 16 channels
+constexpr int kTD = kD / 16;       // 8 output tiles
+constexpr int kTile = 512;         // packed floats per (K step, tile): [hi|lo][64 lanes][8 halves] = 2 KB
+constexpr int kStageLd = 36;       // row stride of the wave-private h tile (floats)
+constexpr int kWaves = 12, kRows = 16, kGroup = kWaves * kRows;      // 192 samples per workgroup
+constexpr int kStepsPerGroup = 4, kBundles = kWaves / kStepsPerGroup;  // 3 bundles of 16 rays x 4 steps
+
+// ---- packed-weight blob: offsets in tiles, layer by layer, [K step][tile] inside a layer ---------------------------
+constexpr int kOffW2 = 0;                          // 18 steps x 18 tiles, standard K mapping
+constexpr int kOffQ1 = kOffW2 + kKS * kTE;         // 1 x 8, standard, bias folded at k = 16
+constexpr int kOffQ2 = kOffQ1 + kTD;               // 4 x 8, chained
+constexpr int kOffUG = kOffQ2 + 4 * kTD;           // 1 x 8, standard, bias folded
+constexpr int kOffK1 = kOffUG + kTD;               // 18 x 8, chained over [e_0 ; e_1] (9 steps per source)
+constexpr int kOffK2 = kOffK1 + 18 * kTD;          // 4 x 8, chained
+constexpr int kBlobTiles = kOffK2 + 4 * kTD;
+constexpr int kNumChunks = 2 * kKS + 2 * 5 + 2 + 1 + 2 + 1;           // 52 weight chunks per pass, same order as car_fused.hip
+constexpr int kChunkTiles = kTE;                   // largest chunk: 18 tiles = 36 KB
+constexpr int kPieces = 3;                         // LDS-DMA pieces per chunk: 12 waves x 1 KB each
+
+constexpr int kBiasE = 0, kBiasQ2 = kE, kBiasK1 = kE + kD, kBiasK2 = kE + 2 * kD, kBiasFloats = kE + 3 * kD;
+
+// ---- dynamic LDS carve-up (floats) --------------------------------------------------------------------------------
+constexpr int kLdsW = 0;                                        // [2][18][512]           weight chunks          72 KB
+constexpr int kLdsStage = kLdsW + 2 * kChunkTiles * kTile;      // [12][16][36]           h tiles, wave private     27 KB
+constexpr int kLdsTapB = kLdsStage + kGroup * kStageLd;         // [192][2][3] uint       byte offset of the nw texel | 1: x1 != x0 | 2: y1 != y0   4.5 KB
+constexpr int kLdsTapW = kLdsTapB + kGroup * 6;                 // [192][2][3][4]         tap weights (nw, ne, sw, se)   18 KB
+constexpr int kLdsPe = kLdsTapW + kGroup * 24;                  // [192][2][4]            tanh(pt_s/5)                6 KB
+constexpr int kLdsWpt = kLdsPe + kGroup * 8;                    // [576][4]               (W1[:,C:C+3], b1)           9 KB
+constexpr int kLdsBias = kLdsWpt + kC * 4;                      // [672]
+constexpr int kLdsG = kLdsBias + kBiasFloats;                   // [192][16]              geometric query g per sample 12 KB
+constexpr int kLdsFloats = kLdsG + kGroup * 16;
+constexpr size_t kLdsBytes = (size_t)kLdsFloats * sizeof(float);
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+
+struct Fused4Args {
+    const CarPose* poses;
+    const CarRay* rays;
+    const float* steps;
+    const float* gmap[3];
+    int gh[3], gw[3];
+    const float* wpt;
+    const float* blob;
+    const float* bias;
+    int b, V, R, P, H, W;
+    int xcd_bands;
+    int ray_major;
+    long S;
+    float* e;
+    float* qry;
+    float* ug;
+    float* logit;
+    float* pt;
+    float* pixel_val;
+};
+
+// chunk order:  W2 x18 (source 0) | W2 x18 (source 1) | K1 over e_1 x5 (2,2,2,2,1 K steps) | K1 over e_0 x5 | K2 x2 | Q1 | Q2 x2 | UG
+constexpr int kChK1 = 5;
+constexpr int kG_W2b = kKS, kG_K1b = 2 * kKS, kG_K1a = kG_K1b + kChK1, kG_K2 = kG_K1a + kChK1, kG_Q1 = kG_K2 + 2, kG_Q2 = kG_Q1 + 1,
+              kG_UG = kG_Q2 + 2;
+__device__ __forceinline__ int chunk_tile_offset(int g) {
+    if (g < kG_W2b) return kOffW2 + g * kTE;
+    if (g < kG_K1b) return kOffW2 + (g - kG_W2b) * kTE;
+    if (g < kG_K1a) return kOffK1 + 9 * kTD + (g - kG_K1b) * 2 * kTD;
+    if (g < kG_K2) return kOffK1 + (g - kG_K1a) * 2 * kTD;
+    if (g < kG_Q1) return kOffK2 + (g - kG_K2) * 2 * kTD;
+    if (g < kG_Q2) return kOffQ1;
+    if (g < kG_UG) return kOffQ2 + (g - kG_Q2) * 2 * kTD;
+    return kOffUG;
+}
+__device__ __forceinline__ int chunk_tiles(int g) {
+    if (g < kG_K1b) return kTE;
+    if (g == kG_K1a - 1 || g == kG_K2 - 1 || g == kG_Q1 || g == kG_UG) return kTD;       // odd last K1 step, Q1, UG
+    return 2 * kTD;
+}
+
+// Descriptor of the chunk to prefetch, resolved once per chunk with scalar branches so the per-piece issue is straight-line
+struct NextChunk { const float* src; float* dst; int nkb; };
+__device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, float* lds, int g) {
+    const int ge = g < kNumChunks ? g : kNumChunks - 1;            // past the end: re-copy the last chunk onto itself
+    NextChunk n;
+    n.src = blob + (long)chunk_tile_offset(ge) * kTile;
+    n.dst = lds + kLdsW + (ge & 1) * kChunkTiles * kTile;
+    n.nkb = 2 * chunk_tiles(ge);
+    return n;
+}
+// piece p of the next chunk: wave w copies KB number 12 p + w (wrapped into the chunk: re-copying identical bytes is harmless).
+// LDS-DMA in inline asm, see car_linear.hip.  Must only run after the barrier that retired the buffer's previous chunk.
+template <int ABL = 0>
+__device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, int lane, int wave) {
+    if constexpr (ABL == 3) return;
+    int kb = kWaves * p + wave;
+    kb = kb < n.nkb ? kb : kb - n.nkb;
+    kb = kb < n.nkb ? kb : kb - n.nkb;
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(n.dst + kb * 256));
+    const float* gsrc = n.src + kb * 256 + 4 * lane;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int ABL = 0>
+__device__ __forceinline__ void stream_issue_all(const float* __restrict__ blob, float* lds, int g, int lane, int wave) {
+    if (g >= kNumChunks) return;
+    const NextChunk n = next_chunk(blob, lds, g);
+#pragma unroll
+    for (int p = 0; p < kPieces; ++p) stream_issue_piece<ABL>(n, p, lane, wave);
+}
+// end of a chunk: the DMA of the next chunk has landed and every wave is done reading the current one.  KEEP = number of
+// vector loads this wave issued AFTER its last DMA piece and wants to leave in flight across the barrier (loads return in
+// order, so "at most KEEP outstanding" still means every DMA piece has landed).
+template <int ABL = 0, int KEEP = 0>
+__device__ __forceinline__ void stream_sync() {
+    if constexpr (ABL == 3) return;
+    if constexpr (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// x = hi + lo in fp16 halves.  The halves are rounded toward zero (v_cvt_pkrtz_f16_f32 converts two values per instruction):
+// x - hi is exact in fp32 and |x - hi - lo| < 2^-20 |x|, still fp32-class after the three-product MFMA.
+__device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(x[e], x[e + 1]);
+        const fp16x2 l2 = __builtin_amdgcn_cvt_pkrtz(x[e] - (float)h2[0], x[e + 1] - (float)h2[1]);
+        hi[e] = (_Float16)h2[0]; hi[e + 1] = (_Float16)h2[1];
+        lo[e] = (_Float16)l2[0]; lo[e + 1] = (_Float16)l2[1];
+    }
+}
+
+// two output tiles x three split products, interleaved so consecutive MFMAs never share an accumulator
+__device__ __forceinline__ void mfma_pair(f32x4& c0, f32x4& c1, const float* w0, const float* w1, const half8& bhi, const half8& blo) {
+    const half8 ah0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0));
+    const half8 ah1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1));
+    const half8 al0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0 + 256));
+    const half8 al1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1 + 256));
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhi, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhi, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blo, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blo, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bhi, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bhi, c1, 0, 0, 0);
+}
+
+// the same with the A operands (two tiles, hi and lo) read one slot ahead: a ds_read_b128 issued right before its MFMAs
+// exposes the LDS latency (~100+ cycles) in every slot, and the scheduling barriers keep hipcc from hoisting it
+struct AHi { float4 h0, h1; };
+__device__ __forceinline__ AHi load_ahi(const float* w0) {
+    AHi a;
+    a.h0 = *reinterpret_cast<const float4*>(w0);
+    a.h1 = *reinterpret_cast<const float4*>(w0 + 512);
+    return a;
+}
+// the hi halves come from the previous slot; the lo halves are read now and first used by the fifth MFMA (64 cycles later)
+__device__ __forceinline__ void mfma_ahead(f32x4& c0, f32x4& c1, const AHi& a, const float* w0, const half8& bhi, const half8& blo) {
+    const float4 l0 = *reinterpret_cast<const float4*>(w0 + 256), l1 = *reinterpret_cast<const float4*>(w0 + 512 + 256);
+    const half8 ah0 = __builtin_bit_cast(half8, a.h0), ah1 = __builtin_bit_cast(half8, a.h1);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhi, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhi, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blo, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blo, c1, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, l0), bhi, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, l1), bhi, c1, 0, 0, 0);
+}
+
+// accumulators start at bias * scale: lane (s, q) register r of tile t holds channel 16 t + 4 q + r
+template <int NT>
+__device__ __forceinline__ void init_bias(f32x4 (&acc)[NT], const float* lbias, int q, float scale) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float4 b4 = *reinterpret_cast<const float4*>(lbias + 16 * t + 4 * q);
+        acc[t][0] = b4.x * scale; acc[t][1] = b4.y * scale; acc[t][2] = b4.z * scale; acc[t][3] = b4.w * scale;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void scale_acc(f32x4 (&acc)[NT], float f) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] *= f;
+}
+template <int NT>
+__device__ __forceinline__ void store_rows(const f32x4 (&acc)[NT], float* row, int q) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        *reinterpret_cast<float4*>(row + 16 * t + 4 * q) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+}
+
+// one chained layer with 128 outputs over NSRC source tiles (two per K step), weight chunks of two K steps
+template <int NSRC, bool RELU, int ABL>
+__device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&src)[NSRC], const float* __restrict__ blob,
+                                              float* lds, int& g, int lane, int wave) {
+    constexpr int kSteps = NSRC / 2;
+#pragma unroll
+    for (int m0 = 0; m0 < kSteps; m0 += 2) {
+        const int nks = m0 + 1 < kSteps ? 2 : 1;
+        const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
+        const NextChunk nx = next_chunk(blob, lds, g + 1);
+#pragma unroll
+        for (int kl = 0; kl < 2; ++kl) {
+            if (kl < nks) {
+                const int m = m0 + kl < kSteps ? m0 + kl : kSteps - 1;
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    x[e] = src[2 * m + (e >> 2)][e & 3];
+                    if (RELU) x[e] = fmaxf(x[e], 0.f);
+                }
+                half8 bhi, blo;
+                split8(x, bhi, blo);
+#pragma unroll
+                for (int q = 0; q < kTD / 2; ++q) {
+                    const float* w0 = wl + ((kl * kTD + 2 * q) * 2) * 256;
+                    mfma_pair(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, bhi, blo);
+                    if (kl * 4 + q < kPieces) stream_issue_piece<ABL>(nx, kl * 4 + q, lane, wave);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // a single-step chunk has only 4 slots: issue the remaining pieces of its successor here
+#pragma unroll
+        for (int p = nks * 4; p < kPieces; ++p) stream_issue_piece<ABL>(nx, p, lane, wave);
+        stream_sync<ABL>();
+        ++g;
+    }
+}
+
+// a K = 16 (+ folded bias) layer with 128 outputs: one K step, B operand (ghi, glo) prepared by the caller
+__device__ __forceinline__ void small_layer(f32x4 (&acc)[kTD], const half8& ghi, const half8& glo, const float* wl) {
+#pragma unroll
+    for (int q = 0; q < kTD / 2; ++q) {
+        const float* w0 = wl + (2 * q * 2) * 256;
+        mfma_pair(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, ghi, glo);
+    }
+}
+
+// ABL > 0: timing-only ablations (wrong results): 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers
+template <int ABL>
+__global__ void __launch_bounds__(768) fused4_kernel(const Fused4Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = lane & 15, q4 = lane >> 4;
+    const int nblk = gridDim.x;
+    int blk = blockIdx.x;
+    if (a.xcd_bands) {                                                 // contiguous band of sample groups per XCD, see car_fused.hip
+        const int q8 = nblk / 8, r8 = nblk % 8, xcd = blk % 8, idx = blk / 8;
+        blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    // 192 samples = 48 consecutive rays x 4 consecutive steps: wave = (bundle of 16 rays, step), lane & 15 = ray of the bundle, so the
+    // 16 rows a wave gathers together are the same step of neighbouring rays (shared texel rows, see car_fused2.hip)
+    const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + 3 * kRows - 1) / (3 * kRows);
+    const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
+    const int ray_i = bun * (kBundles * kRows) + (wave / kStepsPerGroup) * kRows + s, pp = pg * kStepsPerGroup + wave % kStepsPerGroup;
+    const bool live = ray_i < a.R && pp < a.P;
+    const long i = ((long)nn * a.R + (ray_i < a.R ? ray_i : a.R - 1)) * a.P + (pp < a.P ? pp : a.P - 1);
+
+    for (int k = tid; k < kC; k += 768) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
+    for (int k = tid; k < kBiasFloats; k += 768) lds[kLdsBias + k] = a.bias[k];
+    int g = 0;
+    stream_issue_all<ABL>(a.blob, lds, 0, lane, wave);
+
+    // ---- geometry of this lane's sample (the four lane groups repeat it); lane group 0 / 1 prepares source view 0 / 1 ----
+    const int P = a.P, V = a.V;
+    const int p = (int)(i % P);
+    const long nr = i / P;
+    const int n = (int)(nr / a.R);
+    const int v = n % V, sc = n / V;
+    {
+        const CarPose& Ps = a.poses[n];
+        const CarRay ray = a.rays[nr];
+        CarSample smp;
+        for (int k = 0; k < 2; ++k) smp.grid[k] = ray.start[k] + (ray.end[k] - ray.start[k]) * a.steps[p];
+        car_sample_setup(Ps, a.poses + sc * 2, ray, 2, a.H, a.W, &smp);
+        if (q4 < 2) {
+            const int sv = q4;
+            float gx, gy;
+            int mode, m;
+            if (sv == v) { gx = smp.grid[0]; gy = smp.grid[1]; mode = 0; m = n; }
+            else { gx = sv == 0 ? smp.grid_in[0][0] : smp.grid_in[1][0]; gy = sv == 0 ? smp.grid_in[0][1] : smp.grid_in[1][1]; mode = 1; m = sc * V + sv; }
+            unsigned* tb = reinterpret_cast<unsigned*>(lds + kLdsTapB) + ((wave * kRows + s) * 2 + sv) * 3;
+            float* tw = lds + kLdsTapW + ((wave * kRows + s) * 2 + sv) * 12;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                int idx[4];
+                float w[4];
+                car_bilinear_taps(gx, gy, a.gw[l], a.gh[l], mode, idx, w);
+                // the four taps are (x0|x1, y0|y1) after clamping: nw + {0, 1 texel} + {0, 1 row}; a texel row is kC*4 = 2304 B, a multiple
+                // of 256, so the two flags ride in the low bits of the nw texel's byte offset
+                tb[l] = (unsigned)(m * a.gh[l] * a.gw[l] + idx[0]) * (unsigned)(kC * 4) | (idx[1] != idx[0] ? 1u : 0u) | (idx[2] != idx[0] ? 2u : 0u);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) tw[4 * l + t] = w[t];
+            }
+            float* pe = lds + kLdsPe + ((wave * kRows + s) * 2 + sv) * 4;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pe[k] = tanhf((sv == 0 ? smp.pt_in[0][k] : smp.pt_in[1][k]) / 5.0f);
+            pe[3] = 0.0f;
+        }
+        if (live && q4 == 0) {
+            a.pixel_val[2 * i] = smp.grid[0]; a.pixel_val[2 * i + 1] = smp.grid[1];
+            a.pt[3 * i + 0] = smp.pt[0]; a.pt[3 * i + 1] = smp.pt[1]; a.pt[3 * i + 2] = smp.pt[2];
+        }
+        if (q4 < 2) {
+            float* gl = lds + kLdsG + (wave * kRows + s) * 16 + 8 * q4;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gl[k] = q4 == 0 ? smp.g[k] : smp.g[8 + k];
+        }
+    }
+    __syncthreads();                                                   // tables and tap records visible
+
+    // ---- gather machinery: lane owns rows rr = (lane>>3) + 8*it (it = 0, 1) and channel quad qd = lane & 7 of a chunk.
+    //      A batch = the 4 tap loads of one row group `it` at one level; two batches (bufA: it 0, bufB: it 1) are in flight. ----
+    const int qd = lane & 7, r0 = lane >> 3;
+    float* stage = lds + kLdsStage + wave * kRows * kStageLd;
+    float4 hacc[2];
+    f32x4 bufA[4], bufB[4];
+    const unsigned qd16 = 16u * qd;
+    const unsigned row_step[3] = {(unsigned)a.gw[0] * (kC * 4), (unsigned)a.gw[1] * (kC * 4), (unsigned)a.gw[2] * (kC * 4)};
+
+    auto issue_row = [&](f32x4 (&tap)[4], int sv, int c, int l, int it) {
+        if constexpr (ABL == 1 || ABL == 2 || ABL == 3) return;
+        const char* base = reinterpret_cast<const char*>(a.gmap[l] + 32 * c);
+        const unsigned tbv = reinterpret_cast<const unsigned*>(lds + kLdsTapB)[((wave * kRows + r0 + 8 * it) * 2 + sv) * 3 + l];
+        const unsigned o00 = (tbv & ~3u) + qd16, dx = (tbv & 1u) ? (unsigned)(kC * 4) : 0u, dy = (tbv & 2u) ? row_step[l] : 0u;
+        tap[0] = *reinterpret_cast<const f32x4*>(base + o00);
+        tap[1] = *reinterpret_cast<const f32x4*>(base + (o00 + dx));
+        tap[2] = *reinterpret_cast<const f32x4*>(base + (o00 + dy));
+        tap[3] = *reinterpret_cast<const f32x4*>(base + (o00 + dx + dy));
+    };
+    auto blend_row = [&](const f32x4 (&tap)[4], int sv, int l, int it) {
+        if constexpr (ABL == 2 || ABL == 3) return;
+        const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 12 + 4 * l);
+        const float ww[4] = {w.x, w.y, w.z, w.w};
+        f32x2 lo2 = {hacc[it].x, hacc[it].y}, hi2 = {hacc[it].z, hacc[it].w};          // v_pk_fma_f32: two FMAs per instruction
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 gq = tap[t];
+            const f32x2 w2 = {ww[t], ww[t]};
+            lo2 = __builtin_elementwise_fma(w2, f32x2{gq[0], gq[1]}, lo2);
+            hi2 = __builtin_elementwise_fma(w2, f32x2{gq[2], gq[3]}, hi2);
+        }
+        hacc[it] = make_float4(lo2[0], lo2[1], hi2[0], hi2[1]);
+    };
+    auto affine_row = [&](int sv, int c, int it) {
+        if constexpr (ABL == 2 || ABL == 3) return;
+        const int rr = r0 + 8 * it;
+        const float4 pe = *reinterpret_cast<const float4*>(lds + kLdsPe + ((wave * kRows + rr) * 2 + sv) * 4);
+        const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 4 * (32 * c + 4 * qd));
+        const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+        hacc[it] = make_float4(fmaf(w0.z, pe.z, fmaf(w0.y, pe.y, w0.x * pe.x)) + w0.w,
+                               fmaf(w1.z, pe.z, fmaf(w1.y, pe.y, w1.x * pe.x)) + w1.w,
+                               fmaf(w2.z, pe.z, fmaf(w2.y, pe.y, w2.x * pe.x)) + w2.w,
+                               fmaf(w3.z, pe.z, fmaf(w3.y, pe.y, w3.x * pe.x)) + w3.w);
+    };
+    auto finish_row = [&](int it) {
+        if constexpr (ABL == 2 || ABL == 3) return;
+        const float4 o = hacc[it];
+        *reinterpret_cast<float4*>(stage + (r0 + 8 * it) * kStageLd + 4 * qd) =
+            make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    };
+    auto read_b = [&](half8& bhi, half8& blo) {                        // this lane's 8 channels of the wave's h tile, split
+        const float4 x0 = *reinterpret_cast<const float4*>(stage + s * kStageLd + 8 * q4);
+        const float4 x1 = *reinterpret_cast<const float4*>(stage + s * kStageLd + 8 * q4 + 4);
+        const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        split8(x, bhi, blo);
+    };
+
+    // first chunk of source 0: nothing to hide it under
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        affine_row(0, 0, it);
+#pragma unroll
+        for (int l = 2; l >= 0; --l) {
+            issue_row(bufA, 0, 0, l, it);
+            blend_row(bufA, 0, l, it);
+        }
+        finish_row(it);
+    }
+    stream_sync();                                                     // weight chunk 0 landed
+    constexpr bool kTapsLive = (ABL == 0);
+    issue_row(bufA, 0, 1, 2, 0);                                       // pipeline prologue: level 2 of chunk (0, 1), both row groups
+    issue_row(bufB, 0, 1, 2, 1);
+
+    const float up = (float)(1 << kWShift), down = 1.0f / (float)(1 << kWShift);
+    f32x4 acc[kTE];
+    half8 bhi, blo;
+    read_b(bhi, blo);
+#pragma unroll 1
+    for (int sv = 0; sv < 2; ++sv) {
+        init_bias<kTE>(acc, lds + kLdsBias + kBiasE, q4, up);
+#pragma unroll 1
+        for (int c = 0; c < kKS; ++c) {
+            // chunk being gathered: m+1 = (nsv, nc); level 2 of chunk m+2 = (n2sv, n2c) is issued at the end.  Branch-free on purpose:
+            // past the last chunk the gather harmlessly re-reads chunks of source 1.
+            const int nsv = (c + 1 < kKS) ? sv : 1;
+            const int nc = (c + 1 < kKS) ? c + 1 : 0;
+            const int n2sv = (c + 2 < kKS) ? sv : 1;
+            const int n2c = (c + 2 < kKS) ? c + 2 : c + 2 - kKS;
+            const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
+            const NextChunk nx = next_chunk(a.blob, lds, g + 1);
+            // 9 slots of (4 ds_read_b128 + 6 MFMAs of 16 cycles); between them one piece of the gather / DMA issue.  Batches (level, row
+            // group) in the order (2,0) (2,1) (1,0) (1,1) (0,0) (0,1); batch k is blended in slot {1,2,4,5,7,8}[k] and batch k+2 issued
+            // into the buffer it frees; slots 0-2 also carry the DMA pieces, slot 0 the affine start values.
+            auto piece = [&](int qs) {
+                if (qs < kPieces) stream_issue_piece<ABL>(nx, qs, lane, wave);
+                if (qs == 0) { affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); }
+                else if (qs == 1) { blend_row(bufA, nsv, 2, 0); issue_row(bufA, nsv, nc, 1, 0); }
+                else if (qs == 2) { blend_row(bufB, nsv, 2, 1); issue_row(bufB, nsv, nc, 1, 1); }
+                else if (qs == 4) { blend_row(bufA, nsv, 1, 0); issue_row(bufA, nsv, nc, 0, 0); }
+                else if (qs == 5) { blend_row(bufB, nsv, 1, 1); issue_row(bufB, nsv, nc, 0, 1); }
+                else if (qs == 7) { blend_row(bufA, nsv, 0, 0); finish_row(0); issue_row(bufA, n2sv, n2c, 2, 0); }
+                else if (qs == 8) { blend_row(bufB, nsv, 0, 1); finish_row(1); issue_row(bufB, n2sv, n2c, 2, 1); }
+            };
+#pragma unroll
+            for (int qs = 0; qs < kTE / 2; ++qs) {
+                const float* w0 = wl + (2 * qs * 2) * 256;
+                mfma_pair(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
+                piece(qs);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            read_b(bhi, blo);                                          // next chunk's B operand (own LDS tile, in-order LDS)
+            // the 8 tap loads issued in slots 7 and 8 (after the last DMA piece) stay in flight over the barrier
+            stream_sync<ABL, kTapsLive ? 8 : 0>();
+            ++g;
+        }
+        scale_acc<kTE>(acc, down);
+        if (sv == 0 && live) store_rows<kTE>(acc, a.e + i * (2 * kE), q4);
+    }
+    // ---- k1 = Wk1 [e_0 ; e_1] + bk1: first the e_1 half, chained from the accumulators; then e_1 is stored and its registers take
+    //      e_0 back from the output tensor (written by this wave one source pass ago: L2), same layout, for the other half ----
+    f32x4 k1[kTD];
+    init_bias<kTD>(k1, lds + kLdsBias + kBiasK1, q4, up);
+    chained_layer<kTE, false, ABL>(k1, acc, a.blob, lds, g, lane, wave);
+    if (live) store_rows<kTE>(acc, a.e + i * (2 * kE) + kE, q4);
+#pragma unroll
+    for (int t = 0; t < kTE; ++t) acc[t] = *reinterpret_cast<const f32x4*>(a.e + i * (2 * kE) + 16 * t + 4 * q4);
+    chained_layer<kTE, false, ABL>(k1, acc, a.blob, lds, g, lane, wave);
+    scale_acc<kTD>(k1, down);
+    f32x4 key[kTD];
+    init_bias<kTD>(key, lds + kLdsBias + kBiasK2, q4, up);
+    chained_layer<kTD, true, ABL>(key, k1, a.blob, lds, g, lane, wave);
+    scale_acc<kTD>(key, down);
+
+    // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ;  ug = Wr1[:,128:] g + br1 ---------------------
+    half8 ghi, glo;                                                    // B operand of the two layers fed by g (k = 16: folded bias)
+    {
+        const float* gl = lds + kLdsG + (wave * kRows + s) * 16 + 8 * (q4 & 1);
+        float gx8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gx8[k] = q4 < 2 ? gl[k] : (q4 == 2 && k == 0) ? 1.0f : 0.0f;
+        split8(gx8, ghi, glo);
+    }
+    f32x4 t1[kTD], qv[kTD];
+#pragma unroll
+    for (int t = 0; t < kTD; ++t) t1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stream_issue_all<ABL>(a.blob, lds, g + 1, lane, wave);
+    small_layer(t1, ghi, glo, lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane);          // q1
+    stream_sync<ABL>();
+    ++g;
+    scale_acc<kTD>(t1, down);
+    init_bias<kTD>(qv, lds + kLdsBias + kBiasQ2, q4, up);
+    chained_layer<kTD, true, ABL>(qv, t1, a.blob, lds, g, lane, wave);
+    scale_acc<kTD>(qv, down);
+    float dot = 0.0f;
+#pragma unroll
+    for (int t = 0; t < kTD; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dot = fmaf(key[t][r], qv[t][r], dot);
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    if (live) {
+        store_rows<kTD>(qv, a.qry + i * kD, q4);
+        if (q4 == 0) a.logit[i] = dot / 16.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < kTD; ++t) t1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    small_layer(t1, ghi, glo, lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane);          // ug
+    scale_acc<kTD>(t1, down);
+    if (live) store_rows<kTD>(t1, a.ug + i * kD, q4);
+}
+
+}  // namespace
+
+extern "C" int car_fused_samples_v4(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                                    const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
+                                    const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                                    float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, void* stream) {
+    CAR_REQUIRE(poses && rays && steps && gmaps && level_h && level_w && wpt && blob && bias, "car_fused_samples_v4: null input");
+    CAR_REQUIRE(e && qry && ug && logit && pt && pixel_val, "car_fused_samples_v4: null output");
+    CAR_REQUIRE(n_levels == 3 && C == kC && V == 2, "car_fused_samples_v4: built for 3 pyramid levels, C = %d, V = 2 (got %d, %d, %d)", kC, n_levels, C, V);
+    CAR_REQUIRE(b > 0 && R > 0 && P > 0 && H > 1 && W > 1, "car_fused_samples_v4: bad sizes");
+    Fused4Args a;
+    a.poses = (const CarPose*)poses; a.rays = (const CarRay*)rays; a.steps = steps;
+    for (int l = 0; l < 3; ++l) {
+        a.gmap[l] = gmaps[l]; a.gh[l] = level_h[l]; a.gw[l] = level_w[l];
+        CAR_REQUIRE(a.gmap[l] && a.gh[l] > 0 && a.gw[l] > 0 && (long)b * V * a.gh[l] * a.gw[l] * (kC * 4) < 4294967296L, "car_fused_samples_v4: bad level %d (a level's map must stay below 4 GiB)", l);
+    }
+    a.wpt = wpt; a.blob = blob; a.bias = bias;
+    a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
+    a.S = (long)b * V * R * P;
+    const char* xb = getenv("CAR_FUSED_XCD_BANDS");
+    a.xcd_bands = xb ? atoi(xb) : 1;
+    a.ray_major = 1;
+    a.e = e; a.qry = qry; a.ug = ug; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
+    const long groups = (long)b * V * car_div_up(R, kBundles * kRows) * car_div_up(P, kStepsPerGroup);
+    const char* abl_env = getenv("CAR_FUSED_ABLATE");
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    void (*kern)(const Fused4Args) = abl == 1 ? fused4_kernel<1> : abl == 2 ? fused4_kernel<2> : abl == 3 ? fused4_kernel<3> : fused4_kernel<0>;
+    hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e1 != hipSuccess) { car_set_error("car_fused_samples_v4: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(768), kLdsBytes, (hipStream_t)stream, a);
+    CAR_CHECK_LAUNCH("car_fused_samples_v4");
+    return CAR_OK;
+}

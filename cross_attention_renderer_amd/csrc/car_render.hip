@@ -306,7 +306,7 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
     const float* gm[3];
     size_t at = 0;
     for (int l = 0; l < 3; ++l) { gm[l] = in->gmaps + at; at += (size_t)b * V * d.level_h[l] * d.level_w[l] * kC; }
-    CAR_TRY(car_fused_samples_v2(in->poses, ws + w.rays, steps, gm, d.level_h, d.level_w, 3, kC, pl + p.wpt, pl + p.blob, pl + p.fbias,
+    CAR_TRY(car_fused_samples_v4(in->poses, ws + w.rays, steps, gm, d.level_h, d.level_w, 3, kC, pl + p.wpt, pl + p.blob, pl + p.fbias,
                                  b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.ug, ws + w.logit, ws + w.pt, pixel_val, stream));
     // a14 + a16: attention round 1, depth read-out, argmax
     CAR_TRY(car_attend(ws + w.logit, nullptr, kD, ws + w.e, kC, b, V, R, P, nullptr, 0.0f, at_wt, ws + w.ebar, kC, 1, ws + w.pt, in->poses,

@@ -220,9 +220,10 @@ class RenderEngine:
         # 576->288 layer of the fused kernel on the f16 matrix pipe with fp16 hi/lo operand splits (3 products per term,
         # fp32-class accuracy) instead of the fp32 pipe
         self.split_fp16 = True
+        # 4: csrc/car_fused4.hip (as 2 with 12 waves x 16 samples, three waves per SIMD, same packed weights);
         # 2: csrc/car_fused2.hip (8 waves x 16 samples, 16x16x32 f16 tiles, two waves per SIMD; always split-fp16);
         # 1: csrc/car_fused.hip (4 waves x 32 samples, one wave per SIMD; fp32 or split-fp16 per ``split_fp16``)
-        self.fused_version = 2
+        self.fused_version = 4
         self.fuse_round2 = True        # round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
         self._round2_key = None
         self._round2 = None
@@ -524,7 +525,8 @@ class RenderEngine:
             m.query_encode_latent_2.weight, m.query_encode_latent_2.bias, m.query_embed.weight, m.query_embed.bias,
             m.query_embed_2.weight, m.query_embed_2.bias, m.query_repeat_embed.weight, m.query_repeat_embed.bias,
             m.key_map.weight, m.key_map.bias, m.key_map_2.weight, m.key_map_2.bias)) + (str(dev), self.split_fp16, self.fused_version)
-        v2 = self.fused_version == 2
+        v4 = self.fused_version == 4
+        v2 = self.fused_version == 2 or v4
         if key != self._fused_key:
             self._fused = pack_fused2_weights(m, dev) if v2 else pack_fused_weights(m, dev, self.split_fp16)
             assert self._fused[0].numel() == (lib.car_fused2_blob_floats() if v2 else lib.car_fused_blob_floats())
@@ -546,9 +548,9 @@ class RenderEngine:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         if v2:
-            _lib.check(lib.car_fused_samples_v2(_ptr(poses), _ptr(rays), _ptr(steps), ptrs, hs, ws, L, 576, _ptr(wpt), _ptr(blob),
+            _lib.check((lib.car_fused_samples_v4 if v4 else lib.car_fused_samples_v2)(_ptr(poses), _ptr(rays), _ptr(steps), ptrs, hs, ws, L, 576, _ptr(wpt), _ptr(blob),
                                                 _ptr(bias), b, V, R, P, H, W, _ptr(e), _ptr(q), _ptr(ug), _ptr(logit), _ptr(pt),
-                                                _ptr(pixel_val), _stream()), "car_fused_samples_v2")
+                                                _ptr(pixel_val), _stream()), "car_fused_samples_v4" if v4 else "car_fused_samples_v2")
         else:
             _lib.check(lib.car_fused_samples(_ptr(poses), _ptr(rays), _ptr(steps), ptrs, hs, ws, L, 576, _ptr(wpt), _ptr(blob),
                                              _ptr(bias), b, V, R, P, H, W, _ptr(e), _ptr(q), _ptr(ug), _ptr(logit), _ptr(pt),
@@ -559,7 +561,7 @@ class RenderEngine:
             # 16x128 (ug); the gather FMAs and the geometry are not counted
             macs = 2 * 576 * 288 + 576 * 128 + 128 * 128 + 16 * 128 + 128 * 128 + 16 * 128
             pipe = "f16 matrix pipe, fp16 hi/lo split x3" if (self.split_fp16 or v2) else "fp32 matrix pipe"
-            kname = "fused2_kernel" if v2 else "fused_sample_kernel"
+            kname = "fused4_kernel" if v4 else "fused2_kernel" if v2 else "fused_sample_kernel"
             self.timing.setdefault("fused_samples", []).append(
                 (ev[0], ev[1], 2.0 * S * macs, f"{kname} on {S} samples (e, key, qry, ug, logits; {pipe})"))
         return self._finish(inp, z, b, V, R, P, 576, m.latent_dim, e, None, q, logit, ug, pt, pixel_val, poses, rays, coords9,

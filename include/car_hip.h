@@ -140,6 +140,13 @@ int car_fused_samples_v2(const float* poses, const float* rays, const float* ste
                          const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
                          float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, void* stream);
 
+/* Same stage, same blob and bias table as car_fused_samples_v2, three waves per SIMD (csrc/car_fused4.hip): 12 waves x 16 samples
+ * per workgroup (48 consecutive rays x 4 consecutive steps), at most 168 registers per wave. */
+int car_fused_samples_v4(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                         const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
+                         const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                         float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, void* stream);
+
 /* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
  *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).
  * Weights are re-laid out once into the MFMA operand order by car_linear_pack (bias folded in as column K). */

@@ -34,7 +34,7 @@ def to_device(inp, device):
 
 
 def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_poses=False, project_maps=True,
-             fuse_samples=True, split_fp16=True, fuse_round2=True, fused_version=2):
+             fuse_samples=True, split_fp16=True, fuse_round2=True, fused_version=None):
     """Returns (config, fixture, oracle output dict (CPU), HIP output dict (tensors moved to CPU)).
 
     fixture_poses=True: both sides use the relative-pose matrices stored in the fixture (the ones the reference
@@ -52,7 +52,8 @@ def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_pos
     m._engine.fuse_samples = fuse_samples
     m._engine.split_fp16 = split_fp16
     m._engine.fuse_round2 = fuse_round2
-    m._engine.fused_version = fused_version
+    if fused_version is not None:
+        m._engine.fused_version = fused_version
     with torch.no_grad():
         out = m(to_device(inp, device), z=[t.to(device) for t in z], debug=debug)
     torch.cuda.synchronize()

@@ -180,7 +180,7 @@ def test_literal_gather_gemm_pipeline_matches_oracle(name):
     assert err_stats(out["stages"]["interp_val"], out2["stages"]["interp_val"])["max"] < 5e-5
 
 
-@pytest.mark.parametrize("version", [2, 1])
+@pytest.mark.parametrize("version", [4, 2, 1])
 @pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c3", "t2_c5"])
 def test_fused_sample_kernel_matches_stage_pipeline(name, version):
     """A/B of csrc/car_fused2.hip / car_fused.hip (geometry + encode + e + key/query MLPs + logits in one kernel, everything
@@ -207,6 +207,19 @@ def test_split_fp16_layer_is_fp32_class(name):
     assert rel_err(a["rgb"], b_["rgb"]) < 1e-5
     _check_outputs(a, lambda k: ora[k], "split-fp16 vs oracle")
     _check_outputs(b_, lambda k: ora[k], "fp32 pipe vs oracle")
+
+
+@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c3", "t2_c4"])
+def test_fused_v4_equals_v2(name):
+    """Three waves per SIMD (csrc/car_fused4.hip) against two (car_fused2.hip): same arithmetic per sample; only the order in which
+    the very first chunk adds its pyramid levels and the order of the key layer's two halves (e_1 first) differ, i.e. rounding."""
+    c, fx, ora, a = run_case(name, fused_version=4)
+    _, _, _, b_ = run_case(name, fused_version=2)
+    assert torch.equal(a["stages"]["pt"], b_["stages"]["pt"])
+    assert err_stats(a["stages"]["interp_val"], b_["stages"]["interp_val"])["max"] < 2e-6
+    assert rel_err(a["at_wt"], b_["at_wt"]) < 1e-5
+    assert rel_err(a["rgb"], b_["rgb"]) < 1e-5
+    _check_outputs(a, lambda k: ora[k], "fused v4 vs oracle")
 
 
 @pytest.mark.parametrize("name", ["t1_c1", "t2_c2", "t2_c4"])

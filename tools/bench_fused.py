@@ -17,7 +17,7 @@ def main():
     dev = torch.device("cuda:0")
     model = bench.build_model(dev)
     model._engine = RenderEngine(model)
-    model._engine.fused_version = int(os.environ.get("CAR_FUSED_VERSION", "2"))     # 1: car_fused.hip, 2: car_fused2.hip
+    model._engine.fused_version = int(os.environ.get("CAR_FUSED_VERSION", "2"))     # 1: car_fused.hip, 2: car_fused2.hip, 4: car_fused4.hip
     inp, z = bench.make_frame(0.5, dev)
     uv = inp["query"]["uv"][:, :, 96 * 256: 96 * 256 + 8192].contiguous()
     chunk = {"context": inp["context"], "query": dict(inp["query"], uv=uv)}
