@@ -1,4 +1,4 @@
-"""Times csrc/car_fused2.hip (CAR_FUSED_VERSION=1: car_fused.hip) alone (one 8192-ray chunk at 256x256x64) for each CAR_FUSED_ABLATE variant.  Timing only:
+"""Times the fused per-sample kernel (the engine's default csrc/car_fused4.hip; CAR_FUSED_VERSION=2 / 1: car_fused2.hip / car_fused.hip) alone (one 8192-ray chunk at 256x256x64) for each CAR_FUSED_ABLATE variant.  Timing only:
 variants > 0 compute wrong results by construction.  Usage (GPU box): python tools/bench_fused.py [variants...]"""
 import os
 import sys
@@ -17,7 +17,8 @@ def main():
     dev = torch.device("cuda:0")
     model = bench.build_model(dev)
     model._engine = RenderEngine(model)
-    model._engine.fused_version = int(os.environ.get("CAR_FUSED_VERSION", "2"))     # 1: car_fused.hip, 2: car_fused2.hip, 4: car_fused4.hip
+    if "CAR_FUSED_VERSION" in os.environ:
+        model._engine.fused_version = int(os.environ["CAR_FUSED_VERSION"])     # 1: car_fused.hip, 2: car_fused2.hip, 4: car_fused4.hip
     inp, z = bench.make_frame(0.5, dev)
     uv = inp["query"]["uv"][:, :, 96 * 256: 96 * 256 + 8192].contiguous()
     chunk = {"context": inp["context"], "query": dict(inp["query"], uv=uv)}
