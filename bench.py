@@ -207,6 +207,12 @@ def main():
             "config": {"workload": f"256x256 query frame, 64 samples/view, 2 context views (config 2), {-(-65536 // args.chunk_rays)} forward calls x {args.chunk_rays} rays",
                        "rays_per_step_per_gpu": R, "parallelism": f"ray-sharded frames x{world}, RCCL all-gather of tiles"},
             "roofline": roof,
+            # SURVEY.md §8(d) prices the path with the REFERENCE's arithmetic: V*P*2 617 728 + 791 808 FLOP per ray (335.9 MFLOP at
+            # P = 64) against the fp32 matrix peak.  This implementation executes about a third of that (first point-MLP layer per
+            # texel, value projection after the attention average) and runs it on the f16 pipe, hence a figure above 1.
+            "reference_flops": {"flop_per_ray": V * P * 2617728 + 791808,
+                                "equivalent_tflops": rays_total / elapsed * (V * P * 2617728 + 791808) / 1e12,
+                                "frac_of_fp32_mfma_peak": rays_total / elapsed * (V * P * 2617728 + 791808) / FP32_MFMA_PEAK / world},
             # the CPU leg runs on rank 0 of a single-GPU job only (it is a per-host figure and would stall the other ranks)
             "cpu_baseline": cpu_baseline(args.cpu_rays) if (args.cpu_rays > 0 and world == 1) else None,
         }

@@ -49,7 +49,9 @@ def test_entry_points_parse_reference_flags():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("script,extra", [("render_realestate10k_traj.py", ["--n_frames", "2"]),
-                                          ("eval_realestate10k.py", ["--batch_size", "1"])])
+                                          ("render_unposed_traj.py", ["--n_frames", "2"]),
+                                          ("eval_realestate10k.py", ["--batch_size", "1"]),
+                                          ("eval_acid.py", ["--batch_size", "1"])])
 def test_entry_points_run_on_gpu(script, extra, tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, "experiment_scripts", script), "--experiment_name", "t", "--views", "2",
            "--synthetic", "--img_sidelength", "64", "--out_dir", str(tmp_path), "--logging_root", str(tmp_path)] + extra
