@@ -86,11 +86,10 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps,
                 r.y = ((tp[u][0].y * wv[u][0] + tp[u][1].y * wv[u][1]) + tp[u][2].y * wv[u][2]) + tp[u][3].y * wv[u][3];
                 r.z = ((tp[u][0].z * wv[u][0] + tp[u][1].z * wv[u][1]) + tp[u][2].z * wv[u][2]) + tp[u][3].z * wv[u][3];
                 r.w = ((tp[u][0].w * wv[u][0] + tp[u][1].w * wv[u][1]) + tp[u][2].w * wv[u][2]) + tp[u][3].w * wv[u][3];
-                // streaming store: the gathered rows are written once and must not evict the feature maps from L2
-                __builtin_nontemporal_store(r.x, out + orow[u] * ld_out + col_out + 4 * oq[u] + 0);
-                __builtin_nontemporal_store(r.y, out + orow[u] * ld_out + col_out + 4 * oq[u] + 1);
-                __builtin_nontemporal_store(r.z, out + orow[u] * ld_out + col_out + 4 * oq[u] + 2);
-                __builtin_nontemporal_store(r.w, out + orow[u] * ld_out + col_out + 4 * oq[u] + 3);
+                // streaming store (one 16-byte instruction): the gathered rows are written once and must not evict the feature maps from L2
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 rv = {r.x, r.y, r.z, r.w};
+                __builtin_nontemporal_store(rv, reinterpret_cast<f32x4*>(out + orow[u] * ld_out + col_out + 4 * oq[u]));
             }
         }
         __syncthreads();

@@ -21,6 +21,11 @@ def main():
         model._engine.fused_version = int(os.environ["CAR_FUSED_VERSION"])     # 1: car_fused.hip, 2: car_fused2.hip, 4: car_fused4.hip
     inp, z = bench.make_frame(0.5, dev)
     uv = inp["query"]["uv"][:, :, 96 * 256: 96 * 256 + 8192].contiguous()
+    if "CAR_BENCH_TILE" in os.environ:                 # experiment: rays in 2-D tiles of (rows x cols) pixels instead of row strips
+        th, tw = [int(x) for x in os.environ["CAR_BENCH_TILE"].split("x")]
+        g = uv.view(1, 1, 32, 256, 2)                  # 32 image rows x 256 columns
+        g = g.view(1, 1, 32 // th, th, 256 // tw, tw, 2).permute(0, 1, 2, 4, 3, 5, 6).reshape(1, 1, 8192, 2)
+        uv = g.contiguous()
     chunk = {"context": inp["context"], "query": dict(inp["query"], uv=uv)}
     variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 4]
     with torch.no_grad():
