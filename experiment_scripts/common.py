@@ -23,7 +23,8 @@ def parser(description: str) -> argparse.ArgumentParser:
     p = argparse.ArgumentParser(description=description)
     p.add_argument("--experiment_name", type=str, required=True)
     p.add_argument("--logging_root", type=str, default="logs")
-    p.add_argument("--data_root", type=str, default=None)
+    p.add_argument("--data_root", type=str, default=None, help="directory of scene directories (one *.npz of frames each)")
+    p.add_argument("--pose_root", type=str, default=None, help="directory of <scene>.txt camera files (RealEstate10K format)")
     p.add_argument("--checkpoint_path", type=str, default=None)
     p.add_argument("--batch_size", type=int, default=1)
     p.add_argument("--gpus", type=int, default=1)

@@ -1,6 +1,7 @@
 """Trajectory rendering entry point (mirrors reference experiment_scripts/render_realestate10k_traj.py).
 
     python experiment_scripts/render_realestate10k_traj.py --experiment_name demo --views 2 --synthetic [--gpus N]
+    python experiment_scripts/render_realestate10k_traj.py --experiment_name demo --views 2 --data_root SCENES --pose_root CAMERAS
 
 Per scene: ``z = model.get_z(...)`` once, then one chunked ``model(model_input, z=z)`` pass per trajectory frame
 (render_realestate10k_traj.py:97, 118-145); frames are written as PNG + NPY (no mp4 writer in this image)."""
@@ -12,31 +13,64 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import common  # noqa: E402
 
 
+def _scene_inputs(opt, H, dev):
+    """(name, model_input with every query frame, z) per scene: real cameras from --data_root / --pose_root
+    (cross_attention_renderer_amd/dataio.py) or one seeded synthetic pair."""
+    import torch
+    from cross_attention_renderer_amd import dataio, harness, synthetic
+    if not opt.data_root or opt.synthetic:
+        inp, z = harness.synthetic_pair(H, opt.views)
+        frames = harness.trajectory(harness.to_device(inp, dev), opt.n_frames)
+        yield "synthetic", frames, [t.to(dev) for t in z]
+        return
+    if not opt.pose_root:
+        raise SystemExit("--data_root needs --pose_root (directory of <scene>.txt camera files)")
+    uv = synthetic.pixel_grid(H, H)
+    for scene in sorted(p for p in os.listdir(opt.data_root) if os.path.isdir(os.path.join(opt.data_root, p))):
+        full = dataio.get_camera_pose(os.path.join(opt.data_root, scene), opt.pose_root, uv, views=opt.views)
+        scale = H / 256.0                                  # the reader's intrinsics are pixels of the 256 x 256 crop
+        for part in ("query", "context"):
+            full[part]["intrinsics"] = full[part]["intrinsics"].clone()
+            full[part]["intrinsics"][..., :2, :3] *= scale
+        full = harness.to_device(full, dev)
+        nq = min(opt.n_frames, full["query"]["cam2world"].shape[1])
+        frames = [{"context": full["context"],
+                   "query": {"cam2world": full["query"]["cam2world"][:, i:i + 1], "intrinsics": full["query"]["intrinsics"][:, i:i + 1],
+                             "uv": full["query"]["uv"][:, i:i + 1].contiguous(), "rgb": full["query"]["rgb"][:, i:i + 1]}}
+                  for i in range(nq)]
+        # The DPT encoder (get_z) is not part of this path (SURVEY.md §8f row 2): without a user-supplied model.encoder the feature
+        # pyramid is the seeded synthetic one, i.e. geometry and timing are real, colours are not.
+        z = [t.to(dev) for t in synthetic.feature_maps(1, opt.views, H, seed=1)]
+        yield scene, frames, z
+
+
 def render(rank, opt):
     import torch
     from cross_attention_renderer_amd import harness
     dev = common.init_rank(rank, opt)
     model = common.build_model(opt, dev)
     H = opt.img_sidelength
-    if opt.data_root and not opt.synthetic:
-        raise SystemExit("dataset readers are not built yet (SURVEY.md §8f row 3); use --synthetic")
-    inp, z = harness.synthetic_pair(H, opt.views)
-    inp, z = harness.to_device(inp, dev), [t.to(dev) for t in z]
-    out_dir = opt.out_dir or os.path.join(opt.logging_root, opt.experiment_name, "renders")
-    if rank == 0:
-        os.makedirs(out_dir, exist_ok=True)
-    t0 = time.time()
-    for i, frame in enumerate(harness.trajectory(inp, opt.n_frames)):
-        tile = harness.render_frame(model, frame, z, rank=rank, world=opt.gpus)
+    out_root = opt.out_dir or os.path.join(opt.logging_root, opt.experiment_name, "renders")
+    t0, n_done = time.time(), 0
+    for scene, frames, z in _scene_inputs(opt, H, dev):
+        out_dir = out_root if scene == "synthetic" else os.path.join(out_root, scene)
         if rank == 0:
-            rgb = tile[0, :, :3].reshape(H, H, 3)
-            harness.write_png(os.path.join(out_dir, f"frame_{i:04d}.png"), rgb)
-            torch.save({"rgb": rgb.cpu(), "depth": tile[0, :, 3].reshape(H, H).cpu(), "valid": tile[0, :, 4].reshape(H, H).cpu()},
-                       os.path.join(out_dir, f"frame_{i:04d}.pt"))
+            os.makedirs(out_dir, exist_ok=True)
+        for i, frame in enumerate(frames):
+            tile = harness.render_frame(model, frame, z, rank=rank, world=opt.gpus)
+            n_done += 1
+            if rank == 0:
+                rgb = tile[0, :, :3].reshape(H, H, 3)
+                harness.write_png(os.path.join(out_dir, f"frame_{i:04d}.png"), rgb)
+                torch.save({"rgb": rgb.cpu(), "depth": tile[0, :, 3].reshape(H, H).cpu(), "valid": tile[0, :, 4].reshape(H, H).cpu()},
+                           os.path.join(out_dir, f"frame_{i:04d}.pt"))
+                gt = frame["query"].get("rgb")
+                if gt is not None and tuple(gt.shape[2:4]) == (H, H):
+                    print(f"{scene} frame {i}: PSNR {harness.psnr((rgb.clamp(-1, 1) + 1) / 2, (gt[0, 0].clamp(-1, 1) + 1) / 2):.2f} dB")
     torch.cuda.synchronize()
     if rank == 0:
         dt = time.time() - t0
-        print(f"rendered {opt.n_frames} frames of {H}x{H} in {dt:.2f} s ({opt.n_frames * H * H / dt:,.0f} rays/s) -> {out_dir}")
+        print(f"rendered {n_done} frames of {H}x{H} in {dt:.2f} s ({n_done * H * H / dt:,.0f} rays/s) -> {out_root}")
 
 
 if __name__ == "__main__":

@@ -63,3 +63,18 @@ def test_entry_points_run_on_gpu(script, extra, tmp_path):
     else:
         psnr = float(out.stdout.split("psnr vs unchunked render")[1].split("dB")[0])
         assert psnr > 100.0, out.stdout          # chunking must not change the image
+
+
+@pytest.mark.gpu
+def test_render_script_reads_a_scene_directory(tmp_path):
+    """--data_root / --pose_root: cameras of every frame come from the RealEstate10K reader (tests/golden/dataio_scene)."""
+    scene_root = os.path.join(ROOT, "tests", "golden", "dataio_scene")
+    import shutil
+    data_root = tmp_path / "scenes"
+    shutil.copytree(os.path.join(scene_root, "scene0"), data_root / "scene0")
+    cmd = [sys.executable, os.path.join(ROOT, "experiment_scripts", "render_realestate10k_traj.py"), "--experiment_name", "t", "--views", "2",
+           "--data_root", str(data_root), "--pose_root", os.path.join(scene_root, "poses"), "--img_sidelength", "64", "--n_frames", "2",
+           "--out_dir", str(tmp_path / "out")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (tmp_path / "out" / "scene0" / "frame_0001.png").exists() and "rendered 2 frames" in out.stdout
