@@ -1,0 +1,66 @@
+"""Whole-frame parity run on a GPU box: renders the bench frame (256x256, 64 samples, 2 views, 65 536 rays) with the HIP path and
+checks EVERY ray against the CPU oracle (the restatement pinned to the reference; ~2 minutes on the box's host cores).
+Prints a markdown table; `python tools/validate_frame.py [alpha ...] > profiles/<name>.md`."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from oracle import car_oracle as O  # noqa: E402
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    e = (a - b).abs() / b.abs().clamp_min(1.0)
+    return e.max().item(), (e > 1e-4).double().mean().item()
+
+
+def main():
+    import __graft_entry__ as ge
+    ge.build()
+    from cross_attention_renderer_amd.engine import RenderEngine
+    alphas = [float(a) for a in sys.argv[1:]] or [0.5]
+    dev = torch.device("cuda:0")
+    model = bench.build_model(dev)
+    model._engine = RenderEngine(model)
+    cpu_model = bench.build_model(torch.device("cpu"))
+    sd = dict(cpu_model.state_dict())
+    print("# Whole-frame parity: HIP path vs CPU oracle, every ray of the bench frame\n")
+    print(f"device {torch.cuda.get_device_name(0)}, host threads {torch.get_num_threads()}, tolerance |a-b| <= 1e-4 max(1,|b|)\n")
+    print("| query pose (alpha) | rays | rgb max err | depth max err | at_wt max err | elements > 1e-4 | valid_mask equal | at_wt_max equal | oracle s | HIP ms |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
+    for alpha in alphas:
+        inp, z = bench.make_frame(alpha, None)
+        cfg = O.RenderConfig(n_view=bench.V, npoints=bench.P, H=bench.H, W=bench.H)
+        t0 = time.time()
+        with torch.no_grad():
+            parts = []
+            for c0 in range(0, bench.H * bench.H, 8192):
+                sub = {"context": inp["context"], "query": dict(inp["query"], uv=inp["query"]["uv"][:, :, c0:c0 + 8192].contiguous())}
+                parts.append(O.render_forward(sd, sub, z, cfg))
+        t_or = time.time() - t0
+        ora = {k: torch.cat([p[k] for p in parts], dim=(2 if k == "rgb" else 1)) for k in ("rgb", "depth_ray", "at_wt", "valid_mask", "at_wt_max")}
+        dinp = {k: {kk: vv.to(dev) for kk, vv in v.items()} for k, v in inp.items()}
+        dz = [t.to(dev) for t in z]
+        with torch.no_grad():
+            model(dinp, z=dz)
+            torch.cuda.synchronize()
+            t1 = time.time()
+            out = model(dinp, z=dz)
+            torch.cuda.synchronize()
+        t_hip = (time.time() - t1) * 1e3
+        e_rgb, f_rgb = rel(out["rgb"], ora["rgb"])
+        e_d, f_d = rel(out["depth_ray"], ora["depth_ray"])
+        e_w, f_w = rel(out["at_wt"], ora["at_wt"])
+        same_valid = bool(torch.equal(out["valid_mask"].cpu(), ora["valid_mask"]))
+        same_arg = (out["at_wt_max"].cpu() == ora["at_wt_max"]).double().mean().item()
+        print(f"| {alpha} | {bench.H * bench.H} | {e_rgb:.2e} | {e_d:.2e} | {e_w:.2e} | {max(f_rgb, f_d, f_w):.1e} | {same_valid} | {same_arg:.5f} | {t_or:.0f} | {t_hip:.1f} |")
+        sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()
