@@ -115,7 +115,7 @@ __device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, 
 // LDS-DMA in inline asm, see car_linear.hip.  Must only run after the barrier that retired the buffer's previous chunk.
 template <int ABL = 0>
 __device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, int lane, int wave) {
-    if constexpr (ABL == 3) return;
+    if constexpr (ABL == 3 || ABL == 5) return;
     int kb = kWaves * p + wave;
     kb = kb < n.nkb ? kb : kb - n.nkb;
     kb = kb < n.nkb ? kb : kb - n.nkb;
@@ -137,7 +137,7 @@ __device__ __forceinline__ void stream_issue_all(const float* __restrict__ blob,
 // order, so "at most KEEP outstanding" still means every DMA piece has landed).
 template <int ABL = 0, int KEEP = 0>
 __device__ __forceinline__ void stream_sync() {
-    if constexpr (ABL == 3) return;
+    if constexpr (ABL == 3 || ABL == 5) return;
     if constexpr (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -261,7 +261,8 @@ __device__ __forceinline__ void small_layer(f32x4 (&acc)[kTD], const half8& ghi,
     }
 }
 
-// ABL > 0: timing-only ablations (wrong results): 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers
+// ABL > 0: timing-only ablations (wrong results): 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers,
+// 5 the gather alone (no e-path MFMAs, no weight DMA, no barriers)
 template <int ABL>
 __global__ void __launch_bounds__(768) fused4_kernel(const Fused4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -403,7 +404,7 @@ __global__ void __launch_bounds__(768) fused4_kernel(const Fused4Args a) {
         finish_row(it);
     }
     stream_sync();                                                     // weight chunk 0 landed
-    constexpr bool kTapsLive = (ABL == 0);
+    constexpr bool kTapsLive = (ABL == 0 || ABL == 5);
     issue_row(bufA, 0, 1, 2, 0);                                       // pipeline prologue: level 2 of chunk (0, 1), both row groups
     issue_row(bufB, 0, 1, 2, 1);
 
@@ -440,7 +441,7 @@ __global__ void __launch_bounds__(768) fused4_kernel(const Fused4Args a) {
 #pragma unroll
             for (int qs = 0; qs < kTE / 2; ++qs) {
                 const float* w0 = wl + (2 * qs * 2) * 256;
-                mfma_pair(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
+                if constexpr (ABL != 5) mfma_pair(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
                 piece(qs);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -531,7 +532,7 @@ extern "C" int car_fused_samples_v4(const float* poses, const float* rays, const
     const long groups = (long)b * V * car_div_up(R, kBundles * kRows) * car_div_up(P, kStepsPerGroup);
     const char* abl_env = getenv("CAR_FUSED_ABLATE");
     const int abl = abl_env ? atoi(abl_env) : 0;
-    void (*kern)(const Fused4Args) = abl == 1 ? fused4_kernel<1> : abl == 2 ? fused4_kernel<2> : abl == 3 ? fused4_kernel<3> : fused4_kernel<0>;
+    void (*kern)(const Fused4Args) = abl == 1 ? fused4_kernel<1> : abl == 2 ? fused4_kernel<2> : abl == 3 ? fused4_kernel<3> : abl == 5 ? fused4_kernel<5> : fused4_kernel<0>;
     hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e1 != hipSuccess) { car_set_error("car_fused_samples_v4: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
     (void)hipGetLastError();
