@@ -16,39 +16,13 @@
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) void lds_void;
-
-constexpr int kWShift = 8;
-
-constexpr int kC = 576;            // feature channels = width of h
-constexpr int kE = 288;            // per-source width of e
-constexpr int kD = 128;            // hidden width of the key / query MLPs
-constexpr int kKS = kC / 32;       // 18 K steps (= weight chunks) of the 576 -> 288 layer
-constexpr int kTE = kE / 16;       // 18 output tiles of 16 channels
-constexpr int kTD = kD / 16;       // 8 output tiles
-constexpr int kTile = 512;         // packed floats per (K step, tile): [hi|lo][64 lanes][8 halves] = 2 KB
-constexpr int kStageLd = 36;       // row stride of the wave-private h tile (floats)
 constexpr int kWaves = 12, kRows = 16, kGroup = kWaves * kRows;      // 192 samples per workgroup
 constexpr int kStepsPerGroup = 4, kBundles = kWaves / kStepsPerGroup;  // 3 bundles of 16 rays x 4 steps
 
-// ---- packed-weight blob: offsets in tiles, layer by layer, [K step][tile] inside a layer ---------------------------
-constexpr int kOffW2 = 0;                          // 18 steps x 18 tiles, standard K mapping
-constexpr int kOffQ1 = kOffW2 + kKS * kTE;         // 1 x 8, standard, bias folded at k = 16
-constexpr int kOffQ2 = kOffQ1 + kTD;               // 4 x 8, chained
-constexpr int kOffUG = kOffQ2 + 4 * kTD;           // 1 x 8, standard, bias folded
-constexpr int kOffK1 = kOffUG + kTD;               // 18 x 8, chained over [e_0 ; e_1] (9 steps per source)
-constexpr int kOffK2 = kOffK1 + 18 * kTD;          // 4 x 8, chained
-constexpr int kBlobTiles = kOffK2 + 4 * kTD;
-constexpr int kNumChunks = 2 * kKS + 2 * 5 + 2 + 1 + 2 + 1;           // 52 weight chunks per pass, same order as car_fused.hip
-constexpr int kChunkTiles = kTE;                   // largest chunk: 18 tiles = 36 KB
 constexpr int kPieces = 3;                         // LDS-DMA pieces per chunk: 12 waves x 1 KB each
 
-constexpr int kBiasE = 0, kBiasQ2 = kE, kBiasK1 = kE + kD, kBiasK2 = kE + 2 * kD, kBiasFloats = kE + 3 * kD;
+#include "car_fused16.h"
 
-// ---- dynamic LDS carve-up (floats) --------------------------------------------------------------------------------
-constexpr int kLdsW = 0;                                        // [2][18][512]           weight chunks          72 KB
 constexpr int kLdsStage = kLdsW + 2 * kChunkTiles * kTile;      // [12][16][36]           h tiles, wave private     27 KB
 constexpr int kLdsTapB = kLdsStage + kGroup * kStageLd;         // [192][2][3] uint       byte offset of the nw texel | 1: x1 != x0 | 2: y1 != y0   4.5 KB
 constexpr int kLdsTapW = kLdsTapB + kGroup * 6;                 // [192][2][3][4]         tap weights (nw, ne, sw, se)   18 KB
@@ -99,166 +73,6 @@ __device__ __forceinline__ int chunk_tiles(int g) {
     if (g < kG_K1b) return kTE;
     if (g == kG_K1a - 1 || g == kG_K2 - 1 || g == kG_Q1 || g == kG_UG) return kTD;       // odd last K1 step, Q1, UG
     return 2 * kTD;
-}
-
-// Descriptor of the chunk to prefetch, resolved once per chunk with scalar branches so the per-piece issue is straight-line
-struct NextChunk { const float* src; float* dst; int nkb; };
-__device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, float* lds, int g) {
-    const int ge = g < kNumChunks ? g : kNumChunks - 1;            // past the end: re-copy the last chunk onto itself
-    NextChunk n;
-    n.src = blob + (long)chunk_tile_offset(ge) * kTile;
-    n.dst = lds + kLdsW + (ge & 1) * kChunkTiles * kTile;
-    n.nkb = 2 * chunk_tiles(ge);
-    return n;
-}
-// piece p of the next chunk: wave w copies KB number 12 p + w (wrapped into the chunk: re-copying identical bytes is harmless).
-// LDS-DMA in inline asm, see car_linear.hip.  Must only run after the barrier that retired the buffer's previous chunk.
-template <int ABL = 0>
-__device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, int lane, int wave) {
-    if constexpr (ABL == 3 || ABL == 5) return;
-    int kb = kWaves * p + wave;
-    kb = kb < n.nkb ? kb : kb - n.nkb;
-    kb = kb < n.nkb ? kb : kb - n.nkb;
-    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(n.dst + kb * 256));
-    const float* gsrc = n.src + kb * 256 + 4 * lane;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int ABL = 0>
-__device__ __forceinline__ void stream_issue_all(const float* __restrict__ blob, float* lds, int g, int lane, int wave) {
-    if (g >= kNumChunks) return;
-    const NextChunk n = next_chunk(blob, lds, g);
-#pragma unroll
-    for (int p = 0; p < kPieces; ++p) stream_issue_piece<ABL>(n, p, lane, wave);
-}
-// end of a chunk: the DMA of the next chunk has landed and every wave is done reading the current one.  KEEP = number of
-// vector loads this wave issued AFTER its last DMA piece and wants to leave in flight across the barrier (loads return in
-// order, so "at most KEEP outstanding" still means every DMA piece has landed).
-template <int ABL = 0, int KEEP = 0>
-__device__ __forceinline__ void stream_sync() {
-    if constexpr (ABL == 3 || ABL == 5) return;
-    if constexpr (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
-typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// x = hi + lo in fp16 halves.  The halves are rounded toward zero (v_cvt_pkrtz_f16_f32 converts two values per instruction):
-// x - hi is exact in fp32 and |x - hi - lo| < 2^-20 |x|, still fp32-class after the three-product MFMA.
-__device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        const fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(x[e], x[e + 1]);
-        const fp16x2 l2 = __builtin_amdgcn_cvt_pkrtz(x[e] - (float)h2[0], x[e + 1] - (float)h2[1]);
-        hi[e] = (_Float16)h2[0]; hi[e + 1] = (_Float16)h2[1];
-        lo[e] = (_Float16)l2[0]; lo[e + 1] = (_Float16)l2[1];
-    }
-}
-
-// two output tiles x three split products, interleaved so consecutive MFMAs never share an accumulator
-__device__ __forceinline__ void mfma_pair(f32x4& c0, f32x4& c1, const float* w0, const float* w1, const half8& bhi, const half8& blo) {
-    const half8 ah0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0));
-    const half8 ah1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1));
-    const half8 al0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0 + 256));
-    const half8 al1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1 + 256));
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhi, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhi, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blo, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blo, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bhi, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bhi, c1, 0, 0, 0);
-}
-
-// the same with the A operands (two tiles, hi and lo) read one slot ahead: a ds_read_b128 issued right before its MFMAs
-// exposes the LDS latency (~100+ cycles) in every slot, and the scheduling barriers keep hipcc from hoisting it
-struct AHi { float4 h0, h1; };
-__device__ __forceinline__ AHi load_ahi(const float* w0) {
-    AHi a;
-    a.h0 = *reinterpret_cast<const float4*>(w0);
-    a.h1 = *reinterpret_cast<const float4*>(w0 + 512);
-    return a;
-}
-// the hi halves come from the previous slot; the lo halves are read now and first used by the fifth MFMA (64 cycles later)
-__device__ __forceinline__ void mfma_ahead(f32x4& c0, f32x4& c1, const AHi& a, const float* w0, const half8& bhi, const half8& blo) {
-    const float4 l0 = *reinterpret_cast<const float4*>(w0 + 256), l1 = *reinterpret_cast<const float4*>(w0 + 512 + 256);
-    const half8 ah0 = __builtin_bit_cast(half8, a.h0), ah1 = __builtin_bit_cast(half8, a.h1);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhi, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhi, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blo, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blo, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, l0), bhi, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, l1), bhi, c1, 0, 0, 0);
-}
-
-// accumulators start at bias * scale: lane (s, q) register r of tile t holds channel 16 t + 4 q + r
-template <int NT>
-__device__ __forceinline__ void init_bias(f32x4 (&acc)[NT], const float* lbias, int q, float scale) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float4 b4 = *reinterpret_cast<const float4*>(lbias + 16 * t + 4 * q);
-        acc[t][0] = b4.x * scale; acc[t][1] = b4.y * scale; acc[t][2] = b4.z * scale; acc[t][3] = b4.w * scale;
-    }
-}
-template <int NT>
-__device__ __forceinline__ void scale_acc(f32x4 (&acc)[NT], float f) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] *= f;
-}
-template <int NT>
-__device__ __forceinline__ void store_rows(const f32x4 (&acc)[NT], float* row, int q) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        *reinterpret_cast<float4*>(row + 16 * t + 4 * q) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-}
-
-// one chained layer with 128 outputs over NSRC source tiles (two per K step), weight chunks of two K steps
-template <int NSRC, bool RELU, int ABL>
-__device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&src)[NSRC], const float* __restrict__ blob,
-                                              float* lds, int& g, int lane, int wave) {
-    constexpr int kSteps = NSRC / 2;
-#pragma unroll
-    for (int m0 = 0; m0 < kSteps; m0 += 2) {
-        const int nks = m0 + 1 < kSteps ? 2 : 1;
-        const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
-        const NextChunk nx = next_chunk(blob, lds, g + 1);
-#pragma unroll
-        for (int kl = 0; kl < 2; ++kl) {
-            if (kl < nks) {
-                const int m = m0 + kl < kSteps ? m0 + kl : kSteps - 1;
-                float x[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    x[e] = src[2 * m + (e >> 2)][e & 3];
-                    if (RELU) x[e] = fmaxf(x[e], 0.f);
-                }
-                half8 bhi, blo;
-                split8(x, bhi, blo);
-#pragma unroll
-                for (int q = 0; q < kTD / 2; ++q) {
-                    const float* w0 = wl + ((kl * kTD + 2 * q) * 2) * 256;
-                    mfma_pair(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, bhi, blo);
-                    if (kl * 4 + q < kPieces) stream_issue_piece<ABL>(nx, kl * 4 + q, lane, wave);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        // a single-step chunk has only 4 slots: issue the remaining pieces of its successor here
-#pragma unroll
-        for (int p = nks * 4; p < kPieces; ++p) stream_issue_piece<ABL>(nx, p, lane, wave);
-        stream_sync<ABL>();
-        ++g;
-    }
-}
-
-// a K = 16 (+ folded bias) layer with 128 outputs: one K step, B operand (ghi, glo) prepared by the caller
-__device__ __forceinline__ void small_layer(f32x4 (&acc)[kTD], const half8& ghi, const half8& glo, const float* wl) {
-#pragma unroll
-    for (int q = 0; q < kTD / 2; ++q) {
-        const float* w0 = wl + (2 * q * 2) * 256;
-        mfma_pair(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, ghi, glo);
-    }
 }
 
 // ABL > 0: timing-only ablations (wrong results): 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers,
@@ -457,15 +271,15 @@ __global__ void __launch_bounds__(768) fused4_kernel(const Fused4Args a) {
     //      e_0 back from the output tensor (written by this wave one source pass ago: L2), same layout, for the other half ----
     f32x4 k1[kTD];
     init_bias<kTD>(k1, lds + kLdsBias + kBiasK1, q4, up);
-    chained_layer<kTE, false, ABL>(k1, acc, a.blob, lds, g, lane, wave);
+    chained_layer<kTE, false, ABL, false>(k1, acc, a.blob, lds, g, lane, wave);
     if (live) store_rows<kTE>(acc, a.e + i * (2 * kE) + kE, q4);
 #pragma unroll
     for (int t = 0; t < kTE; ++t) acc[t] = *reinterpret_cast<const f32x4*>(a.e + i * (2 * kE) + 16 * t + 4 * q4);
-    chained_layer<kTE, false, ABL>(k1, acc, a.blob, lds, g, lane, wave);
+    chained_layer<kTE, false, ABL, false>(k1, acc, a.blob, lds, g, lane, wave);
     scale_acc<kTD>(k1, down);
     f32x4 key[kTD];
     init_bias<kTD>(key, lds + kLdsBias + kBiasK2, q4, up);
-    chained_layer<kTD, true, ABL>(key, k1, a.blob, lds, g, lane, wave);
+    chained_layer<kTD, true, ABL, false>(key, k1, a.blob, lds, g, lane, wave);
     scale_acc<kTD>(key, down);
 
     // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ;  ug = Wr1[:,128:] g + br1 ---------------------
@@ -486,7 +300,7 @@ __global__ void __launch_bounds__(768) fused4_kernel(const Fused4Args a) {
     ++g;
     scale_acc<kTD>(t1, down);
     init_bias<kTD>(qv, lds + kLdsBias + kBiasQ2, q4, up);
-    chained_layer<kTD, true, ABL>(qv, t1, a.blob, lds, g, lane, wave);
+    chained_layer<kTD, true, ABL, false>(qv, t1, a.blob, lds, g, lane, wave);
     scale_acc<kTD>(qv, down);
     float dot = 0.0f;
 #pragma unroll
