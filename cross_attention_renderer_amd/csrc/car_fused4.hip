@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(768) fused4_kernel(const Fused4Args a) {
     }
     // 192 samples = 48 consecutive rays x 4 consecutive steps: wave = (bundle of 16 rays, step), lane & 15 = ray of the bundle, so the
     // 16 rows a wave gathers together are the same step of neighbouring rays (shared texel rows, see car_fused2.hip)
-    const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + 3 * kRows - 1) / (3 * kRows);
+    const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + kBundles * kRows - 1) / (kBundles * kRows);
     const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
     const int ray_i = bun * (kBundles * kRows) + (wave / kStepsPerGroup) * kRows + s, pp = pg * kStepsPerGroup + wave % kStepsPerGroup;
     const bool live = ray_i < a.R && pp < a.P;
