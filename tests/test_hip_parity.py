@@ -371,3 +371,31 @@ def test_fused_path_ragged_sizes_against_the_oracle(R, P, b):
         assert e["max"] <= TOL, (k, e)
     assert torch.equal(out["valid_mask"].cpu(), ora["valid_mask"])
     assert (out["at_wt_max"].cpu() == ora["at_wt_max"]).float().mean() > 0.99
+
+
+
+def test_one_call_c_abi_without_second_round():
+    """repeat_attention=False (models.py:547) through car_render_forward, the Python engine and the oracle at real widths."""
+    from cross_attention_renderer_amd import synthetic as S
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    from cross_attention_renderer_amd.native import NativeRenderer
+    dev = torch.device("cuda:0")
+    H, P, R = 64, 32, 200
+    torch.manual_seed(0)
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, repeat_attention=False).eval()
+    S.perturb_parameters(m, seed=6)
+    m.H = m.W = H
+    inp = S.stereo_scene(H, b=1, uv=C.select_rays(H, R), seed=9, alpha=0.6)
+    z = S.feature_maps(1, 2, H, seed=3)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ora = O.render_forward(sd, inp, z, O.RenderConfig(n_view=2, npoints=P, H=H, W=H, repeat_attention=False))
+        md = m.to(dev)
+        dinp, dz = to_device(inp, dev), [t.to(dev) for t in z]
+        eng = md(dinp, z=dz)
+        nat = NativeRenderer(md, dev).forward(dinp, dz)
+    torch.cuda.synchronize()
+    for k in ("rgb", "depth_ray", "at_wt", "valid_mask", "at_wt_max"):
+        assert torch.equal(eng[k].cpu(), nat[k].cpu()), k
+    for k in ("rgb", "depth_ray", "at_wt"):
+        assert err_stats(eng[k].cpu(), ora[k])["max"] <= TOL, k
