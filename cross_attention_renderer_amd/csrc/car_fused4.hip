@@ -101,26 +101,31 @@ __global__ void __launch_bounds__(768) fused4_kernel(const Fused4Args a) {
     int g = 0;
     stream_issue_all<ABL>(a.blob, lds, 0, lane, wave);
 
-    // ---- geometry of this lane's sample (the four lane groups repeat it); lane group 0 / 1 prepares source view 0 / 1 ----
+    // ---- geometry: the 192 samples of the group are spread over the 192 lanes of waves 0-2 (one sample per lane, both source views),
+    //      instead of every wave repeating its 16 samples in four lane groups: a third of the issue time on the critical path ----
     const int P = a.P, V = a.V;
-    const int p = (int)(i % P);
-    const long nr = i / P;
-    const int n = (int)(nr / a.R);
-    const int v = n % V, sc = n / V;
-    {
+    if (wave < kGroup / 64) {
+        const int sg = wave * 64 + lane, gwv = sg >> 4, gs = sg & 15;     // sample sg belongs to row gs of matrix wave gwv
+        const int g_ray = bun * (kBundles * kRows) + (gwv / kStepsPerGroup) * kRows + gs, g_pp = pg * kStepsPerGroup + gwv % kStepsPerGroup;
+        const bool g_live = g_ray < a.R && g_pp < a.P;
+        const long gi = ((long)nn * a.R + (g_ray < a.R ? g_ray : a.R - 1)) * a.P + (g_pp < a.P ? g_pp : a.P - 1);
+        const int p = (int)(gi % P);
+        const long nr = gi / P;
+        const int n = (int)(nr / a.R);
+        const int v = n % V, sc = n / V;
         const CarPose& Ps = a.poses[n];
         const CarRay ray = a.rays[nr];
         CarSample smp;
         for (int k = 0; k < 2; ++k) smp.grid[k] = ray.start[k] + (ray.end[k] - ray.start[k]) * a.steps[p];
         car_sample_setup(Ps, a.poses + sc * 2, ray, 2, a.H, a.W, &smp);
-        if (q4 < 2) {
-            const int sv = q4;
+#pragma unroll
+        for (int sv = 0; sv < 2; ++sv) {
             float gx, gy;
             int mode, m;
             if (sv == v) { gx = smp.grid[0]; gy = smp.grid[1]; mode = 0; m = n; }
             else { gx = sv == 0 ? smp.grid_in[0][0] : smp.grid_in[1][0]; gy = sv == 0 ? smp.grid_in[0][1] : smp.grid_in[1][1]; mode = 1; m = sc * V + sv; }
-            unsigned* tb = reinterpret_cast<unsigned*>(lds + kLdsTapB) + ((wave * kRows + s) * 2 + sv) * 3;
-            float* tw = lds + kLdsTapW + ((wave * kRows + s) * 2 + sv) * 12;
+            unsigned* tb = reinterpret_cast<unsigned*>(lds + kLdsTapB) + (sg * 2 + sv) * 3;
+            float* tw = lds + kLdsTapW + (sg * 2 + sv) * 12;
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 int idx[4];
@@ -129,23 +134,19 @@ __global__ void __launch_bounds__(768) fused4_kernel(const Fused4Args a) {
                 // the four taps are (x0|x1, y0|y1) after clamping: nw + {0, 1 texel} + {0, 1 row}; a texel row is kC*4 = 2304 B, a multiple
                 // of 256, so the two flags ride in the low bits of the nw texel's byte offset
                 tb[l] = (unsigned)(m * a.gh[l] * a.gw[l] + idx[0]) * (unsigned)(kC * 4) | (idx[1] != idx[0] ? 1u : 0u) | (idx[2] != idx[0] ? 2u : 0u);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) tw[4 * l + t] = w[t];
+                *reinterpret_cast<float4*>(tw + 4 * l) = make_float4(w[0], w[1], w[2], w[3]);
             }
-            float* pe = lds + kLdsPe + ((wave * kRows + s) * 2 + sv) * 4;
+            const float px = sv == 0 ? smp.pt_in[0][0] : smp.pt_in[1][0], py = sv == 0 ? smp.pt_in[0][1] : smp.pt_in[1][1],
+                        pz = sv == 0 ? smp.pt_in[0][2] : smp.pt_in[1][2];
+            *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f), tanhf(py / 5.0f), tanhf(pz / 5.0f), 0.0f);
+        }
+        if (g_live) {
+            a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1];
+            a.pt[3 * gi + 0] = smp.pt[0]; a.pt[3 * gi + 1] = smp.pt[1]; a.pt[3 * gi + 2] = smp.pt[2];
+        }
+        float* gl = lds + kLdsG + sg * 16;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) pe[k] = tanhf((sv == 0 ? smp.pt_in[0][k] : smp.pt_in[1][k]) / 5.0f);
-            pe[3] = 0.0f;
-        }
-        if (live && q4 == 0) {
-            a.pixel_val[2 * i] = smp.grid[0]; a.pixel_val[2 * i + 1] = smp.grid[1];
-            a.pt[3 * i + 0] = smp.pt[0]; a.pt[3 * i + 1] = smp.pt[1]; a.pt[3 * i + 2] = smp.pt[2];
-        }
-        if (q4 < 2) {
-            float* gl = lds + kLdsG + (wave * kRows + s) * 16 + 8 * q4;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) gl[k] = q4 == 0 ? smp.g[k] : smp.g[8 + k];
-        }
+        for (int k = 0; k < 16; k += 4) *reinterpret_cast<float4*>(gl + k) = make_float4(smp.g[k], smp.g[k + 1], smp.g[k + 2], smp.g[k + 3]);
     }
     __syncthreads();                                                   // tables and tap records visible
 
