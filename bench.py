@@ -198,6 +198,17 @@ def main():
                     roof["traffic_source"] = tr["source"]
             except OSError:
                 pass
+        # whole-frame HBM view: bytes every kernel of one frame moves on the memory side (committed PMC passes) over the measured frame time
+        hbm = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                fr = json.load(f).get("frame")
+            if fr and args.chunk_rays >= R:
+                per_frame = fr["bytes_per_frame"]
+                hbm = {"bytes_per_frame": per_frame, "achieved": per_frame / (elapsed / args.steps) / 1e12, "peak": 8.0, "unit": "TB/s",
+                       "frac": per_frame / (elapsed / args.steps) / 8.0e12, "source": fr["source"]}
+        except OSError:
+            pass
         line = {
             "metric": "rendered_rays_per_sec", "value": rays_total / elapsed, "unit": "rays/s",
             "frames_per_sec": world * args.steps / elapsed,
@@ -207,6 +218,7 @@ def main():
             "config": {"workload": f"256x256 query frame, 64 samples/view, 2 context views (config 2), {-(-65536 // args.chunk_rays)} forward calls x {args.chunk_rays} rays",
                        "rays_per_step_per_gpu": R, "parallelism": f"ray-sharded frames x{world}, RCCL all-gather of tiles"},
             "roofline": roof,
+            "hbm": hbm,
             # SURVEY.md §8(d) prices the path with the REFERENCE's arithmetic: V*P*2 617 728 + 791 808 FLOP per ray (335.9 MFLOP at
             # P = 64) against the fp32 matrix peak.  This implementation executes about a third of that (first point-MLP layer per
             # texel, value projection after the attention average) and runs it on the f16 pipe, hence a figure above 1.
