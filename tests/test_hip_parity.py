@@ -343,7 +343,7 @@ def test_one_call_c_abi_equals_python_engine(name):
 
 
 
-@pytest.mark.parametrize("R,P,b", [(37, 13, 1), (16, 8, 2), (131, 70, 1)])
+@pytest.mark.parametrize("R,P,b", [(37, 13, 1), (16, 8, 2), (131, 70, 1), (96, 32, 5)])
 def test_fused_path_ragged_sizes_against_the_oracle(R, P, b):
     """Ray counts that are no multiple of 16 and sample counts that are no multiple of 8 (the fused kernel works on groups of
     16 rays x 8 steps, the round-2 kernel on blocks of 32 samples): real widths, H = 64, rays picked across the frame."""
