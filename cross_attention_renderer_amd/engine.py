@@ -525,8 +525,14 @@ class RenderEngine:
             m.query_encode_latent_2.weight, m.query_encode_latent_2.bias, m.query_embed.weight, m.query_embed.bias,
             m.query_embed_2.weight, m.query_embed_2.bias, m.query_repeat_embed.weight, m.query_repeat_embed.bias,
             m.key_map.weight, m.key_map.bias, m.key_map_2.weight, m.key_map_2.bias)) + (str(dev), self.split_fp16, self.fused_version)
-        v4 = self.fused_version == 4
-        v2 = self.fused_version == 2 or v4
+        version = self.fused_version
+        # the 16x16x32 kernels address texel rows by 32-bit byte offsets inside a level: a level of 4 GiB or more (more than 14 scenes
+        # of two 256x256 views in one call) goes through the first-generation kernel, which uses 64-bit addresses
+        if version in (2, 4) and max(t.numel() * 4 for t in gmaps) >= 1 << 32:
+            version = 1
+        key = key[:-1] + (version,)
+        v4 = version == 4
+        v2 = version == 2 or v4
         if key != self._fused_key:
             self._fused = pack_fused2_weights(m, dev) if v2 else pack_fused_weights(m, dev, self.split_fp16)
             assert self._fused[0].numel() == (lib.car_fused2_blob_floats() if v2 else lib.car_fused_blob_floats())
