@@ -36,7 +36,7 @@ class CarWeights(ctypes.Structure):
 
 
 class CarInputs(ctypes.Structure):
-    _fields_ = [("poses", _P), ("uv", _P), ("gmaps", _P), ("steps", _P)]
+    _fields_ = [("poses", _P), ("uv", _P), ("gmaps", _P * 4), ("gmeta", _P), ("steps", _P)]
 
 
 class CarOutputs(ctypes.Structure):
@@ -58,24 +58,30 @@ SIGNATURES = {
     "car_gather_encode": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_long, _P, c_int, _P]),
     "car_fused_blob_floats": (c_size_t, []),
     "car_fused_bias_floats": (c_size_t, []),
-    "car_fused_samples": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
-                                  _P, _P, _P, _P, _P, _P, c_int, _P]),
-    "car_fused2_blob_floats": (c_size_t, []),
-    "car_fused_samples_v2": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     _P, _P, _P, _P, _P, _P, _P]),
-    "car_fused_samples_v4": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     _P, _P, _P, _P, _P, _P, _P]),
+    "car_fused_samples": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  _P, _P, _P, _P, _P, _P, _P]),
     "car_linear_packed_floats": (c_size_t, [c_int, c_int]),
     "car_linear_pack": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "car_linear": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_long, c_int, _P]),
     "car_attend": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P, c_int, c_int,
                            _P, _P, _P, _P, _P]),
+    "car_round2_packed_floats": (c_size_t, []),
+    "car_round2_bias_floats": (c_size_t, []),
     "car_round2_logits": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "car_fused_pack": (c_int, [ctypes.POINTER(CarWeights), _P, _P, _P, _P]),
+    "car_round2_pack": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "car_add_ray_bias_relu": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "car_finalize": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "car_plan_bytes": (c_size_t, [ctypes.POINTER(CarDims)]),
     "car_plan_build": (c_int, [ctypes.POINTER(CarDims), ctypes.POINTER(CarWeights), _P, _P]),
     "car_gmaps_floats": (c_size_t, [ctypes.POINTER(CarDims)]),
+    "car_gmaps_level_offset": (c_size_t, [ctypes.POINTER(CarDims), c_int]),
+    "car_gmeta_offset": (c_size_t, [ctypes.POINTER(CarDims)]),
+    "car_workspace_find": (c_int, [ctypes.POINTER(CarDims), c_char_p, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
+    "car_profile_enable": (None, [c_int]),
+    "car_profile_count": (c_int, []),
+    "car_profile_read": (c_int, [c_int, ctypes.POINTER(c_char_p), ctypes.POINTER(c_float)]),
+    "car_profile_reset": (None, []),
     "car_project_maps": (c_int, [ctypes.POINTER(CarDims), _P, _P, _P, _P]),
     "car_workspace_bytes": (c_size_t, [ctypes.POINTER(CarDims)]),
     "car_render_forward": (c_int, [ctypes.POINTER(CarDims), _P, ctypes.POINTER(CarInputs), ctypes.POINTER(CarOutputs), _P,
@@ -113,7 +119,7 @@ def check_exports() -> None:
     missing = [n for n in SIGNATURES if not hasattr(lib, n)]
     if missing:
         raise RuntimeError(f"libcar_hip.so lacks symbols: {missing}")
-    if lib.car_version() < 100:
+    if lib.car_version() < 200:
         raise RuntimeError("libcar_hip.so is older than the Python package")
 
 

@@ -1,76 +1,41 @@
-// car_fused.hip — the per-sample part of the render forward as ONE kernel (first half of a14).
+// car_fused.hip — the fused per-sample kernel (SURVEY.md §8a rows a6-a13 + the logits of a14; reference models.py:261-344,
+// 487-532).  Per sample, without touching HBM in between: geometry (car_geom.h, fp64 Pluecker intersection) -> per 32-channel
+// chunk a 12-tap gather of the per-texel projected maps (the first point-MLP layer applied once per texel) ->
+// e_s = W2 relu(h_s) + b2 for both source views -> k1 = Wk1 [e_0 ; e_1] -> key -> qry -> logit = <key, qry>/16.  Every layer
+// runs on the f16 matrix pipe as three v_mfma_f32_16x16x32_f16 products of fp16 hi/lo operand halves (car_fused_mma.h); a
+// layer's accumulators are the next layer's B operands.
 //
-// For every epipolar sample (V = 2 context views) it computes, without touching HBM in between:
-//   geometry   pixel_val, fp64 Pluecker point, cross-view projections, geometric query g      (car_geom.h; models.py:261-331, 494-528)
-//   encode     h_s = relu(sum_l bilinear(G_l) + Wpt tanh(pt_s/5) + b1) for both source views s (per-texel first layer, see car_encode.hip)
-//   e          = [W2 h_0 + b2 ; W2 h_1 + b2]                      576 -> 288 per source        (models.py:333-344)
-//   qry        = Wq2 relu(Wq1 g + bq1) + bq2                      16 -> 128 -> 128             (models.py:529)
-//   ug         = Wr1[:,128:] g + br1                              local half of round 2's query (models.py:552-553)
-//   key        = Wk2 relu(Wk1 e + bk1) + bk2                      576 -> 128 -> 128            (models.py:491)
-//   logit      = <key, qry> / 16                                                              (models.py:532)
-// and writes e, qry, ug, logit, pt, pixel_val.  The per-ray softmax / reductions stay in car_attention.hip.
-//
-// CDNA4 mapping.  One workgroup = 4 waves = 128 consecutive samples, ONE wave per SIMD (up to 512 VGPRs): each wave owns
-// 32 samples for the whole chain.  All layers use v_mfma_f32_32x32x2_f32 with weights as the A operand and samples as the
-// B operand (see car_linear.hip), so a layer's accumulators (lane = sample, registers = channels) are exactly the next
-// layer's B operands: e, key and qry never leave the register file ("chained" layers; the K index of a chained layer is
-// permuted to the accumulator layout k = 32*T + (r&3) + 8*(r>>2) + 4*(lane>>5), which the host bakes into the packed
-// weights).  Only the encode output has to be transposed (gather lanes own channels, MFMA lanes own samples); it goes
-// through a wave-private 32x32 LDS tile per K chunk.  The 12 tap loads per output float4 of chunk c+1 are issued in three
-// level-sized batches between the three MFMA sub-blocks of chunk c, so their L2 latency hides under ~3000 matrix cycles.
-// The weights of all six layers (1.1 MB) stream L2 -> LDS by LDS-DMA, double buffered, one barrier per 32-wide K chunk,
-// shared by the four waves.  fp32 MFMA issues one 32x32x2 per 64 cycles per SIMD: everything else (gather FMAs, tanh,
-// fp64 geometry, LDS traffic) fits in its shadow; the kernel is matrix-pipe bound on 0.89 MFLOP per sample.
+// Three waves per SIMD (<= 168 registers per wave), which needs
+//   * the key layer's accumulators (k1, 32 registers) out of the e path: k1 = Wk1 [e_0 ; e_1] is computed after both
+//     sources, chained from the accumulators for e_1 and from e_0 read back from the output tensor it was just stored to (L2);
+//   * half-size tap batches (one level of one row group: 4 float4) in two alternating buffers;
+//   * no read-ahead of the weight operands (the third wave hides the LDS latency instead).
+// One workgroup = 12 waves = 192 samples = 48 consecutive rays x 4 consecutive steps (wave = (16-ray bundle, step)); the weight
+// stream is shared by 192 samples.  The tap tables are stored compactly (base offset + two flags, four weights).
+// The geometric query g (16 floats per sample) is written out for the second attention round (car_round2.hip recomputes the
+// 16 -> 128 half of query_repeat_embed from it instead of reading a 128-wide row back).
 #include "car_common.h"
 #include "car_geom.h"
-#include <stdlib.h>
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) void lds_void;
+constexpr int kWaves = 12, kRows = 16, kGroup = kWaves * kRows;      // 192 samples per workgroup
+constexpr int kStepsPerGroup = 4, kBundles = kWaves / kStepsPerGroup;  // 3 bundles of 16 rays x 4 steps
 
-// PREC = 1: the 576 -> 288 layer runs on the f16 matrix pipe with both operands split into two fp16 halves,
-//   x = hi + lo,  hi = fp16(x), lo = fp16(x - hi),      x*w ~= hi_x*hi_w + hi_x*lo_w + lo_x*hi_w
-// (three v_mfma_f32_32x32x16_f16 per 16-wide K step instead of eight v_mfma_f32_32x32x2_f32: every fp16 x fp16 product is
-// exact in the fp32 accumulator, the dropped lo*lo term is 2^-22 relative, so the result is fp32-class — it is checked
-// against the oracle at 1e-4 like the fp32 kernel, which stays selectable).  The weights are pre-scaled by 2^kWShift on
-// the host so their low halves stay out of the fp16 subnormal range; the accumulators are scaled back exactly.
-constexpr int kWShift = 8;
+constexpr int kPieces = 3;                         // LDS-DMA pieces per chunk: 12 waves x 1 KB each
 
-constexpr int kC = 576;            // feature channels = width of h
-constexpr int kE = 288;            // per-source width of e
-constexpr int kD = 128;            // hidden width of the key / query MLPs
-constexpr int kKT = kC / 32;       // 18 K-chunks of the 576 -> 288 layer
-constexpr int kNTE = kE / 32;      // 9 output tiles
-constexpr int kNTD = kD / 32;      // 4 output tiles
-constexpr int kTile = 1024;        // packed floats per (chunk, tile)
-constexpr int kStageLd = 36;       // row stride of the wave-private h tile (floats): conflict-free b128 reads and writes
+#include "car_fused_mma.h"
 
-// ---- packed-weight blob: tile offsets (units of kTile floats) of each layer, in consumption order -------------------
-constexpr int kOffW2 = 0;                          // 18 chunks x 9 tiles, standard K mapping
-constexpr int kOffQ1 = kOffW2 + kKT * kNTE;        // 1 chunk x 4 tiles, standard, bias folded at k = 16
-constexpr int kOffQ2 = kOffQ1 + kNTD;              // 4 chunks x 4 tiles, chained
-constexpr int kOffUG = kOffQ2 + 4 * kNTD;          // 1 chunk x 4 tiles, standard, bias folded
-constexpr int kOffK1 = kOffUG + kNTD;              // 18 chunks x 4 tiles, chained over [e_0 ; e_1]
-constexpr int kOffK2 = kOffK1 + 2 * kNTE * kNTD;   // 4 chunks x 4 tiles, chained
-constexpr int kBlobTiles = kOffK2 + 4 * kNTD;
-constexpr int kNumChunks = 2 * kKT + 2 * 5 + 2 + 1 + 2 + 1;           // 52 weight chunks per 128-sample pass
-
-// bias table (floats): b2[288] | bq2[128] | bk1[128] | bk2[128]
-constexpr int kBiasE = 0, kBiasQ2 = kE, kBiasK1 = kE + kD, kBiasK2 = kE + 2 * kD, kBiasFloats = kE + 3 * kD;
-
-// ---- dynamic LDS carve-up (floats) --------------------------------------------------------------------------------
-constexpr int kLdsW = 0;                                   // [2][9][1024]          weight chunks           72 KB
-constexpr int kLdsStage = kLdsW + 2 * kNTE * kTile;        // [4][32][36]           h tiles, wave private    18 KB
-constexpr int kLdsTapI = kLdsStage + 4 * 32 * kStageLd;    // [4][32][2][3][4] int  tap texel indices        12 KB
-constexpr int kLdsTapW = kLdsTapI + 4 * 32 * 2 * 3 * 4;    // [4][32][2][3][4]      tap weights              12 KB
-constexpr int kLdsPe = kLdsTapW + 4 * 32 * 2 * 3 * 4;      // [4][32][2][4]         tanh(pt_s/5)              4 KB
-constexpr int kLdsWpt = kLdsPe + 4 * 32 * 2 * 4;           // [576][4]              (W1[:,C:C+3], b1)         9 KB
-constexpr int kLdsBias = kLdsWpt + kC * 4;                 // [672]                                           2.6 KB
-constexpr int kLdsFloats = kLdsBias + kBiasFloats;
+constexpr int kLdsStage = kLdsW + 2 * kChunkTiles * kTile;      // [12][16][36]           h tiles, wave private     27 KB
+constexpr int kLdsTapB = kLdsStage + kGroup * kStageLd;         // [192][2][3] uint       byte offset of the nw texel | 1: x1 != x0 | 2: y1 != y0   4.5 KB
+constexpr int kLdsTapW = kLdsTapB + kGroup * 6;                 // [192][2][3][4]         tap weights (nw, ne, sw, se)   18 KB
+constexpr int kLdsPe = kLdsTapW + kGroup * 24;                  // [192][2][4]            tanh(pt_s/5)                6 KB
+constexpr int kLdsWpt = kLdsPe + kGroup * 8;                    // [576][4]               (W1[:,C:C+3], b1)           9 KB
+constexpr int kLdsBias = kLdsWpt + kC * 4;                      // [672]
+constexpr int kLdsG = kLdsBias + kBiasFloats;                   // [192][16]              geometric query g per sample 12 KB
+constexpr int kLdsFloats = kLdsG + kGroup * 16;
 constexpr size_t kLdsBytes = (size_t)kLdsFloats * sizeof(float);
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
 struct FusedArgs {
     const CarPose* poses;
@@ -78,328 +43,165 @@ struct FusedArgs {
     const float* steps;
     const float* gmap[3];
     int gh[3], gw[3];
-    const float* wpt;        // [576][4]
-    const float* blob;       // kBlobTiles * 1024 floats
-    const float* bias;       // kBiasFloats
+    const float* gmeta;        // [3] max |G_l| per level (car_project_maps)
+    const float* wpt;
+    const float* blob;
+    const float* bias;
     int b, V, R, P, H, W;
-    int xcd_bands;           // 1: remap workgroups so each XCD gets a contiguous band of rays
-    int prec;                // 0: fp32 MFMA for the 576->288 layer; 1: split-fp16 MFMA (blob packed accordingly)
-    long S;                  // b*V*R*P samples
-    float* e;                // [S, 576]
-    float* qry;              // [S, 128]
-    float* ug;               // [S, 128]
-    float* logit;            // [S]
-    float* pt;               // [S, 3]
-    float* pixel_val;        // [S, 2]
+    long S;
+    float* e;
+    float* qry;
+    float* g;
+    float* logit;
+    float* pt;
+    float* pixel_val;
 };
 
-// consumption order (a "chunk" is what one LDS buffer holds between two barriers):
-//   W2 x18 (source 0, 9 tiles) | K1 over e_0 x5 (source tiles {0,1},{2,3},{4,5},{6,7},{8}: 8,8,8,8,4 tiles) | W2 x18 (source 1) |
-//   K1 over e_1 x5 | K2 x2 (8 tiles) | Q1 (4) | Q2 x2 (8) | UG (4)
-// The chained layers take two 32-row source tiles per chunk so that a chunk lasts >= 8192 matrix cycles: an LDS-DMA needs
-// ~1.1 us from issue to landing, which a 4096-cycle chunk cannot hide.
-constexpr int kChK1 = 5;                                   // chunks per K1 half
-constexpr int kG_K1a = kKT, kG_W2b = kG_K1a + kChK1, kG_K1b = kG_W2b + kKT, kG_K2 = kG_K1b + kChK1, kG_Q1 = kG_K2 + 2,
-              kG_Q2 = kG_Q1 + 1, kG_UG = kG_Q2 + 2;
+// chunk order:  W2 x18 (source 0) | W2 x18 (source 1) | K1 over e_1 x5 (2,2,2,2,1 K steps) | K1 over e_0 x5 | K2 x2 | Q1 | Q2 x2
+constexpr int kChK1 = 5;
+constexpr int kG_W2b = kKS, kG_K1b = 2 * kKS, kG_K1a = kG_K1b + kChK1, kG_K2 = kG_K1a + kChK1, kG_Q1 = kG_K2 + 2, kG_Q2 = kG_Q1 + 1;
+static_assert(kG_Q2 + 2 == kNumChunks, "chunk count");
 __device__ __forceinline__ int chunk_tile_offset(int g) {
-    if (g < kG_K1a) return kOffW2 + g * kNTE;
-    if (g < kG_W2b) return kOffK1 + (g - kG_K1a) * 2 * kNTD;
-    if (g < kG_K1b) return kOffW2 + (g - kG_W2b) * kNTE;
-    if (g < kG_K2) return kOffK1 + kNTE * kNTD + (g - kG_K1b) * 2 * kNTD;
-    if (g < kG_Q1) return kOffK2 + (g - kG_K2) * 2 * kNTD;
+    if (g < kG_W2b) return kOffW2 + g * kTE;
+    if (g < kG_K1b) return kOffW2 + (g - kG_W2b) * kTE;
+    if (g < kG_K1a) return kOffK1 + 9 * kTD + (g - kG_K1b) * 2 * kTD;
+    if (g < kG_K2) return kOffK1 + (g - kG_K1a) * 2 * kTD;
+    if (g < kG_Q1) return kOffK2 + (g - kG_K2) * 2 * kTD;
     if (g < kG_Q2) return kOffQ1;
-    if (g < kG_UG) return kOffQ2 + (g - kG_Q2) * 2 * kNTD;
-    return kOffUG;
+    return kOffQ2 + (g - kG_Q2) * 2 * kTD;
 }
 __device__ __forceinline__ int chunk_tiles(int g) {
-    if (g < kG_K1a || (g >= kG_W2b && g < kG_K1b)) return kNTE;
-    if (g == kG_W2b - 1 || g == kG_K2 - 1 || g == kG_Q1 || g == kG_UG) return kNTD;       // odd last K1 tile, Q1, UG
-    return 2 * kNTD;
+    if (g < kG_K1b) return kTE;
+    if (g == kG_K1a - 1 || g == kG_K2 - 1 || g == kG_Q1) return kTD;                      // odd last K1 step, Q1
+    return 2 * kTD;
 }
 
-// LDS-DMA of weight chunk g into buffer (g & 1): every wave copies a quarter of every tile (see car_linear.hip for why
-// this is inline asm).  Nothing is issued past the last chunk.
-__device__ __forceinline__ void stream_issue(const float* __restrict__ blob, float* lds, int g, int tid, int wave) {
-    if (g >= kNumChunks) return;
-    const float* src = blob + (long)chunk_tile_offset(g) * kTile;
-    float* dst = lds + kLdsW + (g & 1) * kNTE * kTile;
-    const int nt = chunk_tiles(g);
-    for (int t = 0; t < nt; ++t) {
-        const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(dst + 4 * (t * 256 + wave * 64)));
-        const float* gsrc = src + 4 * (t * 256 + tid);
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-    }
-}
-// Descriptor of the weight chunk to prefetch, resolved ONCE per chunk (scalar code with branches) so that the per-tile
-// issue below is straight-line code: a branch inside the unrolled MFMA body splits it into basic blocks and pins the
-// gather/DMA pieces (and their waits) to the block boundaries.
-struct NextChunk { const float* src; float* dst; int nt; };
-__device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, float* lds, int g) {
-    const int ge = g < kNumChunks ? g : kNumChunks - 1;            // past the end: re-copy the last chunk onto itself (same bytes)
-    NextChunk n;
-    n.src = blob + (long)chunk_tile_offset(ge) * kTile;
-    n.dst = lds + kLdsW + (ge & 1) * kNTE * kTile;
-    n.nt = chunk_tiles(ge);
-    return n;
-}
-// one tile (4 KB) of the next weight chunk; t may exceed the chunk's tile count, then an earlier tile is copied again
-// (identical bytes, harmless).  Must only run after the barrier that ended the chunk which last used that buffer.
-template <int ABL = 0>
-__device__ __forceinline__ void stream_issue_tile(const NextChunk& n, int t, int tid, int wave) {
-    if constexpr (ABL == 3) return;
-    int te = t < n.nt ? t : t - n.nt;
-    te = te < n.nt ? te : te - n.nt;
-    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(n.dst + 4 * (te * 256 + wave * 64)));
-    const float* gsrc = n.src + 4 * (te * 256 + tid);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// end of a chunk: the DMA of the next chunk has landed and every wave is done reading the current one
-template <int ABL = 0>
-__device__ __forceinline__ void stream_sync() {
-    if constexpr (ABL == 3) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
-// 16 MFMA steps of one chunk on tiles [T0, T0+NTS) of acc, A from the LDS weight buffer, B from 16 registers
-template <int NT, int T0, int NTS>
-__device__ __forceinline__ void mfma_tiles(f32x16 (&acc)[NT], const float (&bv)[16], const float* wl) {
-#pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) {
-#pragma unroll
-        for (int t = T0; t < T0 + NTS; ++t) {
-            const float4 a = *reinterpret_cast<const float4*>(wl + (t * 4 + j4) * 256);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv[4 * j4 + 0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv[4 * j4 + 1], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv[4 * j4 + 2], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv[4 * j4 + 3], acc[t], 0, 0, 0);
-        }
-    }
-}
-
-// accumulators start at the layer's bias: lane (s, h) register r of tile t holds channel 32 t + (r&3) + 8 (r>>2) + 4 h
-template <int NT>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[NT], const float* lbias, int h) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = lbias[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h];
-}
-
-template <int NT>
-__device__ __forceinline__ void store_rows(const f32x16 (&acc)[NT], float* row, int h) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(row + 32 * t + 8 * g + 4 * h) =
-                make_float4(acc[t][4 * g + 0], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-}
-
-// one chained layer with 128 outputs: B operands are the NSRC x 16 registers of `src` (optionally through ReLU)
-template <int NSRC, bool RELU, int ABL = 0, int PREC = 0>
-__device__ __forceinline__ void chained_layer(f32x16 (&acc)[kNTD], const f32x16 (&src)[NSRC], const float* __restrict__ blob,
-                                              float* lds, int& g, int tid, int wave, int lane) {
-#pragma unroll
-    for (int T0 = 0; T0 < NSRC; T0 += 2) {
-        constexpr int kG = 4 * kNTD;                                   // MFMA groups per source tile
-        const int nsrc = T0 + 1 < NSRC ? 2 : 1;
-        const float* wl = lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane;
-        const NextChunk nx = next_chunk(blob, lds, g + 1);
-        // slots are pinned with sched_barrier(0) (hipcc otherwise regroups the pieces and shrinks the latency slack they
-        // were placed for); the A operand of the next group is therefore read one slot ahead by hand
-        if constexpr (PREC == 1) {
-            // split-fp16 path: per source tile, the 16 accumulator values of this lane become two 8-wide K groups (hi, lo);
-            // packed tile (Tl, t): [kg][hi|lo][lane][8 halves].  3 MFMAs of 32 cycles per (t, kg).
-#pragma unroll
-            for (int Tl = 0; Tl < 2; ++Tl) {
-                if (Tl < nsrc) {
-                    const f32x16& sv = src[T0 + Tl < NSRC ? T0 + Tl : NSRC - 1];
-                    half8 bhi[2], blo[2];
-#pragma unroll
-                    for (int kg = 0; kg < 2; ++kg)
-#pragma unroll
-                        for (int e8 = 0; e8 < 8; ++e8) {
-                            float x = sv[8 * kg + e8];
-                            if (RELU) x = fmaxf(x, 0.f);
-                            const _Float16 hi = (_Float16)x;
-                            bhi[kg][e8] = hi;
-                            blo[kg][e8] = (_Float16)(x - (float)hi);
-                        }
-#pragma unroll
-                    for (int t = 0; t < kNTD; ++t)
-#pragma unroll
-                        for (int kg = 0; kg < 2; ++kg) {
-                            const float* wt = wl + (Tl * kNTD + t) * kTile;
-                            const half8 ah = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wt + ((kg * 2 + 0) * 64) * 4));
-                            const half8 al = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wt + ((kg * 2 + 1) * 64) * 4));
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[kg], acc[t], 0, 0, 0);
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[kg], acc[t], 0, 0, 0);
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[kg], acc[t], 0, 0, 0);
-                            const int gq = (Tl * kNTD + t) * 2 + kg;
-                            if (gq < kNTE) stream_issue_tile<ABL>(nx, gq, tid, wave);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                }
-            }
-            // a single-source-tile chunk has only 8 slots: issue the rest of a 9-tile successor here
-#pragma unroll
-            for (int gq = nsrc * 2 * kNTD; gq < kNTE; ++gq) stream_issue_tile<ABL>(nx, gq, tid, wave);
-        } else {
-        float4 aw[kNTD];
-#pragma unroll
-        for (int t = 0; t < kNTD; ++t) aw[t] = *reinterpret_cast<const float4*>(wl + (t * 4) * 256);
-        // (source tile Tl, step group j4, step e, out tile t): round-robin over the 4 out tiles, see the e-path loop
-#pragma unroll
-        for (int Tl = 0; Tl < 2; ++Tl)
-#pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int t = 0; t < kNTD; ++t) {
-            const int mi = Tl * 4 * kG + j4 * 4 * kNTD + e * kNTD + t;
-            if (mi < nsrc * 4 * kG) {
-            const f32x16& sv = src[T0 + Tl < NSRC ? T0 + Tl : NSRC - 1];
-            float bq = sv[4 * j4 + e];
-            if (RELU) bq = fmaxf(bq, 0.f);
-            const float av = e == 0 ? aw[t].x : e == 1 ? aw[t].y : e == 2 ? aw[t].z : aw[t].w;
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq, acc[t], 0, 0, 0);
-            if (e == 3) {                                              // refresh tile t's A operand for its next step group
-                const int nj = j4 + 1 < 4 ? j4 + 1 : 0, nT = j4 + 1 < 4 ? Tl : Tl + 1;
-                if (nT < nsrc) aw[t] = *reinterpret_cast<const float4*>(wl + ((nT * kNTD + t) * 4 + nj) * 256);
-            }
-            if (mi % 4 == 3) {
-                const int gq = mi / 4;
-                if (gq < kNTE) stream_issue_tile<ABL>(nx, gq, tid, wave);            // next chunk may have up to 9 tiles
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            }
-        }
-        }
-        stream_sync<ABL>();
-        ++g;
-    }
-}
-
-// scale helpers of the split-fp16 layers: accumulators start at bias * 2^kWShift and are scaled back exactly
-template <int NT>
-__device__ __forceinline__ void scale_acc(f32x16 (&acc)[NT], float f) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] *= f;
-}
-
-// ABL > 0 are timing-only ablations (results are wrong by construction), selected with CAR_FUSED_ABLATE for tools/bench_fused.py:
-//   1 no tap loads   2 no gather work at all   3 = 2 + no weight DMA / barriers   4 = 0 but without the chained layers
-//   5 / 6 / 7 no tap loads of pyramid level 2 / 1 / 0
-template <int ABL, int SCHED = 0, int PREC = 0>
-__global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a) {
+// ABL > 0: timing-only ablations (wrong results), instantiated only in the -DCAR_ABLATION development build (tools/):
+// 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers, 5 the gather alone (no e-path MFMAs, no weight DMA, no
+// barriers); probes of the texture-address path on top of 5: 6 odd rows masked off (whole quads of lanes inactive), 7 odd channel
+// quads masked off (half of every quad of lanes inactive), 9 no level-0 taps, 10 level-2 taps only in the first two chunks
+template <int ABL>
+__global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = lane & 31, h = lane >> 5;
-    // XCD-aware placement: workgroup b runs on XCD b % 8 (observed dispatch order, used for speed only), so give every XCD
-    // a contiguous band of sample groups (= consecutive rays = neighbouring epipolar lines): each private L2 then holds
-    // its own band's texels instead of one eighth of everybody's.
+    const int s = lane & 15, q4 = lane >> 4;
     const int nblk = gridDim.x;
     int blk = blockIdx.x;
-    if (a.xcd_bands) {
+    {   // workgroup b runs on XCD b % 8 (observed, speed only): give every XCD a contiguous band of sample groups so that the
+        // texel rows its workgroups share stay in one L2
         const int q8 = nblk / 8, r8 = nblk % 8, xcd = blk % 8, idx = blk / 8;
-        blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;     // bijective for any grid size
+        blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
-    const long i_raw = (long)blk * 128 + wave * 32 + s;
-    const bool live = i_raw < a.S;
-    const long i = live ? i_raw : a.S - 1;
+    // 192 samples = 48 consecutive rays x 4 consecutive steps: wave = (bundle of 16 rays, step), lane & 15 = ray of the bundle, so the
+    // 16 rows a wave gathers together are the same step of neighbouring rays (shared texel rows)
+    const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + kBundles * kRows - 1) / (kBundles * kRows);
+    const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
+    const int ray_i = bun * (kBundles * kRows) + (wave / kStepsPerGroup) * kRows + s, pp = pg * kStepsPerGroup + wave % kStepsPerGroup;
+    const bool live = ray_i < a.R && pp < a.P;
+    const long i = ((long)nn * a.R + (ray_i < a.R ? ray_i : a.R - 1)) * a.P + (pp < a.P ? pp : a.P - 1);
 
-    // ---- tables shared by the workgroup -----------------------------------------------------------------------------
-    for (int k = tid; k < kC; k += 256) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
-    for (int k = tid; k < kBiasFloats; k += 256) lds[kLdsBias + k] = a.bias[k];
-    int g = 0;                                     // index of the weight chunk being consumed
-    stream_issue(a.blob, lds, 0, tid, wave);
+    for (int k = tid; k < kC; k += 768) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
+    for (int k = tid; k < kBiasFloats; k += 768) lds[kLdsBias + k] = a.bias[k];
+    int g = 0;
+    stream_issue_all<ABL>(a.blob, lds, 0, lane, wave);
 
-    // ---- geometry of this lane's sample; lane half h prepares source view h ---------------------------------------
+    // ---- geometry: the 192 samples of the group are spread over the 192 lanes of waves 0-2 (one sample per lane, both source views),
+    //      instead of every wave repeating its 16 samples in four lane groups: a third of the issue time on the critical path ----
     const int P = a.P, V = a.V;
-    const int p = (int)(i % P);
-    const long nr = i / P;
-    const int n = (int)(nr / a.R);
-    const int v = n % V, sc = n / V;
-    const CarPose& Ps = a.poses[n];
-    const CarRay ray = a.rays[nr];
-    CarSample smp;
-    for (int k = 0; k < 2; ++k) smp.grid[k] = ray.start[k] + (ray.end[k] - ray.start[k]) * a.steps[p];
-    car_sample_setup(Ps, a.poses + sc * 2, ray, 2, a.H, a.W, &smp);   // V == 2: literal so the per-view loops unroll (no scratch)
-    {
-        const int sv = h;                                              // this lane prepares source view sv of sample s
-        float gx, gy;
-        int mode, m;
-        if (sv == v) { gx = smp.grid[0]; gy = smp.grid[1]; mode = 0; m = n; }
-        else { gx = sv == 0 ? smp.grid_in[0][0] : smp.grid_in[1][0]; gy = sv == 0 ? smp.grid_in[0][1] : smp.grid_in[1][1]; mode = 1; m = sc * V + sv; }
-        int* ti = reinterpret_cast<int*>(lds + kLdsTapI) + ((wave * 32 + s) * 2 + sv) * 12;
-        float* tw = lds + kLdsTapW + ((wave * 32 + s) * 2 + sv) * 12;
+    if (wave < kGroup / 64) {
+        const int sg = wave * 64 + lane, gwv = sg >> 4, gs = sg & 15;     // sample sg belongs to row gs of matrix wave gwv
+        const int g_ray = bun * (kBundles * kRows) + (gwv / kStepsPerGroup) * kRows + gs, g_pp = pg * kStepsPerGroup + gwv % kStepsPerGroup;
+        const bool g_live = g_ray < a.R && g_pp < a.P;
+        const long gi = ((long)nn * a.R + (g_ray < a.R ? g_ray : a.R - 1)) * a.P + (g_pp < a.P ? g_pp : a.P - 1);
+        const int p = (int)(gi % P);
+        const long nr = gi / P;
+        const int n = (int)(nr / a.R);
+        const int v = n % V, sc = n / V;
+        const CarPose& Ps = a.poses[n];
+        const CarRay ray = a.rays[nr];
+        CarSample smp;
+        for (int k = 0; k < 2; ++k) smp.grid[k] = ray.start[k] + (ray.end[k] - ray.start[k]) * a.steps[p];
+        car_sample_setup(Ps, a.poses + sc * 2, ray, 2, a.H, a.W, &smp);
 #pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            int idx[4];
-            float w[4];
-            car_bilinear_taps(gx, gy, a.gw[l], a.gh[l], mode, idx, w);
+        for (int sv = 0; sv < 2; ++sv) {
+            float gx, gy;
+            int mode, m;
+            if (sv == v) { gx = smp.grid[0]; gy = smp.grid[1]; mode = 0; m = n; }
+            else { gx = sv == 0 ? smp.grid_in[0][0] : smp.grid_in[1][0]; gy = sv == 0 ? smp.grid_in[0][1] : smp.grid_in[1][1]; mode = 1; m = sc * V + sv; }
+            unsigned* tb = reinterpret_cast<unsigned*>(lds + kLdsTapB) + (sg * 2 + sv) * 3;
+            float* tw = lds + kLdsTapW + (sg * 2 + sv) * 12;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { ti[4 * l + t] = m * a.gh[l] * a.gw[l] + idx[t]; tw[4 * l + t] = w[t]; }
+            for (int l = 0; l < 3; ++l) {
+                int idx[4];
+                float w[4];
+                car_bilinear_taps(gx, gy, a.gw[l], a.gh[l], mode, idx, w);
+                // the four taps are (x0|x1, y0|y1) after clamping: nw + {0, 1 texel} + {0, 1 row}; a texel row is kC*4 = 2304 B, a multiple
+                // of 256, so the two flags ride in the low bits of the nw texel's byte offset
+                tb[l] = (unsigned)(m * a.gh[l] * a.gw[l] + idx[0]) * (unsigned)(kC * 4) | (idx[1] != idx[0] ? 1u : 0u) | (idx[2] != idx[0] ? 2u : 0u);
+                *reinterpret_cast<float4*>(tw + 4 * l) = make_float4(w[0], w[1], w[2], w[3]);
+            }
+            const float px = sv == 0 ? smp.pt_in[0][0] : smp.pt_in[1][0], py = sv == 0 ? smp.pt_in[0][1] : smp.pt_in[1][1],
+                        pz = sv == 0 ? smp.pt_in[0][2] : smp.pt_in[1][2];
+            *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f), tanhf(py / 5.0f), tanhf(pz / 5.0f), 0.0f);
         }
-        float* pe = lds + kLdsPe + ((wave * 32 + s) * 2 + sv) * 4;
+        if (g_live) {
+            a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1];
+            a.pt[3 * gi + 0] = smp.pt[0]; a.pt[3 * gi + 1] = smp.pt[1]; a.pt[3 * gi + 2] = smp.pt[2];
+        }
+        float* gl = lds + kLdsG + sg * 16;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) pe[k] = tanhf((sv == 0 ? smp.pt_in[0][k] : smp.pt_in[1][k]) / 5.0f);
-        pe[3] = 0.0f;
+        for (int k = 0; k < 16; k += 4) {
+            const float4 g4 = make_float4(smp.g[k], smp.g[k + 1], smp.g[k + 2], smp.g[k + 3]);
+            *reinterpret_cast<float4*>(gl + k) = g4;
+            if (g_live) *reinterpret_cast<float4*>(a.g + 16 * gi + k) = g4;
+        }
     }
-    if (live && h == 0) {
-        a.pixel_val[2 * i] = smp.grid[0]; a.pixel_val[2 * i + 1] = smp.grid[1];
-        a.pt[3 * i + 0] = smp.pt[0]; a.pt[3 * i + 1] = smp.pt[1]; a.pt[3 * i + 2] = smp.pt[2];
-    }
-    // B operand of the two K=16 layers fed by g (standard mapping: lanes 0-31 carry k = 0..15, lanes 32-63 carry the
-    // folded bias input k = 16 and zeros)
-    float gb[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) gb[k] = h == 0 ? smp.g[k] : (k == 0 ? 1.0f : 0.0f);
     __syncthreads();                                                   // tables and tap records visible
 
-    // ---- gather machinery: lane owns rows rr = (lane>>3) + 8*it (it = 0..3) and channel quad qd = lane & 7 of a chunk ----
+    // ---- gather machinery: lane owns rows rr = (lane>>3) + 8*it (it = 0, 1) and channel quad qd = lane & 7 of a chunk.
+    //      A batch = the 4 tap loads of one row group `it` at one level; two batches (bufA: it 0, bufB: it 1) are in flight. ----
     const int qd = lane & 7, r0 = lane >> 3;
-    float* stage = lds + kLdsStage + wave * 32 * kStageLd;
-    float4 hacc[4];                                                    // h of the chunk being gathered, 4 rows x float4
-    float4 tapA[16], tapB[16];                                         // two levels' worth of taps (4 rows x 4 taps) in flight
+    float* stage = lds + kLdsStage + wave * kRows * kStageLd;
+    float4 hacc[2];
+    f32x4 bufA[4], bufB[4];
+    const unsigned qd16 = 16u * qd;
+    const unsigned row_step[3] = {(unsigned)a.gw[0] * (kC * 4), (unsigned)a.gw[1] * (kC * 4), (unsigned)a.gw[2] * (kC * 4)};
 
-    // The gather of chunk c+1 is cut into per-row pieces that are dealt out between the 36 MFMA groups of chunk c (see
-    // the slot table in the chunk loop): a wave has ONE instruction stream, so anything not sitting between two MFMAs
-    // leaves the matrix pipe idle.
-    auto issue_row = [&](float4 (&tap)[16], int sv, int c, int l, int it) {          // 4 tap loads of one row
+    auto issue_row = [&](f32x4 (&tap)[4], int sv, int c, int l, int it) {
         if constexpr (ABL == 1 || ABL == 2 || ABL == 3) return;
-        if constexpr (ABL >= 5 && ABL <= 7) { if (l == 7 - ABL) return; }              // 5: no level-2 taps, 6: no level 1, 7: no level 0
-        const float* base = a.gmap[l] + 32 * c + 4 * qd;
-        const int* ti = reinterpret_cast<const int*>(lds + kLdsTapI) + ((wave * 32 + r0 + 8 * it) * 2 + sv) * 12 + 4 * l;
-        const int4 id = *reinterpret_cast<const int4*>(ti);
-        tap[4 * it + 0] = *reinterpret_cast<const float4*>(base + (long)id.x * kC);
-        tap[4 * it + 1] = *reinterpret_cast<const float4*>(base + (long)id.y * kC);
-        tap[4 * it + 2] = *reinterpret_cast<const float4*>(base + (long)id.z * kC);
-        tap[4 * it + 3] = *reinterpret_cast<const float4*>(base + (long)id.w * kC);
+        if constexpr (ABL == 9) { if (l == 0) return; }
+        if constexpr (ABL == 10) { if (l == 2 && c >= 2) return; }
+        if constexpr (ABL == 6) { if (r0 & 1) return; }
+        if constexpr (ABL == 7) { if (qd & 1) return; }
+        const char* base = reinterpret_cast<const char*>(a.gmap[l] + 32 * c);
+        // ABL 8: lane = (sample s, k group q4) as the MFMA's B operand wants it, the two row groups become the two 16-byte pieces
+        const int row = ABL == 8 ? s : r0 + 8 * it;
+        const unsigned col = ABL == 8 ? 16u * q4 + 64u * it : qd16;
+        const unsigned tbv = reinterpret_cast<const unsigned*>(lds + kLdsTapB)[((wave * kRows + row) * 2 + sv) * 3 + l];
+        const unsigned o00 = (tbv & ~3u) + col, dx = (tbv & 1u) ? (unsigned)(kC * 4) : 0u, dy = (tbv & 2u) ? row_step[l] : 0u;
+        tap[0] = *reinterpret_cast<const f32x4*>(base + o00);
+        tap[1] = *reinterpret_cast<const f32x4*>(base + (o00 + dx));
+        tap[2] = *reinterpret_cast<const f32x4*>(base + (o00 + dy));
+        tap[3] = *reinterpret_cast<const f32x4*>(base + (o00 + dx + dy));
     };
-    auto blend_row = [&](const float4 (&tap)[16], int sv, int l, int it) {           // hacc[it] += sum_t w_t tap_t
+    auto blend_row = [&](const f32x4 (&tap)[4], int sv, int l, int it) {
         if constexpr (ABL == 2 || ABL == 3) return;
-        const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * 32 + r0 + 8 * it) * 2 + sv) * 12 + 4 * l);
+        const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 12 + 4 * l);
         const float ww[4] = {w.x, w.y, w.z, w.w};
-        float4 acc4 = hacc[it];
+        f32x2 lo2 = {hacc[it].x, hacc[it].y}, hi2 = {hacc[it].z, hacc[it].w};          // v_pk_fma_f32: two FMAs per instruction
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float4 gq = tap[4 * it + t];
-            acc4.x = fmaf(ww[t], gq.x, acc4.x); acc4.y = fmaf(ww[t], gq.y, acc4.y);
-            acc4.z = fmaf(ww[t], gq.z, acc4.z); acc4.w = fmaf(ww[t], gq.w, acc4.w);
+            const f32x4 gq = tap[t];
+            const f32x2 w2 = {ww[t], ww[t]};
+            lo2 = __builtin_elementwise_fma(w2, f32x2{gq[0], gq[1]}, lo2);
+            hi2 = __builtin_elementwise_fma(w2, f32x2{gq[2], gq[3]}, hi2);
         }
-        hacc[it] = acc4;
+        hacc[it] = make_float4(lo2[0], lo2[1], hi2[0], hi2[1]);
     };
-    auto affine_row = [&](int sv, int c, int it) {                     // hacc[it] = Wpt tanh(pt_sv/5) + b1 (start value)
+    auto affine_row = [&](int sv, int c, int it) {
         if constexpr (ABL == 2 || ABL == 3) return;
         const int rr = r0 + 8 * it;
-        const float4 pe = *reinterpret_cast<const float4*>(lds + kLdsPe + ((wave * 32 + rr) * 2 + sv) * 4);
+        const float4 pe = *reinterpret_cast<const float4*>(lds + kLdsPe + ((wave * kRows + rr) * 2 + sv) * 4);
         const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 4 * (32 * c + 4 * qd));
         const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
         hacc[it] = make_float4(fmaf(w0.z, pe.z, fmaf(w0.y, pe.y, w0.x * pe.x)) + w0.w,
@@ -407,206 +209,192 @@ __global__ void __launch_bounds__(256, 1) fused_sample_kernel(const FusedArgs a)
                                fmaf(w2.z, pe.z, fmaf(w2.y, pe.y, w2.x * pe.x)) + w2.w,
                                fmaf(w3.z, pe.z, fmaf(w3.y, pe.y, w3.x * pe.x)) + w3.w);
     };
-    auto finish_row = [&](int it) {                                    // ReLU, into the wave's h tile
+    auto finish_row = [&](int it) {
         if constexpr (ABL == 2 || ABL == 3) return;
         const float4 o = hacc[it];
         *reinterpret_cast<float4*>(stage + (r0 + 8 * it) * kStageLd + 4 * qd) =
             make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
     };
+    // Scales of the split-fp16 arithmetic (car_fused_mma.h).  Packed weights carry 2^shift per layer (dW.. = 2^-shift, from the
+    // bias table).  h is bounded by the per-level maxima of the projected maps plus the point / bias term, because the tap
+    // weights of a level are non-negative and sum to at most one and |tanh| <= 1: one power of two hp for the whole launch.
+    const float* lsc = lds + kLdsBias + kBiasScale;
+    auto uniform = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };   // keep it in an SGPR
+    float hp, e_up, e_down;
+    {
+        float hinv;
+        pow2_scale(fmaxf(((a.gmeta[0] + a.gmeta[1]) + a.gmeta[2]) + lsc[5], 1e-30f), hp, hinv);
+        const float dW2 = lsc[kLayerW2];
+        e_up = uniform(hp / dW2); e_down = uniform(dW2 * hinv); hp = uniform(hp);
+    }
+    auto read_b = [&](half8& bhi, half8& blo) {                        // this lane's 8 channels of the wave's h tile, split
+        const float4 x0 = *reinterpret_cast<const float4*>(stage + s * kStageLd + 8 * q4);
+        const float4 x1 = *reinterpret_cast<const float4*>(stage + s * kStageLd + 8 * q4 + 4);
+        const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        split8(x, hp, bhi, blo);
+    };
 
-    // ---- e_s = W2 h_s + b2, then immediately its share of k1 = Wk1 [e_0 ; e_1] + bk1 (chained on the accumulators), then e_s
-    //      is stored and its registers are reused for the other source.  The gather of chunk cc+1 hides under the MFMAs of cc.
     // first chunk of source 0: nothing to hide it under
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < 2; ++it) {
         affine_row(0, 0, it);
 #pragma unroll
-        for (int l = 0; l < 3; ++l) { issue_row(tapA, 0, 0, l, it); blend_row(tapA, 0, l, it); }
+        for (int l = 2; l >= 0; --l) {
+            issue_row(bufA, 0, 0, l, it);
+            blend_row(bufA, 0, l, it);
+        }
         finish_row(it);
     }
     stream_sync();                                                     // weight chunk 0 landed
+    constexpr bool kTapsLive = (ABL == 0 || ABL >= 5);
+    issue_row(bufA, 0, 1, 2, 0);                                       // pipeline prologue: level 2 of chunk (0, 1), both row groups
+    issue_row(bufB, 0, 1, 2, 1);
 
-    f32x16 k1[kNTD];
-    init_bias<kNTD>(k1, lds + kLdsBias + kBiasK1, h);
-    if constexpr (PREC == 1) scale_acc<kNTD>(k1, (float)(1 << kWShift));
-    f32x16 acc[kNTE];
-    float bv[16];                                                      // B operands of the current chunk (this lane's 16 channels)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 x = *reinterpret_cast<const float4*>(stage + s * kStageLd + 16 * h + 4 * q);
-        bv[4 * q + 0] = x.x; bv[4 * q + 1] = x.y; bv[4 * q + 2] = x.z; bv[4 * q + 3] = x.w;
-    }
+    f32x4 acc[kTE];
+    float m0 = 0.0f;                                                   // largest |e_0| of this lane's sample
+    half8 bhi, blo;
+    read_b(bhi, blo);
 #pragma unroll 1
     for (int sv = 0; sv < 2; ++sv) {
-        init_bias<kNTE>(acc, lds + kLdsBias + kBiasE, h);
-        if constexpr (PREC == 1) {
-#pragma unroll
-            for (int t = 0; t < kNTE; ++t) acc[t] *= (float)(1 << kWShift);        // the packed weights carry 2^kWShift
-        }
+        init_bias<kTE>(acc, lds + kLdsBias + kBiasE, q4, e_up);
 #pragma unroll 1
-        for (int c = 0; c < kKT; ++c) {
-            // next chunk to gather: (sv, c+1), or (1, 0) after the last chunk of source 0.  Kept branch-free on purpose (a
-            // conditional gather makes hipcc copy the in-flight tap registers at the block boundary, i.e. wait for them
-            // before the MFMAs): after the very last chunk the gather harmlessly re-reads chunk (1, 0).
-            const int nsv = (c + 1 < kKT) ? sv : 1;
-            const int nc = (c + 1 < kKT) ? c + 1 : 0;
-            const float* wl = lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane;
+        for (int c = 0; c < kKS; ++c) {
+            // chunk being gathered: m+1 = (nsv, nc); level 2 of chunk m+2 = (n2sv, n2c) is issued at the end.  Branch-free on purpose:
+            // past the last chunk the gather harmlessly re-reads chunks of source 1.
+            const int nsv = (c + 1 < kKS) ? sv : 1;
+            const int nc = (c + 1 < kKS) ? c + 1 : 0;
+            const int n2sv = (c + 2 < kKS) ? sv : 1;
+            const int n2c = (c + 2 < kKS) ? c + 2 : c + 2 - kKS;
+            const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
             const NextChunk nx = next_chunk(a.blob, lds, g + 1);
-            // 36 groups of (one ds_read_b128 of weights + 4 dependent MFMAs); between them, one piece of the next chunk's
-            // gather or of the next weight chunk's DMA issue.  Slot table (level 2 = full resolution, the slowest to
-            // arrive, goes first):
-            //   0-3 issue L2 -> tapA    4-12 DMA tile 0..8    4-7 affine start values    12-15 issue L1 -> tapB
-            //   16-19 blend L2 (tapA)   20-23 issue L0 -> tapA    28-31 blend L1 (tapB)   32-35 blend L0, ReLU, LDS write
-            auto piece = [&](int gq) {            // slot gq = 0..35 of the chunk: one piece of the next chunk's gather / DMA issue
-                if constexpr (SCHED == 0) {
-                    if (gq >= 4 && gq < 13) stream_issue_tile<ABL>(nx, gq - 4, tid, wave);
-                    if (gq < 4) issue_row(tapA, nsv, nc, 2, gq);
-                    else if (gq < 8) affine_row(nsv, nc, gq - 4);
-                    else if (gq >= 12 && gq < 16) issue_row(tapB, nsv, nc, 1, gq - 12);
-                    else if (gq >= 16 && gq < 20) blend_row(tapA, nsv, 2, gq - 16);
-                    else if (gq >= 20 && gq < 24) issue_row(tapA, nsv, nc, 0, gq - 20);
-                    else if (gq >= 28 && gq < 32) blend_row(tapB, nsv, 1, gq - 28);
-                    else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
-                } else if constexpr (SCHED == 1) {
-                    // both big levels ahead of the DMA in the wave's in-order VMEM queue
-                    if (gq >= 8 && gq < 17) stream_issue_tile<ABL>(nx, gq - 8, tid, wave);
-                    if (gq < 4) issue_row(tapA, nsv, nc, 2, gq);
-                    else if (gq < 8) issue_row(tapB, nsv, nc, 1, gq - 4);
-                    else if (gq < 12) affine_row(nsv, nc, gq - 8);
-                    else if (gq >= 16 && gq < 20) blend_row(tapA, nsv, 2, gq - 16);
-                    else if (gq >= 20 && gq < 24) issue_row(tapA, nsv, nc, 0, gq - 20);
-                    else if (gq >= 24 && gq < 28) blend_row(tapB, nsv, 1, gq - 24);
-                    else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
-                } else if constexpr (SCHED == 3) {
-                    // one tap set in flight at a time (16 loads + the DMA): 8 slots of slack each
-                    if (gq >= 4 && gq < 13) stream_issue_tile<ABL>(nx, gq - 4, tid, wave);
-                    if (gq < 4) { issue_row(tapA, nsv, nc, 2, gq); affine_row(nsv, nc, gq); }
-                    else if (gq >= 8 && gq < 12) blend_row(tapA, nsv, 2, gq - 8);
-                    else if (gq >= 12 && gq < 16) issue_row(tapB, nsv, nc, 1, gq - 12);
-                    else if (gq >= 20 && gq < 24) blend_row(tapB, nsv, 1, gq - 20);
-                    else if (gq >= 24 && gq < 28) issue_row(tapA, nsv, nc, 0, gq - 24);
-                    else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
-                } else {
-                    // DMA first (3 tiles per slot), every tap batch 16 slots ahead of its consumer except level 0
-                    if (gq < 3) { stream_issue_tile<ABL>(nx, 3 * gq, tid, wave); stream_issue_tile<ABL>(nx, 3 * gq + 1, tid, wave); stream_issue_tile<ABL>(nx, 3 * gq + 2, tid, wave); }
-                    else if (gq < 7) issue_row(tapA, nsv, nc, 2, gq - 3);
-                    else if (gq < 11) issue_row(tapB, nsv, nc, 1, gq - 7);
-                    else if (gq < 15) affine_row(nsv, nc, gq - 11);
-                    else if (gq >= 20 && gq < 24) blend_row(tapA, nsv, 2, gq - 20);
-                    else if (gq >= 24 && gq < 28) { issue_row(tapA, nsv, nc, 0, gq - 24); blend_row(tapB, nsv, 1, gq - 24); }
-                    else if (gq >= 32) { blend_row(tapA, nsv, 0, gq - 32); finish_row(gq - 32); }
-                }
+            // 9 slots of (4 ds_read_b128 + 6 MFMAs of 16 cycles); between them one piece of the gather / DMA issue.  Batches (level, row
+            // group) in the order (2,0) (2,1) (1,0) (1,1) (0,0) (0,1); batch k is blended in slot {1,2,4,5,7,8}[k] and batch k+2 issued
+            // into the buffer it frees; slots 0-2 also carry the DMA pieces, slot 0 the affine start values.
+            auto piece = [&](int qs) {
+                if (qs < kPieces) stream_issue_piece<ABL>(nx, qs, lane, wave);
+                if (qs == 0) { affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); }
+                else if (qs == 1) { blend_row(bufA, nsv, 2, 0); issue_row(bufA, nsv, nc, 1, 0); }
+                else if (qs == 2) { blend_row(bufB, nsv, 2, 1); issue_row(bufB, nsv, nc, 1, 1); }
+                else if (qs == 4) { blend_row(bufA, nsv, 1, 0); issue_row(bufA, nsv, nc, 0, 0); }
+                else if (qs == 5) { blend_row(bufB, nsv, 1, 1); issue_row(bufB, nsv, nc, 0, 1); }
+                else if (qs == 7) { blend_row(bufA, nsv, 0, 0); finish_row(0); issue_row(bufA, n2sv, n2c, 2, 0); }
+                else if (qs == 8) { blend_row(bufB, nsv, 0, 1); finish_row(1); issue_row(bufB, n2sv, n2c, 2, 1); }
             };
-            if constexpr (PREC == 1) {
-                // split this lane's 16 activations (two 8-wide K groups) into fp16 high and low halves
-                half8 bhi[2], blo[2];
 #pragma unroll
-                for (int kg = 0; kg < 2; ++kg)
-#pragma unroll
-                    for (int e8 = 0; e8 < 8; ++e8) {
-                        const float x = bv[8 * kg + e8];
-                        const _Float16 hi = (_Float16)x;
-                        bhi[kg][e8] = hi;
-                        blo[kg][e8] = (_Float16)(x - (float)hi);
-                    }
-                // packed tile: [kg][hi|lo][lane][8 halves]; 18 slots of (two ds_read_b128, three MFMAs), two pieces each
-#pragma unroll
-                for (int t = 0; t < kNTE; ++t)
-#pragma unroll
-                    for (int kg = 0; kg < 2; ++kg) {
-                        const float4 ahf = *reinterpret_cast<const float4*>(wl + t * kTile + ((kg * 2 + 0) * 64) * 4);
-                        const float4 alf = *reinterpret_cast<const float4*>(wl + t * kTile + ((kg * 2 + 1) * 64) * 4);
-                        const half8 ah = __builtin_bit_cast(half8, ahf), al = __builtin_bit_cast(half8, alf);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[kg], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[kg], acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[kg], acc[t], 0, 0, 0);
-                        piece(2 * (t * 2 + kg));
-                        piece(2 * (t * 2 + kg) + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-            } else {
-            // MFMA order: for each 4-step group j4, steps e = 0..3 round-robin over the 9 output tiles, so consecutive MFMAs
-            // never share an accumulator (a VALU instruction between two MFMAs on the SAME accumulator costs ~40 extra
-            // cycles; between independent ones it is nearly free).  The A operand of tile t (4 steps = one ds_read_b128)
-            // is refreshed in place right after its last use, 8 MFMAs before it is needed again.
-            float4 aw[kNTE];
-#pragma unroll
-            for (int t = 0; t < kNTE; ++t) aw[t] = *reinterpret_cast<const float4*>(wl + (t * 4) * 256);
-#pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4)
-#pragma unroll
-            for (int qs = 0; qs < kNTE; ++qs) {                          // 9 slots per step group, 4 MFMAs each
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const int e = (4 * qs + k4) / kNTE, t = (4 * qs + k4) % kNTE;
-                    const float av = e == 0 ? aw[t].x : e == 1 ? aw[t].y : e == 2 ? aw[t].z : aw[t].w;
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[4 * j4 + e], acc[t], 0, 0, 0);
-                    if (e == 3 && j4 < 3) aw[t] = *reinterpret_cast<const float4*>(wl + (t * 4 + j4 + 1) * 256);
-                }
-                piece(j4 * kNTE + qs);
-                // Pin the slot (see chained_layer).  Measured on MI355X: with one wave per SIMD the gather's VALU/VMEM issue time
-                // is NOT hidden under the wave's own MFMAs (SQ_ACTIVE_INST_VALU adds 1:1 to SQ_WAVE_CYCLES), and spreading a
-                // piece over the four MFMA gaps with sched_group_barrier is slower than leaving it as one lump (9.4 vs 9.0 ms).
+            for (int qs = 0; qs < kTE / 2; ++qs) {
+                const float* w0 = wl + (2 * qs * 2) * 256;
+                if constexpr (ABL < 5) mfma_pair(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
+                piece(qs);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            }
-            // B operands of the next chunk: this wave's own LDS tile, written just above (LDS ops of a wave are in order);
-            // read before the barrier so the latency overlaps it
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 x = *reinterpret_cast<const float4*>(stage + s * kStageLd + 16 * h + 4 * q);
-                bv[4 * q + 0] = x.x; bv[4 * q + 1] = x.y; bv[4 * q + 2] = x.z; bv[4 * q + 3] = x.w;
-            }
-            stream_sync<ABL>();
+            read_b(bhi, blo);                                          // next chunk's B operand (own LDS tile, in-order LDS)
+            // the 8 tap loads issued in slots 7 and 8 (after the last DMA piece) stay in flight over the barrier
+            stream_sync<ABL, kTapsLive ? 8 : 0>();
             ++g;
         }
-        if constexpr (PREC == 1) {
-#pragma unroll
-            for (int t = 0; t < kNTE; ++t) acc[t] *= 1.0f / (float)(1 << kWShift);  // exact power of two
+        scale_acc<kTE>(acc, e_down);
+        if (sv == 0) {
+            m0 = sample_max<kTE, false>(acc);
+            if (live) store_rows<kTE>(acc, a.e + i * (2 * kE), q4);
         }
-        if constexpr (ABL == 4) { g += kChK1; }
-        else chained_layer<kNTE, false, ABL, PREC>(k1, acc, a.blob, lds, g, tid, wave, lane);
-        if (live) store_rows<kNTE>(acc, a.e + i * (2 * kE) + sv * kE, h);
     }
-    f32x16 key[kNTD];
-    init_bias<kNTD>(key, lds + kLdsBias + kBiasK2, h);
-    if constexpr (PREC == 1) { scale_acc<kNTD>(k1, 1.0f / (float)(1 << kWShift)); scale_acc<kNTD>(key, (float)(1 << kWShift)); }
-    if constexpr (ABL != 4) chained_layer<kNTD, true, ABL, PREC>(key, k1, a.blob, lds, g, tid, wave, lane);
-    else g += 2;
-    if constexpr (PREC == 1) scale_acc<kNTD>(key, 1.0f / (float)(1 << kWShift));
+    // ---- k1 = Wk1 [e_0 ; e_1] + bk1: first the e_1 half, chained from the accumulators; then e_1 is stored and its registers take
+    //      e_0 back from the output tensor (written by this wave one source pass ago: L2), same layout, for the other half ----
+    //      Both halves accumulate into the same registers, so they share one per-sample power of two (from max |e_0|, |e_1|).
+    float p, pinv;
+    pow2_scale(fmaxf(fmaxf(m0, sample_max<kTE, false>(acc)), 1e-30f), p, pinv);
+    f32x4 k1[kTD];
+    init_bias<kTD>(k1, lds + kLdsBias + kBiasK1, q4, p / lsc[kLayerK1]);
+    chained_layer<kTE, false, ABL>(k1, acc, p, a.blob, lds, g, lane, wave);
+    if (live) store_rows<kTE>(acc, a.e + i * (2 * kE) + kE, q4);
+#pragma unroll
+    for (int t = 0; t < kTE; ++t) acc[t] = *reinterpret_cast<const f32x4*>(a.e + i * (2 * kE) + 16 * t + 4 * q4);
+    chained_layer<kTE, false, ABL>(k1, acc, p, a.blob, lds, g, lane, wave);
+    scale_acc<kTD>(k1, lsc[kLayerK1] * pinv);
+    f32x4 key[kTD];
+    pow2_scale(fmaxf(sample_max<kTD, true>(k1), 1e-30f), p, pinv);
+    init_bias<kTD>(key, lds + kLdsBias + kBiasK2, q4, p / lsc[kLayerK2]);
+    chained_layer<kTD, true, ABL>(key, k1, p, a.blob, lds, g, lane, wave);
+    scale_acc<kTD>(key, lsc[kLayerK2] * pinv);
 
-    // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ;  ug = Wr1[:,128:] g + br1 ---------------------
-    f32x16 t1[kNTD], qv[kNTD];
+    // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ---------------------------------------------------
+    half8 ghi, glo;                                                    // B operand of the layer fed by g (k = 16: folded bias)
+    {
+        const float* gl = lds + kLdsG + (wave * kRows + s) * 16 + 8 * (q4 & 1);
+        float gx8[8];
 #pragma unroll
-    for (int t = 0; t < kNTD; ++t)
+        for (int k = 0; k < 8; ++k) gx8[k] = q4 < 2 ? gl[k] : (q4 == 2 && k == 0) ? 1.0f : 0.0f;
+        float m = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t1[t][r] = 0.0f;
-    stream_issue(a.blob, lds, g + 1, tid, wave);
-    mfma_tiles<kNTD, 0, kNTD>(t1, gb, lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane);          // q1 (bias folded)
-    stream_sync();
+        for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(gx8[k]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));                           // >= 1: the bias column
+        pow2_scale(m, p, pinv);
+        split8(gx8, p, ghi, glo);
+    }
+    f32x4 t1[kTD], qv[kTD];
+#pragma unroll
+    for (int t = 0; t < kTD; ++t) t1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stream_issue_all<ABL>(a.blob, lds, g + 1, lane, wave);
+    small_layer(t1, ghi, glo, lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane);          // q1
+    stream_sync<ABL>();
     ++g;
-    init_bias<kNTD>(qv, lds + kLdsBias + kBiasQ2, h);
-    if constexpr (PREC == 1) scale_acc<kNTD>(qv, (float)(1 << kWShift));
-    if constexpr (ABL != 4) chained_layer<kNTD, true, ABL, PREC>(qv, t1, a.blob, lds, g, tid, wave, lane);   // qry
-    else g += 2;
-    if constexpr (PREC == 1) scale_acc<kNTD>(qv, 1.0f / (float)(1 << kWShift));
+    scale_acc<kTD>(t1, lsc[kLayerQ1] * pinv);
+    pow2_scale(fmaxf(sample_max<kTD, true>(t1), 1e-30f), p, pinv);
+    init_bias<kTD>(qv, lds + kLdsBias + kBiasQ2, q4, p / lsc[kLayerQ2]);
+    chained_layer<kTD, true, ABL>(qv, t1, p, a.blob, lds, g, lane, wave);
+    scale_acc<kTD>(qv, lsc[kLayerQ2] * pinv);
     float dot = 0.0f;
 #pragma unroll
-    for (int t = 0; t < kNTD; ++t)
+    for (int t = 0; t < kTD; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dot = fmaf(key[t][r], qv[t][r], dot);
-    dot += __shfl_xor(dot, 32, 64);                                    // the other lane half holds the other channels
+        for (int r = 0; r < 4; ++r) dot = fmaf(key[t][r], qv[t][r], dot);
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
     if (live) {
-        store_rows<kNTD>(qv, a.qry + i * kD, h);
-        if (h == 0) a.logit[i] = dot / 16.0f;
+        store_rows<kTD>(qv, a.qry + i * kD, q4);
+        if (q4 == 0) a.logit[i] = dot / 16.0f;
     }
-#pragma unroll
-    for (int t = 0; t < kNTD; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t1[t][r] = 0.0f;
-    stream_issue(a.blob, lds, g + 1, tid, wave);                       // past the last chunk: no-op
-    mfma_tiles<kNTD, 0, kNTD>(t1, gb, lds + kLdsW + (g & 1) * kNTE * kTile + 4 * lane);          // ug (bias folded)
-    if (live) store_rows<kNTD>(t1, a.ug + i * kD, h);
+}
+
+
+int launch_fused(int abl, const float* poses, const float* rays, const float* steps, const float* const* gmaps, const int* level_h,
+                 const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,
+                 int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+    CAR_REQUIRE(poses && rays && steps && gmaps && level_h && level_w && gmeta && wpt && blob && bias, "car_fused_samples: null input");
+    CAR_REQUIRE(e && qry && g && logit && pt && pixel_val, "car_fused_samples: null output");
+    CAR_REQUIRE(n_levels == 3 && C == kC && V == 2, "car_fused_samples: built for 3 pyramid levels, C = %d, V = 2 (got %d, %d, %d)", kC, n_levels, C, V);
+    CAR_REQUIRE(b > 0 && R > 0 && P > 0 && H > 1 && W > 1, "car_fused_samples: bad sizes");
+    FusedArgs a;
+    a.poses = (const CarPose*)poses; a.rays = (const CarRay*)rays; a.steps = steps;
+    for (int l = 0; l < 3; ++l) {
+        a.gmap[l] = gmaps[l]; a.gh[l] = level_h[l]; a.gw[l] = level_w[l];
+        // texel rows are addressed by 32-bit byte offsets inside a level; hosts with more scenes render them in groups (engine.py)
+        CAR_REQUIRE(a.gmap[l] && a.gh[l] > 0 && a.gw[l] > 0 && (long)b * V * a.gh[l] * a.gw[l] * (kC * 4) < 4294967296L,
+                    "car_fused_samples: bad level %d (a level's projected map must stay below 4 GiB per call: render fewer scenes per call)", l);
+    }
+    a.gmeta = gmeta; a.wpt = wpt; a.blob = blob; a.bias = bias;
+    a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
+    a.S = (long)b * V * R * P;
+    a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
+    const long groups = (long)b * V * car_div_up(R, kBundles * kRows) * car_div_up(P, kStepsPerGroup);
+    void (*kern)(const FusedArgs) = fused_kernel<0>;
+#ifdef CAR_ABLATION
+    switch (abl) {
+        case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
+        case 5: kern = fused_kernel<5>; break;   case 6: kern = fused_kernel<6>; break;   case 7: kern = fused_kernel<7>; break;
+        case 8: kern = fused_kernel<8>; break;   case 9: kern = fused_kernel<9>; break;   case 10: kern = fused_kernel<10>; break;
+        default: break;
+    }
+#else
+    (void)abl;
+#endif
+    hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e1 != hipSuccess) { car_set_error("car_fused_samples: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(768), kLdsBytes, (hipStream_t)stream, a);
+    CAR_CHECK_LAUNCH("car_fused_samples");
+    return CAR_OK;
 }
 
 }  // namespace
@@ -615,41 +403,20 @@ extern "C" size_t car_fused_blob_floats(void) { return (size_t)kBlobTiles * kTil
 extern "C" size_t car_fused_bias_floats(void) { return (size_t)kBiasFloats; }
 
 extern "C" int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                                 const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
-                                 const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                                 float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, int prec,
-                                 void* stream) {
-    CAR_REQUIRE(poses && rays && steps && gmaps && level_h && level_w && wpt && blob && bias, "car_fused_samples: null input");
-    CAR_REQUIRE(e && qry && ug && logit && pt && pixel_val, "car_fused_samples: null output");
-    CAR_REQUIRE(n_levels == 3 && C == kC && V == 2, "car_fused_samples: built for 3 pyramid levels, C = %d, V = 2 (got %d, %d, %d)", kC, n_levels, C, V);
-    CAR_REQUIRE(b > 0 && R > 0 && P > 0 && H > 1 && W > 1, "car_fused_samples: bad sizes");
-    FusedArgs a;
-    a.poses = (const CarPose*)poses; a.rays = (const CarRay*)rays; a.steps = steps;
-    for (int l = 0; l < 3; ++l) {
-        a.gmap[l] = gmaps[l]; a.gh[l] = level_h[l]; a.gw[l] = level_w[l];
-        CAR_REQUIRE(a.gmap[l] && a.gh[l] > 0 && a.gw[l] > 0 && (long)b * V * a.gh[l] * a.gw[l] < 2147483647L, "car_fused_samples: bad level %d", l);
-    }
-    a.wpt = wpt; a.blob = blob; a.bias = bias;
-    a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
-    a.S = (long)b * V * R * P;
-    const char* xb = getenv("CAR_FUSED_XCD_BANDS");
-    a.xcd_bands = xb ? atoi(xb) : 1;
-    a.e = e; a.qry = qry; a.ug = ug; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
-    CAR_REQUIRE(prec == 0 || prec == 1, "car_fused_samples: prec must be 0 (fp32 MFMA) or 1 (split fp16 MFMA)");
-    a.prec = prec;
-    const char* abl_env = getenv("CAR_FUSED_ABLATE");
-    const int abl = abl_env ? atoi(abl_env) : 0;
-    const char* sch_env = getenv("CAR_FUSED_SCHED");
-    const int sch = sch_env ? atoi(sch_env) : 1;
-    void (*kern)(const FusedArgs) = (prec == 1 && abl == 0) ? fused_sample_kernel<0, 1, 1> : (prec == 1 && abl == 1) ? fused_sample_kernel<1, 1, 1>
-                                    : (prec == 1 && abl == 2) ? fused_sample_kernel<2, 1, 1> : (prec == 1 && abl == 3) ? fused_sample_kernel<3, 1, 1>
-                                    : (prec == 1 && abl == 4) ? fused_sample_kernel<4, 1, 1> : (abl == 0 && sch == 1) ? fused_sample_kernel<0, 1> : (abl == 0 && sch == 2) ? fused_sample_kernel<0, 2> : (abl == 0 && sch == 0) ? fused_sample_kernel<0, 0> : (abl == 0 && sch == 3) ? fused_sample_kernel<0, 3> : abl == 1 ? fused_sample_kernel<1> : abl == 2 ? fused_sample_kernel<2> : abl == 3 ? fused_sample_kernel<3>
-                                    : abl == 4 ? fused_sample_kernel<4> : abl == 5 ? fused_sample_kernel<5> : abl == 6 ? fused_sample_kernel<6>
-                                    : abl == 7 ? fused_sample_kernel<7> : fused_sample_kernel<0>;
-    hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-    if (e1 != hipSuccess) { car_set_error("car_fused_samples: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(kern, dim3(car_div_up(a.S, 128)), dim3(256), kLdsBytes, (hipStream_t)stream, a);
-    CAR_CHECK_LAUNCH("car_fused_samples");
-    return CAR_OK;
+                                 const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
+                                 const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                                 float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+    return launch_fused(0, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
+                        logit, pt, pixel_val, stream);
 }
+
+#ifdef CAR_ABLATION
+// development build only (tools/build_dev.py): timing-only variants of the kernel, results are wrong by construction
+extern "C" int car_fused_samples_ablate(int abl, const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                                        const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
+                                        const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                                        float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+    return launch_fused(abl, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
+                        logit, pt, pixel_val, stream);
+}
+#endif

@@ -1,37 +1,25 @@
-// car_fused16.h — pieces shared by the fused per-sample kernels built on v_mfma_f32_16x16x32_f16 tiles (car_fused2.hip,
-// car_fused4.hip): layer / blob constants, the LDS-DMA weight stream, the split-fp16 helpers and the chained layers.
-// Included INSIDE each kernel file's anonymous namespace, after it has defined kWaves (waves per workgroup = DMA participants)
+// car_fused_mma.h — matrix-pipe pieces of the fused per-sample kernel (car_fused.hip), built on v_mfma_f32_16x16x32_f16 tiles:
+// layer / blob constants, the LDS-DMA weight stream, the split-fp16 helpers and the chained layers.
+// Included INSIDE the kernel file's anonymous namespace, after it has defined kWaves (waves per workgroup = DMA participants)
 // and kPieces (LDS-DMA pieces per chunk = ceil(36 / kWaves)); the kernel file then defines chunk_tile_offset / chunk_tiles
-// (its order of the 52 weight chunks) and carves its own LDS beyond the two weight buffers.
+// (its order of the weight chunks) and carves its own LDS beyond the two weight buffers.
+//
+// Split-fp16 arithmetic: x = hi + lo with fp16 halves, three products per term (hi*hi + hi*lo + lo*hi, fp32 accumulate; the
+// dropped lo*lo is 2^-22 relative).  fp16 keeps 11 bits only between 2^-14 and 65504, so both operands are moved into that
+// window by powers of two, undone exactly on the fp32 side: a layer's weights carry 2^shift chosen at pack time from the layer's
+// largest weight (car_plan_build), the activations a power of two chosen from their largest magnitude — per sample for the
+// chained layers (the whole input vector sits in registers), per launch for the first layer (bounded by the maxima of the
+// projected maps) — so that the largest value lands in [2^13, 2^14): no overflow, and everything within 2^-17 of the largest
+// value keeps its full 22 bits.
 #pragma once
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int kWShift = 8;
+#include "car_fused_layout.h"
 
-constexpr int kC = 576;            // feature channels = width of h
-constexpr int kE = 288;            // per-source width of e
-constexpr int kD = 128;            // hidden width of the key / query MLPs
-constexpr int kKS = kC / 32;       // 18 K steps (= weight chunks) of the 576 -> 288 layer
-constexpr int kTE = kE / 16;       // 18 output tiles of 16 channels
-constexpr int kTD = kD / 16;       // 8 output tiles
-constexpr int kTile = 512;         // packed floats per (K step, tile): [hi|lo][64 lanes][8 halves] = 2 KB
 constexpr int kStageLd = 36;       // row stride of the wave-private h tile (floats)
-
-// ---- packed-weight blob: offsets in tiles, layer by layer, [K step][tile] inside a layer ---------------------------
-constexpr int kOffW2 = 0;                          // 18 steps x 18 tiles, standard K mapping
-constexpr int kOffQ1 = kOffW2 + kKS * kTE;         // 1 x 8, standard, bias folded at k = 16
-constexpr int kOffQ2 = kOffQ1 + kTD;               // 4 x 8, chained
-constexpr int kOffUG = kOffQ2 + 4 * kTD;           // 1 x 8, standard, bias folded
-constexpr int kOffK1 = kOffUG + kTD;               // 18 x 8, chained over [e_0 ; e_1] (9 steps per source)
-constexpr int kOffK2 = kOffK1 + 18 * kTD;          // 4 x 8, chained
-constexpr int kBlobTiles = kOffK2 + 4 * kTD;
-constexpr int kNumChunks = 2 * kKS + 2 * 5 + 2 + 1 + 2 + 1;           // 52 weight chunks per pass, same order as car_fused.hip
-constexpr int kChunkTiles = kTE;                   // largest chunk: 18 tiles = 36 KB
-
-constexpr int kBiasE = 0, kBiasQ2 = kE, kBiasK1 = kE + kD, kBiasK2 = kE + 2 * kD, kBiasFloats = kE + 3 * kD;
 
 // ---- dynamic LDS carve-up (floats) --------------------------------------------------------------------------------
 constexpr int kLdsW = 0;                                        // [2][18][512]           weight chunks          72 KB
@@ -53,7 +41,7 @@ __device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, 
 // LDS-DMA in inline asm, see car_linear.hip.  Must only run after the barrier that retired the buffer's previous chunk.
 template <int ABL = 0>
 __device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, int lane, int wave) {
-    if constexpr (ABL == 3 || ABL == 5) return;
+    if constexpr (ABL == 3 || ABL >= 5) return;
     int kb = kWaves * p + wave;
     kb = kb < n.nkb ? kb : kb - n.nkb;
     kb = kb < n.nkb ? kb : kb - n.nkb;
@@ -75,7 +63,7 @@ __device__ __forceinline__ void stream_issue_all(const float* __restrict__ blob,
 // order, so "at most KEEP outstanding" still means every DMA piece has landed).
 template <int ABL = 0, int KEEP = 0>
 __device__ __forceinline__ void stream_sync() {
-    if constexpr (ABL == 3 || ABL == 5) return;
+    if constexpr (ABL == 3 || ABL >= 5) return;
     if constexpr (KEEP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -84,16 +72,36 @@ __device__ __forceinline__ void stream_sync() {
 
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// x = hi + lo in fp16 halves.  The halves are rounded toward zero (v_cvt_pkrtz_f16_f32 converts two values per instruction):
-// x - hi is exact in fp32 and |x - hi - lo| < 2^-20 |x|, still fp32-class after the three-product MFMA.
-__device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
+// x * p = hi + lo in fp16 halves, p a power of two chosen by the caller so that the products stay inside fp16's normal range.
+// The halves are rounded toward zero (v_cvt_pkrtz_f16_f32 converts two values per instruction): x p - hi is exact in fp32 and
+// |x p - hi - lo| < 2^-20 |x p|, still fp32-class after the three-product MFMA.
+__device__ __forceinline__ void split8(const float (&x)[8], float p, half8& hi, half8& lo) {
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
-        const fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(x[e], x[e + 1]);
-        const fp16x2 l2 = __builtin_amdgcn_cvt_pkrtz(x[e] - (float)h2[0], x[e + 1] - (float)h2[1]);
+        const float a = x[e] * p, b = x[e + 1] * p;
+        const fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(a, b);
+        const fp16x2 l2 = __builtin_amdgcn_cvt_pkrtz(a - (float)h2[0], b - (float)h2[1]);
         hi[e] = (_Float16)h2[0]; hi[e + 1] = (_Float16)h2[1];
         lo[e] = (_Float16)l2[0]; lo[e + 1] = (_Float16)l2[1];
     }
+}
+// power of two p with m p in [2^13, 2^14) for m > 0 (exponent clamped for tiny / huge m), and inv = 1 / p
+__device__ __forceinline__ void pow2_scale(float m, float& p, float& inv) {
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    e = e < 40 ? 40 : (e > 230 ? 230 : e);
+    p = __uint_as_float((unsigned)(267 - e) << 23);
+    inv = __uint_as_float((unsigned)(e - 13) << 23);
+}
+// largest magnitude of a sample's values: the sample's row is spread over NT x 4 registers of the four lanes (s, q = 0..3)
+template <int NT, bool RELU>
+__device__ __forceinline__ float sample_max(const f32x4 (&v)[NT]) {
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, RELU ? v[t][r] : fabsf(v[t][r]));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    return fmaxf(m, __shfl_xor(m, 32, 64));
 }
 
 // two output tiles x three split products, interleaved so consecutive MFMAs never share an accumulator
@@ -108,27 +116,6 @@ __device__ __forceinline__ void mfma_pair(f32x4& c0, f32x4& c1, const float* w0,
     c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blo, c1, 0, 0, 0);
     c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bhi, c0, 0, 0, 0);
     c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bhi, c1, 0, 0, 0);
-}
-
-// the same with the A operands (two tiles, hi and lo) read one slot ahead: a ds_read_b128 issued right before its MFMAs
-// exposes the LDS latency (~100+ cycles) in every slot, and the scheduling barriers keep hipcc from hoisting it
-struct AHi { float4 h0, h1; };
-__device__ __forceinline__ AHi load_ahi(const float* w0) {
-    AHi a;
-    a.h0 = *reinterpret_cast<const float4*>(w0);
-    a.h1 = *reinterpret_cast<const float4*>(w0 + 512);
-    return a;
-}
-// the hi halves come from the previous slot; the lo halves are read now and first used by the fifth MFMA (64 cycles later)
-__device__ __forceinline__ void mfma_ahead(f32x4& c0, f32x4& c1, const AHi& a, const float* w0, const half8& bhi, const half8& blo) {
-    const float4 l0 = *reinterpret_cast<const float4*>(w0 + 256), l1 = *reinterpret_cast<const float4*>(w0 + 512 + 256);
-    const half8 ah0 = __builtin_bit_cast(half8, a.h0), ah1 = __builtin_bit_cast(half8, a.h1);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhi, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhi, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blo, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blo, c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, l0), bhi, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, l1), bhi, c1, 0, 0, 0);
 }
 
 // accumulators start at bias * scale: lane (s, q) register r of tile t holds channel 16 t + 4 q + r
@@ -152,9 +139,10 @@ __device__ __forceinline__ void store_rows(const f32x4 (&acc)[NT], float* row, i
         *reinterpret_cast<float4*>(row + 16 * t + 4 * q) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
 }
 
-// one chained layer with 128 outputs over NSRC source tiles (two per K step), weight chunks of two K steps
-template <int NSRC, bool RELU, int ABL, bool AHEAD = true>
-__device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&src)[NSRC], const float* __restrict__ blob,
+// one chained layer with 128 outputs over NSRC source tiles (two per K step), weight chunks of two K steps; the source values
+// are multiplied by the power of two p on their way into the fp16 split
+template <int NSRC, bool RELU, int ABL>
+__device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&src)[NSRC], float p, const float* __restrict__ blob,
                                               float* lds, int& g, int lane, int wave) {
     constexpr int kSteps = NSRC / 2;
 #pragma unroll
@@ -173,19 +161,11 @@ __device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&s
                     if (RELU) x[e] = fmaxf(x[e], 0.f);
                 }
                 half8 bhi, blo;
-                split8(x, bhi, blo);
-                AHi an;
-                if constexpr (AHEAD) an = load_ahi(wl + ((kl * kTD) * 2) * 256);
+                split8(x, p, bhi, blo);
 #pragma unroll
                 for (int q = 0; q < kTD / 2; ++q) {
                     const float* w0 = wl + ((kl * kTD + 2 * q) * 2) * 256;
-                    if constexpr (AHEAD) {                             // weight operands read one slot ahead (needs 8 registers)
-                        const AHi ac = an;
-                        if (q + 1 < kTD / 2) an = load_ahi(w0 + 4 * 256);
-                        mfma_ahead(acc[2 * q], acc[2 * q + 1], ac, w0, bhi, blo);
-                    } else {
-                        mfma_pair(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, bhi, blo);
-                    }
+                    mfma_pair(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, bhi, blo);
                     if (kl * 4 + q < kPieces) stream_issue_piece<ABL>(nx, kl * 4 + q, lane, wave);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -193,7 +173,7 @@ __device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&s
         }
         // a single-step chunk has only 4 slots: issue the remaining pieces of its successor here
 #pragma unroll
-        for (int p = nks * 4; p < kPieces; ++p) stream_issue_piece<ABL>(nx, p, lane, wave);
+        for (int p_ = nks * 4; p_ < kPieces; ++p_) stream_issue_piece<ABL>(nx, p_, lane, wave);
         stream_sync<ABL>();
         ++g;
     }

@@ -1,33 +1,68 @@
 // car_render.hip — the one-call forward of the C ABI (include/car_hip.h: car_plan_*, car_project_maps, car_render_forward).
 //
-// Host-side C++ only (plus three trivial re-layout kernels): it carves the caller's plan / workspace buffers and issues the
-// same launch sequence as cross_attention_renderer_amd/engine.py::RenderEngine._render_fused + _finish for the reference's
-// default configuration, so that a host without Python gets `CrossAttentionRenderer.forward(input, z=z)`
-// (reference models.py:190-626) from plain pointers.  tests/test_hip_parity.py checks it bit for bit against the Python engine.
+// Host-side C++ (plus small re-layout / reduction kernels): it carves the caller's plan / workspace buffers, packs every layer
+// into the operand order of the kernels that consume it, and issues the launch sequence of the default configuration
+// (CrossAttentionRenderer(model="midas_vit", n_view=2), reference models.py:190-626) from plain pointers.  This IS the product
+// path: cross_attention_renderer_amd/engine.py calls it for that configuration (its own stage-by-stage sequence covers the
+// constructor variants and serves as the A/B partner in tests/test_hip_parity.py).
 #include "car_common.h"
 #include <math.h>
 #include <string.h>
+#include <vector>
 
-extern "C" size_t car_fused2_blob_floats(void);
+extern "C" size_t car_fused_blob_floats(void);
 extern "C" size_t car_fused_bias_floats(void);
+extern "C" size_t car_round2_packed_floats(void);
+extern "C" size_t car_round2_bias_floats(void);
 
 namespace {
 
-constexpr int kC = 576, kE = 288, kD = 128, kPhiIn = 18, kPhiLd = 20, kBlocks = 3;
-constexpr int kWShift = 8;                         // the split-fp16 weights carry 2^8 (car_fused.hip)
-constexpr int kTile16 = 512;                       // floats per (K step, 16-channel tile) of the car_fused2.hip blob
-// tile offsets of the layers inside that blob (car_fused16.h): W2 | Q1 | Q2 | UG | K1 (source 0, source 1) | K2
-constexpr int kOffW2 = 0, kOffQ1 = 324, kOffQ2 = 332, kOffUG = 364, kOffK1 = 372, kOffK2 = 516;
+#include "car_fused_layout.h"
+
+constexpr int kPhiIn = 18, kPhiLd = 20, kBlocks = 3;
+constexpr int kTile16 = kTile;                     // floats per (K step, 16-channel tile) of the fused kernel's blob
 
 inline size_t up64(size_t x) { return (x + 63) & ~(size_t)63; }
 
+// power of two p with m p in [2^13, 2^14) (the window of the split-fp16 operands, car_fused_mma.h)
+__device__ __forceinline__ float pow2_for(float m) {
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    e = e < 40 ? 40 : (e > 230 ? 230 : e);
+    return __uint_as_float((unsigned)(267 - e) << 23);
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x + 63) / 64; ++w) m = fmaxf(m, red[w]);
+    __syncthreads();
+    return m;
+}
+
 // ---- re-layout kernels ---------------------------------------------------------------------------------------------
-// A-operand tiles of v_mfma_f32_16x16x32_f16 with fp16 hi/lo halves (engine._pack_tiles16_f16_split): per (K step, tile)
-// [hi|lo][lane][8 halves]; lane l carries output 16 t + l % 16 and k = 32 ks + 8 (l >> 4) + e (mode 0) or the accumulator
-// order base + 16 (2 ks + e / 4) + 4 (l >> 4) + e % 4 (mode 1); k == K selects the bias, k > K a zero.
+// Scale of a packed layer: p = 2^shift from the largest |weight| (and |bias| where the bias is folded in as a column);
+// p goes to p_slot (read by the pack kernels), 1/p to down_slot (read by the consuming kernel).  One workgroup.
+__global__ void layer_scale_kernel(const float* __restrict__ W, int ldw, int N, int K, const float* __restrict__ bias,
+                                   float* __restrict__ p_slot, float* __restrict__ down_slot) {
+    __shared__ float red[16];
+    float m = 0.0f;
+    for (long idx = threadIdx.x; idx < (long)N * K; idx += blockDim.x) m = fmaxf(m, fabsf(W[(idx / K) * ldw + idx % K]));
+    if (bias) for (int n = threadIdx.x; n < N; n += blockDim.x) m = fmaxf(m, fabsf(bias[n]));
+    m = block_max(m, red);
+    if (threadIdx.x == 0) {
+        const float p = pow2_for(fmaxf(m, 1e-30f));
+        p_slot[0] = p;
+        down_slot[0] = 1.0f / p;
+    }
+}
+// A-operand tiles of v_mfma_f32_16x16x32_f16 with fp16 hi/lo halves: per (K step, tile) [hi|lo][lane][8 halves]; lane l carries
+// output 16 t + l % 16 and k = 32 ks + 8 (l >> 4) + e (mode 0) or the accumulator order base + 16 (2 ks + e / 4) + 4 (l >> 4) + e % 4
+// (mode 1); k == K selects the bias, k > K a zero.  Values are multiplied by the layer's power of two *p_slot.
 __global__ void pack16_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ bias, int N, int K, int n_tiles,
-                              int ksteps, int mode, int base, _Float16* __restrict__ out) {
+                              int ksteps, int mode, int base, const float* __restrict__ p_slot, _Float16* __restrict__ out) {
     const long total = (long)ksteps * n_tiles * 512;
+    const float p = p_slot[0];
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
         const long tile = idx >> 9;
@@ -36,8 +71,8 @@ __global__ void pack16_kernel(const float* __restrict__ W, int ldw, const float*
         const int k = mode == 0 ? 32 * ks + 8 * q + e : base + 16 * (2 * ks + e / 4) + 4 * q + e % 4;
         float w = 0.0f;
         if (n < N) {
-            if (k < K) w = W[(long)n * ldw + k] * (float)(1 << kWShift);
-            else if (k == K && bias) w = bias[n] * (float)(1 << kWShift);
+            if (k < K) w = W[(long)n * ldw + k] * p;
+            else if (k == K && bias) w = bias[n] * p;
         }
         const _Float16 hi = (_Float16)w;
         const _Float16 lo = (_Float16)(w - (float)hi);
@@ -46,27 +81,48 @@ __global__ void pack16_kernel(const float* __restrict__ W, int ldw, const float*
         o[512] = lo;
     }
 }
-// query_repeat_embed_2 for car_round2.hip (engine.pack_round2_weights): [chunk 4][tile 4][K group 2][hi|lo][lane][8 halves],
-// output 32 t + l % 32, k = 32 c + 16 (l >> 5) + 8 kg + e
-__global__ void pack32_kernel(const float* __restrict__ W, _Float16* __restrict__ out) {
-    const int total = 4 * 4 * 2 * 2 * 64 * 8;
+// A-operand tiles of v_mfma_f32_32x32x16_f16 for car_round2.hip: [chunk][tile 4][K group kgs][hi|lo][lane][8 halves], output
+// 32 t + l % 32; chained = 1: k = 32 c + (e & 3) + 8 (2 kg + (e >> 2)) + 4 (l >> 5) (the accumulator order of the layer before),
+// chained = 0: k = 16 c + 8 (l >> 5) + e with one K group per chunk.
+__global__ void pack32_kernel(const float* __restrict__ W, int ldw, int chunks, int kgs, int chained, const float* __restrict__ p_slot,
+                              _Float16* __restrict__ out) {
+    const int total = chunks * 4 * kgs * 2 * 64 * 8;
+    const float p = p_slot[0];
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int e = idx & 7, lane = (idx >> 3) & 63, hl = (idx >> 9) & 1, kg = (idx >> 10) & 1, t = (idx >> 11) & 3, c = idx >> 13;
-        const int n = 32 * t + (lane & 31), k = 32 * c + 16 * (lane >> 5) + 8 * kg + e;
-        const float w = W[n * kD + k] * (float)(1 << kWShift);
+        const int e = idx & 7, lane = (idx >> 3) & 63, hl = (idx >> 9) & 1;
+        int rest = idx >> 10;
+        const int kg = rest % kgs; rest /= kgs;
+        const int t = rest & 3, c = rest >> 2;
+        const int n = 32 * t + (lane & 31);
+        const int k = chained ? 32 * c + (e & 3) + 8 * (2 * kg + (e >> 2)) + 4 * (lane >> 5) : 16 * c + 8 * (lane >> 5) + e;
+        const float w = W[n * ldw + k] * p;
         const _Float16 hi = (_Float16)w;
         out[idx] = hl == 0 ? hi : (_Float16)(w - (float)hi);
     }
 }
-// [C][4] table (W1[:, C:C+3], b1) of the per-texel first layer
-__global__ void wpt_kernel(const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ wpt) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+// [C][4] table (W1[:, C:C+3], b1) of the per-texel first layer, and the largest row sum of magnitudes (bounds the point / bias
+// term of h because |tanh| <= 1).  One workgroup of kC threads.
+__global__ void wpt_kernel(const float* __restrict__ w1, const float* __restrict__ b1, float* __restrict__ wpt, float* __restrict__ bound) {
+    __shared__ float red[16];
+    const int ch = threadIdx.x;
+    float m = 0.0f;
     if (ch < kC) {
-        wpt[4 * ch + 0] = w1[(long)ch * (kC + 3) + kC + 0];
-        wpt[4 * ch + 1] = w1[(long)ch * (kC + 3) + kC + 1];
-        wpt[4 * ch + 2] = w1[(long)ch * (kC + 3) + kC + 2];
-        wpt[4 * ch + 3] = b1[ch];
+        const float x = w1[(long)ch * (kC + 3) + kC + 0], y = w1[(long)ch * (kC + 3) + kC + 1], z = w1[(long)ch * (kC + 3) + kC + 2], b = b1[ch];
+        wpt[4 * ch + 0] = x; wpt[4 * ch + 1] = y; wpt[4 * ch + 2] = z; wpt[4 * ch + 3] = b;
+        m = ((fabsf(x) + fabsf(y)) + fabsf(z)) + fabsf(b);
     }
+    m = block_max(m, red);
+    if (threadIdx.x == 0) bound[0] = m;
+}
+// out[0] = max |x[i]| (non-negative floats order like their bit patterns); out must be zeroed first
+__global__ void absmax_kernel(const float* __restrict__ x, long n4, unsigned* __restrict__ out) {
+    float m = 0.0f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 // dst[r, 0:D) = scale * src[r, 0:D)   (z_local term of models.py:561-565 before the value projection is accumulated onto it)
 __global__ void scale_rows_kernel(const float* __restrict__ src, int D, float scale, float* __restrict__ dst, int ld, long rows) {
@@ -94,11 +150,11 @@ Plan plan_layout(const car_dims& d) {
     size_t o = 0;
     auto take = [&](size_t n) { const size_t at = o; o += up64(n); return at; };
     p.steps = take((size_t)d.P);
-    p.blob = take(car_fused2_blob_floats());
+    p.blob = take(car_fused_blob_floats());
     p.fbias = take(car_fused_bias_floats());
     p.wpt = take((size_t)kC * 4);
-    p.r2w = take(4 * 4 * 1024);
-    p.r2b = take(kD);
+    p.r2w = take(car_round2_packed_floats());
+    p.r2b = take(car_round2_bias_floats());
     for (int l = 0; l < CAR_MAX_LEVELS; ++l) p.proj[l] = l < d.n_levels ? take(car_linear_packed_floats(d.level_c[l], kC)) : 0;
     p.latent_value = take(car_linear_packed_floats(kC, kE));
     p.encode_latent = take(car_linear_packed_floats(kE, kD));
@@ -131,7 +187,7 @@ int check_dims(const car_dims* d, const char* who) {
 
 // ---- workspace layout ----------------------------------------------------------------------------------------------
 struct Work {
-    size_t rays, phi_x, e, q, ug, logit, logit2, pt, pixel_val, coords, at_wt, at_wt2, amax, depth, ebar, z1, hb, uh, zrep, x, net,
+    size_t rays, phi_x, e, q, g, logit, logit2, pt, pixel_val, coords, at_wt, at_wt2, amax, depth, ebar, z1, hb, uh, zrep, x, net,
         out3, valid, total;                                        // offsets in floats
 };
 Work work_layout(const car_dims& d) {
@@ -143,7 +199,7 @@ Work work_layout(const car_dims& d) {
     w.phi_x = take(BR * kPhiLd);
     w.e = take(S * kC);
     w.q = take(S * kD);
-    w.ug = take(S * kD);
+    w.g = take(S * CAR_G_DIM);
     w.logit = take(S);
     w.logit2 = take(S);
     w.pt = take(S * 3);
@@ -172,7 +228,53 @@ Work work_layout(const car_dims& d) {
         if (rc_ != CAR_OK) return rc_; \
     } while (0)
 
+// ---- stage timing --------------------------------------------------------------------------------------------------
+struct StageRec { const char* name; hipEvent_t start, stop; };
+struct Profile {
+    bool on = false;
+    std::vector<StageRec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        return e;
+    }
+    void clear() {
+        for (StageRec& r : recs) { pool.push_back(r.start); pool.push_back(r.stop); }
+        recs.clear();
+    }
+};
+thread_local Profile g_prof;
+// brackets the launches of one stage with two events on the caller's stream (when profiling is on)
+struct Stage {
+    hipStream_t st;
+    bool live;
+    Stage(const char* name, hipStream_t s) : st(s), live(g_prof.on) {
+        if (!live) return;
+        StageRec r{name, g_prof.event(), g_prof.event()};
+        if (!r.start || !r.stop) { live = false; return; }
+        (void)hipEventRecord(r.start, st);
+        g_prof.recs.push_back(r);
+    }
+    ~Stage() { if (live) (void)hipEventRecord(g_prof.recs.back().stop, st); }
+};
+
 }  // namespace
+
+extern "C" void car_profile_enable(int on) { g_prof.clear(); g_prof.on = on != 0; }
+extern "C" void car_profile_reset(void) { g_prof.clear(); }
+extern "C" int car_profile_count(void) { return (int)g_prof.recs.size(); }
+extern "C" int car_profile_read(int i, const char** name, float* ms) {
+    CAR_REQUIRE(i >= 0 && i < (int)g_prof.recs.size() && name && ms, "car_profile_read: no stage %d", i);
+    const StageRec& r = g_prof.recs[i];
+    if (hipEventSynchronize(r.stop) != hipSuccess || hipEventElapsedTime(ms, r.start, r.stop) != hipSuccess) {
+        car_set_error("car_profile_read: %s", hipGetErrorString(hipGetLastError()));
+        return CAR_E_LAUNCH;
+    }
+    *name = r.name;
+    return CAR_OK;
+}
 
 // torch.linspace (CPU, fp32): step = (b - a) / (n - 1); first half a + step * i, second half b - step * (n - 1 - i)
 extern "C" void car_linspace(float a, float b, int n, float* out) {
@@ -190,11 +292,95 @@ extern "C" size_t car_workspace_bytes(const car_dims* dims) {
     if (check_dims(dims, "car_workspace_bytes") != CAR_OK) return 0;
     return work_layout(*dims).total * sizeof(float);
 }
+extern "C" size_t car_gmaps_level_offset(const car_dims* dims, int level) {
+    if (check_dims(dims, "car_gmaps_level_offset") != CAR_OK || level < 0 || level > dims->n_levels) return 0;
+    size_t n = 0;
+    for (int l = 0; l < level; ++l) n += (size_t)dims->b * dims->V * dims->level_h[l] * dims->level_w[l] * kC;
+    return n;
+}
+extern "C" size_t car_gmeta_offset(const car_dims* dims) { return dims ? car_gmaps_level_offset(dims, dims->n_levels) : 0; }
 extern "C" size_t car_gmaps_floats(const car_dims* dims) {
     if (check_dims(dims, "car_gmaps_floats") != CAR_OK) return 0;
-    size_t n = 0;
-    for (int l = 0; l < dims->n_levels; ++l) n += (size_t)dims->b * dims->V * dims->level_h[l] * dims->level_w[l] * kC;
-    return n;
+    return car_gmeta_offset(dims) + CAR_MAX_LEVELS;
+}
+extern "C" int car_workspace_find(const car_dims* dims, const char* name, size_t* offset_floats, size_t* n_floats) {
+    CAR_TRY(check_dims(dims, "car_workspace_find"));
+    CAR_REQUIRE(name && offset_floats && n_floats, "car_workspace_find: null pointer");
+    const Work w = work_layout(*dims);
+    const size_t n = (size_t)dims->b * dims->V, S = n * dims->R * dims->P, BR = (size_t)dims->b * dims->R;
+    const struct { const char* name; size_t off, cnt; } tab[] = {
+        {"rays", w.rays, n * dims->R * CAR_RAY_FLOATS}, {"e", w.e, S * kC}, {"qry", w.q, S * kD}, {"g", w.g, S * CAR_G_DIM},
+        {"logit", w.logit, S}, {"logit2", w.logit2, S}, {"pt", w.pt, S * 3}, {"at_wt2", w.at_wt2, S}, {"ebar", w.ebar, BR * kC},
+        {"z1", w.z1, BR * kE}, {"uh", w.uh, BR * kD}, {"zrep", w.zrep, BR * 2 * kE}, {"out3", w.out3, BR * 4}};
+    for (const auto& t : tab)
+        if (strcmp(t.name, name) == 0) { *offset_floats = t.off; *n_floats = t.cnt; return CAR_OK; }
+    car_set_error("car_workspace_find: unknown tensor '%s'", name);
+    return CAR_E_ARG;
+}
+
+// Packs the six layers of the fused per-sample kernel (csrc/car_fused.hip) into its operand order: fp16 hi/lo tiles, every layer
+// times its own power of two (chosen from its largest weight; 1/p goes into the bias table).  Asynchronous, device side only.
+extern "C" int car_fused_pack(const car_weights* w, float* blob_f, float* bias, float* wpt, void* stream) {
+    CAR_REQUIRE(w && blob_f && bias && wpt, "car_fused_pack: null pointer");
+    CAR_REQUIRE(w->query_encode_latent_w && w->query_encode_latent_b && w->query_encode_latent_2_w && w->query_encode_latent_2_b &&
+                w->key_map_w && w->key_map_b && w->key_map_2_w && w->key_map_2_b && w->query_embed_w && w->query_embed_b &&
+                w->query_embed_2_w && w->query_embed_2_b, "car_fused_pack: a weight pointer of the fused layers is null");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(bias, 0, sizeof(float) * kBiasFloats, st) != hipSuccess) { car_set_error("car_fused_pack: memset failed"); return CAR_E_LAUNCH; }
+    _Float16* blob = reinterpret_cast<_Float16*>(blob_f);
+    float* fdown = bias + kBiasScale;
+    float* pscale = bias + kBiasScale + 8;                           // pack-time scratch: 2^shift per layer
+    (void)hipGetLastError();
+    auto scale = [&](const float* W, int ldw, int N, int K, const float* b, int layer) {
+        hipLaunchKernelGGL(layer_scale_kernel, dim3(1), dim3(1024), 0, st, W, ldw, N, K, b, pscale + layer, fdown + layer);
+    };
+    auto pack16 = [&](const float* W, int ldw, const float* b, int N, int K, int n_tiles, int ksteps, int mode, int kbase, int layer, int tile_off) {
+        hipLaunchKernelGGL(pack16_kernel, dim3(256), dim3(256), 0, st, W, ldw, b, N, K, n_tiles, ksteps, mode, kbase, pscale + layer,
+                           blob + (size_t)tile_off * kTile16 * 2);
+    };
+    scale(w->query_encode_latent_2_w, kC, kE, kC, nullptr, kLayerW2);
+    scale(w->query_embed_w, 16, kD, 16, w->query_embed_b, kLayerQ1);
+    scale(w->query_embed_2_w, kD, kD, kD, nullptr, kLayerQ2);
+    scale(w->key_map_w, kC, kD, kC, nullptr, kLayerK1);
+    scale(w->key_map_2_w, kD, kD, kD, nullptr, kLayerK2);
+    pack16(w->query_encode_latent_2_w, kC, nullptr, kE, kC, kTE, kKS, 0, 0, kLayerW2, kOffW2);
+    pack16(w->query_embed_w, 16, w->query_embed_b, kD, 16, kTD, 1, 0, 0, kLayerQ1, kOffQ1);
+    pack16(w->query_embed_2_w, kD, nullptr, kD, kD, kTD, 4, 1, 0, kLayerQ2, kOffQ2);
+    pack16(w->key_map_w, kC, nullptr, kD, kC, kTD, 9, 1, 0, kLayerK1, kOffK1);
+    pack16(w->key_map_w, kC, nullptr, kD, kC, kTD, 9, 1, kE, kLayerK1, kOffK1 + 9 * kTD);
+    pack16(w->key_map_2_w, kD, nullptr, kD, kD, kTD, 4, 1, 0, kLayerK2, kOffK2);
+    hipLaunchKernelGGL(wpt_kernel, dim3(1), dim3(kC), 0, st, w->query_encode_latent_w, w->query_encode_latent_b, wpt, fdown + 5);
+    CAR_CHECK_LAUNCH("car_fused_pack");
+    auto d2d = [&](float* dst, const float* src, int n) { return hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, st) == hipSuccess; };
+    if (!d2d(bias + kBiasE, w->query_encode_latent_2_b, kE) || !d2d(bias + kBiasQ2, w->query_embed_2_b, kD) ||
+        !d2d(bias + kBiasK1, w->key_map_b, kD) || !d2d(bias + kBiasK2, w->key_map_2_b, kD)) {
+        car_set_error("car_fused_pack: bias copy failed");
+        return CAR_E_LAUNCH;
+    }
+    return CAR_OK;
+}
+
+// Packs query_repeat_embed (its local_coords half, columns 128..143 of the (128, 144) matrix `wr1`) and query_repeat_embed_2 for
+// csrc/car_round2.hip; same conventions as car_fused_pack.
+extern "C" int car_round2_pack(const float* wr1, const float* br1, const float* wr2, const float* br2, float* wpacked, float* bias, void* stream) {
+    CAR_REQUIRE(wr1 && br1 && wr2 && br2 && wpacked && bias, "car_round2_pack: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)car_round2_bias_floats();
+    if (hipMemsetAsync(bias, 0, sizeof(float) * nb, st) != hipSuccess) { car_set_error("car_round2_pack: memset failed"); return CAR_E_LAUNCH; }
+    float* down = bias + 2 * kD;                                     // [0] Wr1g, [1] Wr2; [2], [3]: their 2^shift (pack-time scratch)
+    _Float16* out = reinterpret_cast<_Float16*>(wpacked);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(layer_scale_kernel, dim3(1), dim3(1024), 0, st, wr1 + kD, kD + 16, kD, 16, (const float*)nullptr, down + 2, down + 0);
+    hipLaunchKernelGGL(layer_scale_kernel, dim3(1), dim3(1024), 0, st, wr2, kD, kD, kD, (const float*)nullptr, down + 3, down + 1);
+    hipLaunchKernelGGL(pack32_kernel, dim3(128), dim3(256), 0, st, wr2, kD, 4, 2, 1, down + 3, out);
+    hipLaunchKernelGGL(pack32_kernel, dim3(16), dim3(256), 0, st, wr1 + kD, kD + 16, 1, 1, 0, down + 2, out + 4 * 4 * 2 * 2 * 64 * 8);
+    CAR_CHECK_LAUNCH("car_round2_pack");
+    if (hipMemcpyAsync(bias, br1, sizeof(float) * kD, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(bias + kD, br2, sizeof(float) * kD, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        car_set_error("car_round2_pack: bias copy failed");
+        return CAR_E_LAUNCH;
+    }
+    return CAR_OK;
 }
 
 extern "C" int car_plan_build(const car_dims* dims, const car_weights* w, void* plan, void* stream) {
@@ -203,6 +389,8 @@ extern "C" int car_plan_build(const car_dims* dims, const car_weights* w, void* 
     const float* const* all = reinterpret_cast<const float* const*>(w);
     for (size_t k = 0; k < sizeof(car_weights) / sizeof(const float*); ++k)
         CAR_REQUIRE(all[k], "car_plan_build: weight pointer %zu of car_weights is null", k);
+    CAR_REQUIRE(car_fused_blob_floats() == (size_t)kBlobTiles * kTile && car_fused_bias_floats() == (size_t)kBiasFloats,
+                "car_plan_build: the fused kernel was built with another weight layout");
     const Plan p = plan_layout(*dims);
     float* base = static_cast<float*>(plan);
     hipStream_t st = (hipStream_t)stream;
@@ -217,31 +405,10 @@ extern "C" int car_plan_build(const car_dims* dims, const car_weights* w, void* 
             return CAR_E_LAUNCH;
         }
     }
-    // split-fp16 operand tiles of the fused per-sample kernel, in its consumption layout
-    _Float16* blob = reinterpret_cast<_Float16*>(base + p.blob);
-    auto pack16 = [&](const float* W, int ldw, const float* bias, int N, int K, int n_tiles, int ksteps, int mode, int kbase, int tile_off) {
-        hipLaunchKernelGGL(pack16_kernel, dim3(256), dim3(256), 0, st, W, ldw, bias, N, K, n_tiles, ksteps, mode, kbase,
-                           blob + (size_t)tile_off * kTile16 * 2);
-    };
-    (void)hipGetLastError();
-    pack16(w->query_encode_latent_2_w, kC, nullptr, kE, kC, kE / 16, kC / 32, 0, 0, kOffW2);
-    pack16(w->query_embed_w, 16, w->query_embed_b, kD, 16, kD / 16, 1, 0, 0, kOffQ1);
-    pack16(w->query_embed_2_w, kD, nullptr, kD, kD, kD / 16, 4, 1, 0, kOffQ2);
-    pack16(w->query_repeat_embed_w + kD, kD + 16, w->query_repeat_embed_b, kD, 16, kD / 16, 1, 0, 0, kOffUG);
-    pack16(w->key_map_w, kC, nullptr, kD, kC, kD / 16, 9, 1, 0, kOffK1);
-    pack16(w->key_map_w, kC, nullptr, kD, kC, kD / 16, 9, 1, kE, kOffK1 + 9 * (kD / 16));
-    pack16(w->key_map_2_w, kD, nullptr, kD, kD, kD / 16, 4, 1, 0, kOffK2);
-    hipLaunchKernelGGL(pack32_kernel, dim3(128), dim3(256), 0, st, w->query_repeat_embed_2_w, reinterpret_cast<_Float16*>(base + p.r2w));
-    hipLaunchKernelGGL(wpt_kernel, dim3((kC + 255) / 256), dim3(256), 0, st, w->query_encode_latent_w, w->query_encode_latent_b, base + p.wpt);
-    CAR_CHECK_LAUNCH("car_plan_build");
-    const float* fb[4] = {w->query_encode_latent_2_b, w->query_embed_2_b, w->key_map_b, w->key_map_2_b};
-    const int fbn[4] = {kE, kD, kD, kD};
-    size_t at = p.fbias;
-    for (int k = 0; k < 4; ++k) {
-        if (hipMemcpyAsync(base + at, fb[k], sizeof(float) * fbn[k], hipMemcpyDeviceToDevice, st) != hipSuccess) { car_set_error("car_plan_build: bias copy failed"); return CAR_E_LAUNCH; }
-        at += fbn[k];
-    }
-    if (hipMemcpyAsync(base + p.r2b, w->query_repeat_embed_2_b, sizeof(float) * kD, hipMemcpyDeviceToDevice, st) != hipSuccess) { car_set_error("car_plan_build: bias copy failed"); return CAR_E_LAUNCH; }
+    // split-fp16 operand tiles of the fused per-sample kernel and of the round-2 kernel
+    CAR_TRY(car_fused_pack(w, base + p.blob, base + p.fbias, base + p.wpt, stream));
+    CAR_TRY(car_round2_pack(w->query_repeat_embed_w, w->query_repeat_embed_b, w->query_repeat_embed_2_w, w->query_repeat_embed_2_b,
+                            base + p.r2w, base + p.r2b, stream));
     // fp32 MFMA layers (car_linear.hip)
     int coff = 0;
     for (int l = 0; l < dims->n_levels; ++l) {
@@ -266,12 +433,18 @@ extern "C" int car_project_maps(const car_dims* dims, const void* plan, const fl
     CAR_REQUIRE(plan && maps && gmaps, "car_project_maps: null pointer");
     const Plan p = plan_layout(*dims);
     const float* base = static_cast<const float*>(plan);
-    size_t at = 0;
+    hipStream_t st = (hipStream_t)stream;
+    float* gmeta = gmaps + car_gmeta_offset(dims);
+    if (hipMemsetAsync(gmeta, 0, sizeof(float) * CAR_MAX_LEVELS, st) != hipSuccess) { car_set_error("car_project_maps: memset failed"); return CAR_E_LAUNCH; }
     for (int l = 0; l < dims->n_levels; ++l) {
         CAR_REQUIRE(maps[l], "car_project_maps: level %d is null", l);
         const long M = (long)dims->b * dims->V * dims->level_h[l] * dims->level_w[l];
-        CAR_TRY(car_linear(maps[l], dims->level_c[l], base + p.proj[l], dims->level_c[l], kC, gmaps + at, kC, M, 0, stream));
-        at += (size_t)M * kC;
+        float* gl = gmaps + car_gmaps_level_offset(dims, l);
+        CAR_TRY(car_linear(maps[l], dims->level_c[l], base + p.proj[l], dims->level_c[l], kC, gl, kC, M, 0, stream));
+        // largest |G_l|: bounds the level's contribution to h (the fused kernel scales its fp16 operands by it)
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, gl, M * kC / 4, reinterpret_cast<unsigned*>(gmeta + l));
+        CAR_CHECK_LAUNCH("car_project_maps (absmax)");
     }
     return CAR_OK;
 }
@@ -280,7 +453,8 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
                                   void* workspace, size_t workspace_bytes, void* stream) {
     CAR_TRY(check_dims(dims, "car_render_forward"));
     CAR_REQUIRE(plan && in && out && workspace, "car_render_forward: null pointer");
-    CAR_REQUIRE(in->poses && in->uv && in->gmaps && out->rgb, "car_render_forward: poses, uv, gmaps and rgb are required");
+    CAR_REQUIRE(in->poses && in->uv && in->gmaps[0] && in->gmaps[1] && in->gmaps[2] && in->gmeta && out->rgb,
+                "car_render_forward: poses, uv, gmaps, gmeta and rgb are required");
     const car_dims& d = *dims;
     const Plan p = plan_layout(d);
     const Work w = work_layout(d);
@@ -291,7 +465,7 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
     hipStream_t st = (hipStream_t)stream;
     const int b = d.b, V = d.V, R = d.R, P = d.P;
     const float* steps = in->steps ? in->steps : pl + p.steps;
-    const long BR = (long)b * R, S = (long)b * V * R * P;
+    const long BR = (long)b * R;
     float* coords = out->coords ? out->coords : ws + w.coords;
     float* pixel_val = out->pixel_val ? out->pixel_val : ws + w.pixel_val;
     float* at_wt = out->at_wt ? out->at_wt : ws + w.at_wt;
@@ -299,47 +473,60 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
     float* valid = out->valid_mask ? out->valid_mask : ws + w.valid;
     int32_t* amax = out->at_wt_max ? out->at_wt_max : reinterpret_cast<int32_t*>(ws + w.amax);
 
-    // a4-a6: rays, their epipolar segments, the decoder's ray input (columns 18, 19 of phi_x stay zero)
-    if (hipMemsetAsync(ws + w.phi_x, 0, sizeof(float) * BR * kPhiLd, st) != hipSuccess) { car_set_error("car_render_forward: memset failed"); return CAR_E_LAUNCH; }
-    CAR_TRY(car_ray_setup(in->poses, in->uv, b, V, R, d.H, d.W, P, 0, steps, ws + w.rays, coords, ws + w.phi_x, kPhiLd, stream));
-    // a6-a13 + round-1 logits: the fused per-sample kernel
-    const float* gm[3];
-    size_t at = 0;
-    for (int l = 0; l < 3; ++l) { gm[l] = in->gmaps + at; at += (size_t)b * V * d.level_h[l] * d.level_w[l] * kC; }
-    CAR_TRY(car_fused_samples_v4(in->poses, ws + w.rays, steps, gm, d.level_h, d.level_w, 3, kC, pl + p.wpt, pl + p.blob, pl + p.fbias,
-                                 b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.ug, ws + w.logit, ws + w.pt, pixel_val, stream));
-    // a14 + a16: attention round 1, depth read-out, argmax
-    CAR_TRY(car_attend(ws + w.logit, nullptr, kD, ws + w.e, kC, b, V, R, P, nullptr, 0.0f, at_wt, ws + w.ebar, kC, 1, ws + w.pt, in->poses,
-                       depth, amax, stream));
+    {   // a4-a6: rays, their epipolar segments, the decoder's ray input (columns 18, 19 of phi_x stay zero)
+        Stage stage("ray_setup", st);
+        if (hipMemsetAsync(ws + w.phi_x, 0, sizeof(float) * BR * kPhiLd, st) != hipSuccess) { car_set_error("car_render_forward: memset failed"); return CAR_E_LAUNCH; }
+        CAR_TRY(car_ray_setup(in->poses, in->uv, b, V, R, d.H, d.W, P, 0, steps, ws + w.rays, coords, ws + w.phi_x, kPhiLd, stream));
+    }
+    {   // a6-a13 + round-1 logits: the fused per-sample kernel
+        Stage stage("fused_samples", st);
+        CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->gmaps, d.level_h, d.level_w, 3, kC, in->gmeta, pl + p.wpt, pl + p.blob,
+                                  pl + p.fbias, b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
+    }
+    {   // a14 + a16: attention round 1, depth read-out, argmax
+        Stage stage("attend_1", st);
+        CAR_TRY(car_attend(ws + w.logit, nullptr, kD, ws + w.e, kC, b, V, R, P, nullptr, 0.0f, at_wt, ws + w.ebar, kC, 1, ws + w.pt, in->poses,
+                           depth, amax, stream));
+    }
     float* zrep = ws + w.zrep;
     if (d.repeat_attention) {
-        // a15: z1 = Wv ebar + bv; second-round query; logits; attention; z = (Wv ebar2 + bv) + V z1
-        CAR_TRY(car_linear(ws + w.ebar, kC, pl + p.latent_value, kC, kE, ws + w.z1, kE, BR, 0, stream));
-        CAR_TRY(car_linear(ws + w.z1, kE, pl + p.encode_latent, kE, kD, ws + w.hb, kD, BR, 0, stream));
-        CAR_TRY(car_linear(ws + w.hb, kD, pl + p.qre_h, kD, kD, ws + w.uh, kD, BR, 0, stream));
-        CAR_TRY(car_round2_logits(ws + w.ug, ws + w.uh, ws + w.q, pl + p.r2w, pl + p.r2b, b, V, R, P, ws + w.logit2, stream));
-        CAR_TRY(car_attend(ws + w.logit2, nullptr, kD, ws + w.e, kC, b, V, R, P, nullptr, 0.0f, ws + w.at_wt2, ws + w.ebar, kC, 1, nullptr,
-                           nullptr, nullptr, nullptr, stream));
+        {   // a15, per ray: z1 = Wv ebar + bv; uh = Wr1[:, :128] encode_latent(z1)
+            Stage stage("ray_layers_1", st);
+            CAR_TRY(car_linear(ws + w.ebar, kC, pl + p.latent_value, kC, kE, ws + w.z1, kE, BR, 0, stream));
+            CAR_TRY(car_linear(ws + w.z1, kE, pl + p.encode_latent, kE, kD, ws + w.hb, kD, BR, 0, stream));
+            CAR_TRY(car_linear(ws + w.hb, kD, pl + p.qre_h, kD, kD, ws + w.uh, kD, BR, 0, stream));
+        }
+        {   // a15, per sample: second-round query and logits
+            Stage stage("round2_logits", st);
+            CAR_TRY(car_round2_logits(ws + w.g, ws + w.uh, ws + w.q, pl + p.r2w, pl + p.r2b, b, V, R, P, ws + w.logit2, stream));
+        }
+        {
+            Stage stage("attend_2", st);
+            CAR_TRY(car_attend(ws + w.logit2, nullptr, kD, ws + w.e, kC, b, V, R, P, nullptr, 0.0f, ws + w.at_wt2, ws + w.ebar, kC, 1, nullptr,
+                               nullptr, nullptr, nullptr, stream));
+        }
+    }
+    {   // z = (Wv ebar2 + bv) + V z1 (models.py:561-565), per-view replication, light-field decoder (resnet_block_fc.py:132-168), a18
+        Stage stage("ray_layers_2", st);
+        if (d.repeat_attention) {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, st, ws + w.z1, kE, (float)V, zrep, V * kE, BR);
+            CAR_CHECK_LAUNCH("car_render_forward (scale)");
+            CAR_TRY(car_linear(ws + w.ebar, kC, pl + p.latent_value, kC, kE, zrep, V * kE, BR, CAR_LIN_ACCUM, stream));
+        } else {
+            CAR_TRY(car_linear(ws + w.ebar, kC, pl + p.latent_value, kC, kE, zrep, V * kE, BR, 0, stream));
+        }
         (void)hipGetLastError();
-        hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, st, ws + w.z1, kE, (float)V, zrep, V * kE, BR);
-        CAR_CHECK_LAUNCH("car_render_forward (scale)");
-        CAR_TRY(car_linear(ws + w.ebar, kC, pl + p.latent_value, kC, kE, zrep, V * kE, BR, CAR_LIN_ACCUM, stream));
-    } else {
-        CAR_TRY(car_linear(ws + w.ebar, kC, pl + p.latent_value, kC, kE, zrep, V * kE, BR, 0, stream));
+        hipLaunchKernelGGL(replicate_views_kernel, dim3(1024), dim3(256), 0, st, zrep, kE, V, BR);
+        CAR_CHECK_LAUNCH("car_render_forward (replicate)");
+        CAR_TRY(car_linear(ws + w.phi_x, kPhiLd, pl + p.lin_in, kPhiIn, kD, ws + w.x, kD, BR, 0, stream));
+        for (int i = 0; i < kBlocks; ++i) {
+            CAR_TRY(car_linear(zrep, V * kE, pl + p.lin_z[i], V * kE, kD, ws + w.x, kD, BR, CAR_LIN_ACCUM, stream));
+            CAR_TRY(car_linear(ws + w.x, kD, pl + p.fc0[i], kD, kD, ws + w.net, kD, BR, CAR_LIN_RELU_IN, stream));
+            CAR_TRY(car_linear(ws + w.net, kD, pl + p.fc1[i], kD, kD, ws + w.x, kD, BR, CAR_LIN_RELU_IN | CAR_LIN_ACCUM, stream));
+        }
+        CAR_TRY(car_linear(ws + w.x, kD, pl + p.lin_out, kD, 3, ws + w.out3, 4, BR, CAR_LIN_RELU_IN, stream));
+        CAR_TRY(car_finalize(ws + w.rays, ws + w.out3, 4, b, V, R, out->rgb, valid, stream));
     }
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(replicate_views_kernel, dim3(1024), dim3(256), 0, st, zrep, kE, V, BR);
-    CAR_CHECK_LAUNCH("car_render_forward (replicate)");
-    // a17: light-field decoder (resnet_block_fc.py:132-168)
-    CAR_TRY(car_linear(ws + w.phi_x, kPhiLd, pl + p.lin_in, kPhiIn, kD, ws + w.x, kD, BR, 0, stream));
-    for (int i = 0; i < kBlocks; ++i) {
-        CAR_TRY(car_linear(zrep, V * kE, pl + p.lin_z[i], V * kE, kD, ws + w.x, kD, BR, CAR_LIN_ACCUM, stream));
-        CAR_TRY(car_linear(ws + w.x, kD, pl + p.fc0[i], kD, kD, ws + w.net, kD, BR, CAR_LIN_RELU_IN, stream));
-        CAR_TRY(car_linear(ws + w.net, kD, pl + p.fc1[i], kD, kD, ws + w.x, kD, BR, CAR_LIN_RELU_IN | CAR_LIN_ACCUM, stream));
-    }
-    CAR_TRY(car_linear(ws + w.x, kD, pl + p.lin_out, kD, 3, ws + w.out3, 4, BR, CAR_LIN_RELU_IN, stream));
-    // a18: valid mask, white background
-    CAR_TRY(car_finalize(ws + w.rays, ws + w.out3, 4, b, V, R, out->rgb, valid, stream));
-    (void)S;
     return CAR_OK;
 }

@@ -1,29 +1,50 @@
 // car_round2.hip — per-sample part of the second attention round in one kernel (reference
 // models.py:548-556):
-//     q2    = Wr2 relu(ug + uh[ray]) + br2         ug = Wr1[:,128:] g + br1 (per sample, from the fused kernel),
-//                                                  uh = Wr1[:,:128] encode_latent(z1)   (per ray)
+//     ug    = Wr1[:,128:] g + br1                  g  = the sample's 16-channel geometric query (from the fused kernel)
+//     q2    = Wr2 relu(ug + uh[ray]) + br2         uh = Wr1[:,:128] encode_latent(z1)   (per ray, car_ray_mid)
 //     logit = <q2, qry> / 16
-// q2 never exists in memory: it is produced in the MFMA accumulators (weights as A operand, samples as B operand, see
-// car_linear.hip; f16 matrix pipe with fp16 hi/lo operand splits as in car_fused.hip) and immediately dotted with the
-// sample's qry row.  The 128x128 layer (64 KB packed) is loaded into LDS once per workgroup (8 waves), so there is no
-// weight stream and no barrier in the main loop.  HBM-bound: it reads ug and qry (2 x 512 B per sample) and writes 4 B per
-// sample.  The MFMA wants lane = sample, memory wants lanes along a row: every 32-row x 32-channel tile is loaded
-// coalesced (8 lanes x 16 B per row = one 128-byte line) and turned through a wave-private LDS tile; row-per-lane loads
-// straight from HBM ran at 2.2 TB/s (3.9 ms per frame).
+// Neither ug nor q2 exists in memory: ug is produced in the MFMA accumulators from the 64-byte g row (weights as A operand,
+// samples as B operand), its registers — plus uh, loaded in the same accumulator layout — are the B operand of the second layer
+// (the accumulator's channel permutation is baked into the packed Wr2, "chained" K order), and q2 is dotted with the sample's
+// qry row straight out of the accumulators.  f16 matrix pipe with fp16 hi/lo operand splits (three products per term, see
+// car_fused_mma.h); the activations of the second layer are scaled per sample by a power of two so that the split stays inside
+// fp16's normal range whatever their magnitude.  Both layers (4 KB + 64 KB packed) sit in LDS, loaded once per workgroup
+// (8 waves): no weight stream and no barrier in the main loop.  HBM-bound on the qry rows (512 B per sample) + g (64 B): they
+// are loaded coalesced (8 lanes x 16 B per row = one 128-byte line) and turned through a wave-private LDS tile.
 #include "car_common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-constexpr int kWShift = 8;          // the packed fp16 hi/lo weights carry 2^8 (see car_fused.hip, PREC = 1)
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 constexpr int kD = 128, kNT = 4, kTile = 1024, kChunks = 4;
 constexpr int kWaves = 8, kStageLd = 36;
-constexpr int kLdsBias = kChunks * kNT * kTile;                     // after the 64 KB of weights
-constexpr int kLdsStage = kLdsBias + kD;                            // [8 waves][32 rows][36]
+constexpr int kLdsW1 = kChunks * kNT * kTile;                       // Wr1g tiles after the 64 KB of Wr2: [4 tiles][hi|lo][64 lanes][8 halves]
+constexpr int kLdsBias = kLdsW1 + kNT * 512;                        // br1 [128] | br2 [128] | 2^-shift of Wr1g, Wr2
+constexpr int kLdsStage = kLdsBias + 2 * kD + 4;                    // [8 waves][32 rows][36]
 constexpr size_t kLdsBytes = (size_t)(kLdsStage + kWaves * 32 * kStageLd) * sizeof(float);
 
-__global__ void __launch_bounds__(512) round2_kernel(const float* __restrict__ ug, const float* __restrict__ uh,
+// x[8] * p -> fp16 hi/lo halves (round toward zero; x*p - hi is exact in fp32)
+__device__ __forceinline__ void split8(const float (&x)[8], float p, half8& hi, half8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const float a = x[e] * p, b = x[e + 1] * p;
+        const fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(a, b);
+        const fp16x2 l2 = __builtin_amdgcn_cvt_pkrtz(a - (float)h2[0], b - (float)h2[1]);
+        hi[e] = (_Float16)h2[0]; hi[e + 1] = (_Float16)h2[1];
+        lo[e] = (_Float16)l2[0]; lo[e + 1] = (_Float16)l2[1];
+    }
+}
+// power of two p with m * p in [2^13, 2^14) (m > 0, clamped for tiny / huge m), and 1/p
+__device__ __forceinline__ void pow2_scale(float m, float& p, float& inv) {
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    e = e < 40 ? 40 : (e > 230 ? 230 : e);
+    p = __uint_as_float((unsigned)(267 - e) << 23);
+    inv = __uint_as_float((unsigned)(e - 13) << 23);
+}
+
+__global__ void __launch_bounds__(512) round2_kernel(const float* __restrict__ g, const float* __restrict__ uh,
                                                      const float* __restrict__ qry, const float* __restrict__ wpacked,
                                                      const float* __restrict__ bias, int V, int R, int P, long S,
                                                      float* __restrict__ logit) {
@@ -31,59 +52,91 @@ __global__ void __launch_bounds__(512) round2_kernel(const float* __restrict__ u
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 31, h = lane >> 5;
     const int qd = lane & 7, r8 = lane >> 3;                        // coalesced side: row r8 + 8 it, channel quad qd of a 32-wide chunk
-    for (int k = tid; k < kChunks * kNT * kTile / 4; k += 512)
+    for (int k = tid; k < (kLdsBias - 0) / 4; k += 512)
         *reinterpret_cast<float4*>(lds + 4 * k) = *reinterpret_cast<const float4*>(wpacked + 4 * k);
-    if (tid < kD) lds[kLdsBias + tid] = bias[tid];
+    if (tid < 2 * kD + 4) lds[kLdsBias + tid] = bias[tid];
     __syncthreads();
-    const float* lbias = lds + kLdsBias;
+    const float* lb1 = lds + kLdsBias;
+    const float* lb2 = lds + kLdsBias + kD;
+    const float down1 = lds[kLdsBias + 2 * kD], down2 = lds[kLdsBias + 2 * kD + 1];
     float* stage = lds + kLdsStage + wave * 32 * kStageLd;
 
     for (long row0 = ((long)blockIdx.x * kWaves + wave) * 32; row0 < S; row0 += (long)gridDim.x * kWaves * 32) {
-        // all inputs of the 32 rows first: 16 + 16 + 16 float4 per lane, every load instruction covers 8 whole 128-byte lines
-        float4 xs[kChunks][4], us[kChunks][4], qs[kChunks][4];
+        // the HBM stream first: qry rows, coalesced (every load instruction covers 8 whole 128-byte lines)
+        float4 qs[kChunks][4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const long row = row0 + r8 + 8 * it < S ? row0 + r8 + 8 * it : S - 1;
-            const long nr = row / P;                               // (scene-view n, ray r)
-            const long ray = ((nr / R) / V) * R + nr % R;          // (scene, ray): uh is shared by the views
 #pragma unroll
-            for (int c = 0; c < kChunks; ++c) {
-                xs[c][it] = *reinterpret_cast<const float4*>(ug + row * kD + 32 * c + 4 * qd);
-                us[c][it] = *reinterpret_cast<const float4*>(uh + ray * kD + 32 * c + 4 * qd);
-                qs[c][it] = *reinterpret_cast<const float4*>(qry + row * kD + 32 * c + 4 * qd);
-            }
+            for (int c = 0; c < kChunks; ++c) qs[c][it] = *reinterpret_cast<const float4*>(qry + row * kD + 32 * c + 4 * qd);
         }
-        f32x16 acc[kNT];
+        // this lane's sample: its g half (B operand of the first layer) and the row of uh its ray owns
+        const long srow = row0 + s < S ? row0 + s : S - 1;
+        const long nr = srow / P;                                  // (scene-view n, ray r)
+        const float* uhrow = uh + (((nr / R) / V) * R + nr % R) * kD;   // (scene, ray): uh is shared by the views
+        half8 ghi, glo;
+        float gp, ginv;
+        {
+            const float4 g0 = *reinterpret_cast<const float4*>(g + srow * 16 + 8 * h);
+            const float4 g1 = *reinterpret_cast<const float4*>(g + srow * 16 + 8 * h + 4);
+            const float gx[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            float m = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(gx[k]));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            pow2_scale(fmaxf(m, 1e-30f), gp, ginv);
+            split8(gx, gp, ghi, glo);
+        }
+        // ug = Wr1g g + br1, accumulator layout: lane (s, h) register 4 g' + r of tile t = channel 32 t + 8 g' + 4 h + r
+        f32x16 ug[kNT];
+        const float up1 = gp / down1;
+#pragma unroll
+        for (int t = 0; t < kNT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ug[t][r] = lb1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h] * up1;
+            const float* w1 = lds + kLdsW1 + t * 512 + 4 * lane;
+            const half8 ah = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1));
+            const half8 al = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1 + 256));
+            ug[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ghi, ug[t], 0, 0, 0);
+            ug[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, glo, ug[t], 0, 0, 0);
+            ug[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ghi, ug[t], 0, 0, 0);
+        }
+        // x = relu(ug + uh) in place, and its largest magnitude over the sample's 128 channels
+        const float undo1 = down1 * ginv;
+        float xm = 0.0f;
 #pragma unroll
         for (int t = 0; t < kNT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = lbias[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h] * (float)(1 << kWShift);
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 u = *reinterpret_cast<const float4*>(uhrow + 32 * t + 8 * gq + 4 * h);
+                const float uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = fmaxf(fmaf(ug[t][4 * gq + r], undo1, uu[r]), 0.0f);
+                    ug[t][4 * gq + r] = x;
+                    xm = fmaxf(xm, x);
+                }
+            }
+        xm = fmaxf(xm, __shfl_xor(xm, 32, 64));
+        float xp, xinv;
+        pow2_scale(fmaxf(xm, 1e-30f), xp, xinv);
+        // q2 = Wr2 x + br2: K step (source tile c, group kg) takes registers 8 kg .. 8 kg + 7 of x's tile c
+        f32x16 acc[kNT];
+        const float up2 = xp / down2;
+#pragma unroll
+        for (int t = 0; t < kNT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = lb2[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h] * up2;
 #pragma unroll
         for (int c = 0; c < kChunks; ++c) {
-            // relu(ug + uh) of this chunk through the wave's tile: written along rows, read back lane = sample
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const float4 x = xs[c][it], u = us[c][it];
-                *reinterpret_cast<float4*>(stage + (r8 + 8 * it) * kStageLd + 4 * qd) =
-                    make_float4(fmaxf(x.x + u.x, 0.f), fmaxf(x.y + u.y, 0.f), fmaxf(x.z + u.z, 0.f), fmaxf(x.w + u.w, 0.f));
-            }
-            float bv[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 x = *reinterpret_cast<const float4*>(stage + s * kStageLd + 16 * h + 4 * q);
-                bv[4 * q + 0] = x.x; bv[4 * q + 1] = x.y; bv[4 * q + 2] = x.z; bv[4 * q + 3] = x.w;
-            }
-            // fp16 hi/lo split of the activations, three exact products per term on the f16 matrix pipe
             half8 bhi[2], blo[2];
 #pragma unroll
-            for (int kg = 0; kg < 2; ++kg)
+            for (int kg = 0; kg < 2; ++kg) {
+                float x8[8];
 #pragma unroll
-                for (int e8 = 0; e8 < 8; ++e8) {
-                    const float x = bv[8 * kg + e8];
-                    const _Float16 hi = (_Float16)x;
-                    bhi[kg][e8] = hi;
-                    blo[kg][e8] = (_Float16)(x - (float)hi);
-                }
+                for (int e = 0; e < 8; ++e) x8[e] = ug[c][8 * kg + e];
+                split8(x8, xp, bhi[kg], blo[kg]);
+            }
             const float* wl = lds + c * kNT * kTile + 4 * lane;
 #pragma unroll
             for (int t = 0; t < kNT; ++t)
@@ -96,42 +149,41 @@ __global__ void __launch_bounds__(512) round2_kernel(const float* __restrict__ u
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[kg], acc[t], 0, 0, 0);
                 }
         }
-        // <q2, qry>: lane (s, h) holds channels 32 t + 8 g + 4 h + (0..3) of its sample in acc[t][4g..4g+3]; qry comes through
-        // the same tile, 32 channels at a time
+        // <q2, qry>: lane (s, h) holds channels 32 t + 8 g' + 4 h + (0..3) of its sample in acc[t][4g'..4g'+3]; qry comes through
+        // the wave's tile, 32 channels at a time
         float dot = 0.0f;
 #pragma unroll
         for (int t = 0; t < kNT; ++t) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) *reinterpret_cast<float4*>(stage + (r8 + 8 * it) * kStageLd + 4 * qd) = qs[t][it];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 qv = *reinterpret_cast<const float4*>(stage + s * kStageLd + 8 * g + 4 * h);
-                dot = fmaf(acc[t][4 * g + 0], qv.x, dot); dot = fmaf(acc[t][4 * g + 1], qv.y, dot);
-                dot = fmaf(acc[t][4 * g + 2], qv.z, dot); dot = fmaf(acc[t][4 * g + 3], qv.w, dot);
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 qv = *reinterpret_cast<const float4*>(stage + s * kStageLd + 8 * gq + 4 * h);
+                dot = fmaf(acc[t][4 * gq + 0], qv.x, dot); dot = fmaf(acc[t][4 * gq + 1], qv.y, dot);
+                dot = fmaf(acc[t][4 * gq + 2], qv.z, dot); dot = fmaf(acc[t][4 * gq + 3], qv.w, dot);
             }
         }
         dot += __shfl_xor(dot, 32, 64);
-        if (h == 0 && row0 + s < S) logit[row0 + s] = dot * (1.0f / (float)(1 << kWShift)) / 16.0f;
+        if (h == 0 && row0 + s < S) logit[row0 + s] = dot * (down2 * xinv) / 16.0f;
     }
 }
 
 }  // namespace
 
-extern "C" int car_round2_logits(const float* ug, const float* uh, const float* qry, const float* wpacked, const float* bias,
+extern "C" size_t car_round2_packed_floats(void) { return (size_t)kLdsBias; }
+extern "C" size_t car_round2_bias_floats(void) { return (size_t)(2 * kD + 4); }
+
+extern "C" int car_round2_logits(const float* g, const float* uh, const float* qry, const float* wpacked, const float* bias,
                                  int b, int V, int R, int P, float* logit, void* stream) {
-    CAR_REQUIRE(ug && uh && qry && wpacked && bias && logit, "car_round2_logits: null pointer");
+    CAR_REQUIRE(g && uh && qry && wpacked && bias && logit, "car_round2_logits: null pointer");
     CAR_REQUIRE(b > 0 && V > 0 && R > 0 && P > 0, "car_round2_logits: bad sizes");
     const long S = (long)b * V * R * P;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)round2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-        if (e != hipSuccess) { car_set_error("car_round2_logits: cannot reserve LDS: %s", hipGetErrorString(e)); return CAR_E_LAUNCH; }
-        attr = true;
-    }
+    hipError_t e = hipFuncSetAttribute((const void*)round2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e != hipSuccess) { car_set_error("car_round2_logits: cannot reserve LDS: %s", hipGetErrorString(e)); return CAR_E_LAUNCH; }
     const long groups = (S + 255) / 256;
     const unsigned blocks = (unsigned)(groups < 1024 ? groups : 1024);       // one 8-wave workgroup per CU x 256 CUs x 4: grid-stride
     (void)hipGetLastError();
-    hipLaunchKernelGGL(round2_kernel, dim3(blocks), dim3(512), kLdsBytes, (hipStream_t)stream, ug, uh, qry, wpacked, bias, V, R,
+    hipLaunchKernelGGL(round2_kernel, dim3(blocks), dim3(512), kLdsBytes, (hipStream_t)stream, g, uh, qry, wpacked, bias, V, R,
                        P, S, logit);
     CAR_CHECK_LAUNCH("car_round2_logits");
     return CAR_OK;

@@ -1,9 +1,17 @@
-"""Host side of the render forward: sequences the HIP stage kernels of ``libcar_hip.so`` on the current stream.
+"""Host side of the render forward: what ``CrossAttentionRenderer.forward`` runs.
 
-``RenderEngine.render(input, z)`` is what ``CrossAttentionRenderer.forward`` runs.  Every arithmetic step of the
-reference forward (models.py:206-621) is a HIP kernel launched through the C ABI (``include/car_hip.h``); PyTorch
-is used for device memory, the stream handle and the (reference-identical) 4x4 pose algebra on the host.
-There is no CPU or eager-PyTorch fallback: tensors must live on a ROCm device and the library must load.
+Every arithmetic step of the reference forward (models.py:206-621) is a HIP kernel of ``libcar_hip.so`` reached through the
+C ABI (``include/car_hip.h``); PyTorch is used for device memory, the stream handle and the (reference-identical) 4x4 pose
+algebra on the host.  There is no CPU or eager-PyTorch fallback: tensors must live on a ROCm device and the library must load.
+
+Two routes:
+  * the reference's default configuration (n_view = 2, three pyramid levels, 576 channels, epipolar sampling) goes through the
+    ONE-CALL C ABI — ``car_plan_build`` once per set of weights, ``car_project_maps`` once per stereo pair,
+    ``car_render_forward`` per batch of rays (csrc/car_render.hip: weight packing and the launch sequence are C++).  This
+    module only sizes the calls: scenes are grouped so that a projected pyramid level stays below 4 GiB per call, and rays are
+    chunked so that the per-call workspace fits the free device memory (rays are independent, so this changes nothing);
+  * the constructor variants (n_view 1 / 3, no_sample, no_latent_concat, other widths) are sequenced here stage by stage —
+    also the A/B partner of the first route in the tests.
 
 Stage map:
   a3 poses.pack_poses (host, torch.inverse like the reference)          a11-a13, a15, a17  car_linear (fp32 MFMA)
@@ -53,149 +61,6 @@ class PackedLinear:
                    "car_linear_pack")
 
 
-def _pack_tiles(W: Tensor, bias: Optional[Tensor], n_tiles: int, chunk_k: Tensor) -> Tensor:
-    """Packs weight rows into MFMA A-operand tiles.  ``chunk_k`` (chunks, 64 lanes, 16 steps) gives, for every chunk, lane
-    and MFMA step, the input index k that lane supplies (k == K selects the bias, k > K a zero).  Result:
-    (chunks, n_tiles, 4, 64, 4) floats = [chunk][tile][j4][lane][e] with step r = 4*j4 + e, output n = 32*tile + lane%32."""
-    N, K = W.shape
-    Wext = torch.zeros(32 * n_tiles, K + 2, dtype=torch.float32)
-    Wext[:N, :K] = W
-    if bias is not None:
-        Wext[:N, K] = bias
-    chunks = chunk_k.shape[0]
-    k = chunk_k.clamp(max=K + 1)                                             # (chunks, 64, 16)
-    lane = torch.arange(64)
-    n = (32 * torch.arange(n_tiles)[:, None] + (lane % 32)[None, :])         # (tiles, 64)
-    out = Wext[n[None, :, :, None].expand(chunks, -1, -1, 16), k[:, None, :, :].expand(-1, n_tiles, -1, -1)]   # (chunks,tiles,64,16)
-    return out.reshape(chunks, n_tiles, 64, 4, 4).permute(0, 1, 3, 2, 4).contiguous()
-
-
-def _std_k(chunks: int) -> Tensor:
-    """standard mapping: chunk c, lane l, step r -> k = 32 c + 16 (l >> 5) + r"""
-    c = torch.arange(chunks)[:, None, None]
-    lane = torch.arange(64)[None, :, None]
-    r = torch.arange(16)[None, None, :]
-    return 32 * c + 16 * (lane // 32) + r
-
-
-def _chained_k(n_src_tiles: int, base: int = 0) -> Tensor:
-    """chained mapping over the accumulator layout of a 32-row tile T: k = base + 32 T + (r&3) + 8 (r>>2) + 4 (l >> 5)"""
-    T = torch.arange(n_src_tiles)[:, None, None]
-    lane = torch.arange(64)[None, :, None]
-    r = torch.arange(16)[None, None, :]
-    return base + 32 * T + (r % 4) + 8 * (r // 4) + 4 * (lane // 32)
-
-
-W_SHIFT = 8          # kWShift of csrc/car_fused.hip: packed fp16 weights carry a factor 2^8
-
-
-def _pack_tiles_f16_split(W: Tensor, n_tiles: int, chunk_k: Tensor) -> Tensor:
-    """Split-fp16 operand tiles of the f16 matrix pipe: per (chunk, tile) [K group (2)][hi | lo][lane (64)][8 halves],
-    returned as float32 words (same 1024 floats per tile as the fp32 packing).  w * 2^W_SHIFT = hi + lo with hi = fp16(.),
-    lo = fp16(. - hi): the scale keeps the low halves out of the fp16 subnormal range; the kernel undoes it exactly."""
-    N, K = W.shape
-    Wext = torch.zeros(32 * n_tiles, K + 1, dtype=torch.float32)
-    Wext[:N, :K] = W * float(1 << W_SHIFT)
-    chunks = chunk_k.shape[0]
-    k = chunk_k.clamp(max=K)                                                 # (chunks, 64, 16); k >= K -> zero column
-    lane = torch.arange(64)
-    n = 32 * torch.arange(n_tiles)[:, None] + (lane % 32)[None, :]           # (tiles, 64)
-    w = Wext[n[None, :, :, None].expand(chunks, -1, -1, 16), k[:, None, :, :].expand(-1, n_tiles, -1, -1)]   # (chunks,tiles,64,16)
-    hi = w.half()
-    lo = (w - hi.float()).half()
-    both = torch.stack([hi, lo], dim=2)                                      # (chunks, tiles, hl, 64, 16)
-    both = both.reshape(chunks, n_tiles, 2, 64, 2, 8).permute(0, 1, 4, 2, 3, 5).contiguous()   # -> (.., kg, hl, lane, 8)
-    return both.view(torch.float32).reshape(chunks, n_tiles, 1024)
-
-
-def pack_fused_weights(m, device, split_fp16: bool = False):
-    """Weights of the fused per-sample kernel (csrc/car_fused.hip) in its operand order: (blob, bias table)."""
-    f = lambda t: t.detach().float().cpu().reshape(t.shape[0], -1)
-    v = lambda t: t.detach().float().cpu()
-    C = m.query_encode_latent.weight.shape[0]
-    E2 = C // 2
-    wr = f(m.query_repeat_embed.weight)
-    w2 = f(m.query_encode_latent_2.weight)
-    # 128-output chained layers: fp32 tiles, or fp16 hi/lo tiles when the f16 matrix pipe is used
-    pk4 = (lambda W, ck: _pack_tiles_f16_split(W, 4, ck)) if split_fp16 else (lambda W, ck: _pack_tiles(W, None, 4, ck))
-    parts = [
-        _pack_tiles_f16_split(w2, E2 // 32, _std_k(C // 32)) if split_fp16 else _pack_tiles(w2, None, E2 // 32, _std_k(C // 32)),   # W2
-        _pack_tiles(f(m.query_embed.weight), v(m.query_embed.bias), 4, _std_k(1)),                            # Q1 (bias folded)
-        pk4(f(m.query_embed_2.weight), _chained_k(4)),                                                        # Q2
-        _pack_tiles(wr[:, 128:].contiguous(), v(m.query_repeat_embed.bias), 4, _std_k(1)),                    # UG (bias folded)
-        torch.cat([pk4(f(m.key_map.weight), _chained_k(E2 // 32, base=E2 * sv)) for sv in range(2)]),         # K1
-        pk4(f(m.key_map_2.weight), _chained_k(4)),                                                            # K2
-    ]
-    blob = torch.cat([p_.reshape(-1) for p_ in parts]).to(device)
-    bias = torch.cat([v(m.query_encode_latent_2.bias), v(m.query_embed_2.bias), v(m.key_map.bias), v(m.key_map_2.bias)]).to(device)
-    return blob, bias
-
-
-def _std16_k(ksteps: int) -> Tensor:
-    """16x16x32 tiles, standard mapping: K step m, lane l, element e -> k = 32 m + 8 (l >> 4) + e"""
-    m = torch.arange(ksteps)[:, None, None]
-    lane = torch.arange(64)[None, :, None]
-    e = torch.arange(8)[None, None, :]
-    return 32 * m + 8 * (lane // 16) + e
-
-
-def _chained16_k(ksteps: int, base: int = 0) -> Tensor:
-    """16x16x32 tiles chained over the accumulators of 16-row source tiles (channel 16 T + 4 (l >> 4) + r): K step m takes
-    source tiles 2m and 2m+1, so  k = base + 16 (2 m + e // 4) + 4 (l >> 4) + e % 4"""
-    m = torch.arange(ksteps)[:, None, None]
-    lane = torch.arange(64)[None, :, None]
-    e = torch.arange(8)[None, None, :]
-    return base + 16 * (2 * m + e // 4) + 4 * (lane // 16) + e % 4
-
-
-def _pack_tiles16_f16_split(W: Tensor, bias: Optional[Tensor], n_tiles: int, kmap: Tensor) -> Tensor:
-    """Split-fp16 A-operand tiles of v_mfma_f32_16x16x32_f16: per (K step, tile) [hi | lo][lane (64)][8 halves] = 512 float32
-    words; lane l carries output channel 16 tile + l % 16 and the eight k of ``kmap[step, l]`` (k == K: the bias, k > K: zero).
-    Weights carry 2^W_SHIFT like _pack_tiles_f16_split."""
-    N, K = W.shape
-    Wext = torch.zeros(16 * n_tiles, K + 2, dtype=torch.float32)
-    Wext[:N, :K] = W * float(1 << W_SHIFT)
-    if bias is not None:
-        Wext[:N, K] = bias * float(1 << W_SHIFT)
-    ks = kmap.shape[0]
-    k = kmap.clamp(max=K + 1)                                                # (ks, 64, 8)
-    lane = torch.arange(64)
-    n = 16 * torch.arange(n_tiles)[:, None] + (lane % 16)[None, :]           # (tiles, 64)
-    w = Wext[n[None, :, :, None].expand(ks, -1, -1, 8), k[:, None, :, :].expand(-1, n_tiles, -1, -1)]      # (ks, tiles, 64, 8)
-    hi = w.half()
-    lo = (w - hi.float()).half()
-    both = torch.stack([hi, lo], dim=2).contiguous()                         # (ks, tiles, hl, 64, 8)
-    return both.view(torch.float32).reshape(ks, n_tiles, 512)
-
-
-def pack_fused2_weights(m, device):
-    """Weights of csrc/car_fused2.hip (16x16x32 f16 tiles, every layer split-fp16) in its operand order: (blob, bias table)."""
-    f = lambda t: t.detach().float().cpu().reshape(t.shape[0], -1)
-    v = lambda t: t.detach().float().cpu()
-    C = m.query_encode_latent.weight.shape[0]
-    E2 = C // 2
-    wr = f(m.query_repeat_embed.weight)
-    pk = _pack_tiles16_f16_split
-    parts = [
-        pk(f(m.query_encode_latent_2.weight), None, E2 // 16, _std16_k(C // 32)),                             # W2
-        pk(f(m.query_embed.weight), v(m.query_embed.bias), 8, _std16_k(1)),                                   # Q1 (bias folded)
-        pk(f(m.query_embed_2.weight), None, 8, _chained16_k(4)),                                              # Q2
-        pk(wr[:, 128:].contiguous(), v(m.query_repeat_embed.bias), 8, _std16_k(1)),                           # UG (bias folded)
-        torch.cat([pk(f(m.key_map.weight), None, 8, _chained16_k(E2 // 32, base=E2 * sv)) for sv in range(2)]),   # K1
-        pk(f(m.key_map_2.weight), None, 8, _chained16_k(4)),                                                  # K2
-    ]
-    blob = torch.cat([p_.reshape(-1) for p_ in parts]).to(device)
-    bias = torch.cat([v(m.query_encode_latent_2.bias), v(m.query_embed_2.bias), v(m.key_map.bias), v(m.key_map_2.bias)]).to(device)
-    return blob, bias
-
-
-def pack_round2_weights(m, device):
-    """query_repeat_embed_2 (128 -> 128) in the operand order of csrc/car_round2.hip: (packed [4,4,1024], bias [128])."""
-    W = m.query_repeat_embed_2.weight.detach().float().cpu().reshape(128, 128)
-    return (_pack_tiles_f16_split(W, 4, _std_k(4)).reshape(-1).to(device),
-            m.query_repeat_embed_2.bias.detach().float().to(device).contiguous())
-
-
 class RenderEngine:
     """Per-module state of the HIP path: packed weights (re-packed when the parameters change) and the
     channel-last copies of the last feature pyramid."""
@@ -207,34 +72,35 @@ class RenderEngine:
         self._packed_key = None
         self._maps_key = None
         self._maps: List[Tensor] = []
+        self._maps_src = None          # the z tensors the channel-last copies were made from (kept alive, see _channel_last)
         self._steps: Dict[tuple, Tensor] = {}
         self.linear_flags = 0          # tests may set NO_GLDS for A/B
-        self.timing = None             # bench: dict layer name -> [(start, end) HIP events on the launch stream]
         self.pose_records = None       # tests: (b*V, 96) CarPose records to use instead of the host pose algebra
         # first point-MLP layer as a gather over per-texel pre-projected maps (csrc/car_encode.hip) instead of a
         # K=579 GEMM per sample; False selects the literal gather -> GEMM pipeline (A/B and stage tests)
         self.project_maps = True
-        # geometry + encode + 576->288 + key/query MLPs + logits as one kernel (csrc/car_fused.hip); needs V == 2, three
-        # pyramid levels, C == 576.  False keeps the stage-by-stage pipeline (A/B and stage tests)
+        # the one-call C ABI with the fused per-sample kernel (needs V == 2, three pyramid levels, C == 576); False keeps the
+        # stage-by-stage pipeline of this module (A/B and stage tests)
         self.fuse_samples = True
-        # 576->288 layer of the fused kernel on the f16 matrix pipe with fp16 hi/lo operand splits (3 products per term,
-        # fp32-class accuracy) instead of the fp32 pipe
-        self.split_fp16 = True
-        # 4: csrc/car_fused4.hip (as 2 with 12 waves x 16 samples, three waves per SIMD, same packed weights);
-        # 2: csrc/car_fused2.hip (8 waves x 16 samples, 16x16x32 f16 tiles, two waves per SIMD; always split-fp16);
-        # 1: csrc/car_fused.hip (4 waves x 32 samples, one wave per SIMD; fp32 or split-fp16 per ``split_fp16``)
-        self.fused_version = 4
-        self.fuse_round2 = True        # round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
+        self.fuse_round2 = True        # staged route: round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
+        # sizing of the one-call route (tests shrink them to force several calls)
+        self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
+        self.max_level_bytes = (1 << 32) - 1               # a projected level of one call: the fused kernel's 32-bit texel offsets
+        self.last_calls = 0            # number of car_render_forward calls the last forward was split into
         self._round2_key = None
         self._round2 = None
-        self._fused_key = None
-        self._fused = None
         self._pose_key = None
         self._pose_dev = None
         self._pose_src = None
         self._gmaps_key = None
         self._gmaps: List[Tensor] = []
         self._wpt: Optional[Tensor] = None
+        self._plan_key = None
+        self._plan: Optional[Tensor] = None
+        self._plan_keep: List[Tensor] = []
+        self._pair_key = None
+        self._pair: Optional[Tensor] = None
+        self._work: Optional[Tensor] = None
 
     # ------------------------------------------------------------------ weights
     def _weights(self, device) -> Dict[str, PackedLinear]:
@@ -270,10 +136,14 @@ class RenderEngine:
 
     # ------------------------------------------------------------------ feature maps
     def _channel_last(self, z: List[Tensor]) -> List[Tensor]:
+        """Channel-last copies of the pyramid, cached on the identity/version of the z tensors.  The tensors themselves are kept
+        next to the key: a freed z would hand its address (and _version 0) to the next scene's pyramid of the same shape, and
+        the stale maps would be rendered."""
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in z)
-        if key != self._maps_key:
+        if key != self._maps_key or self._maps_src is None or any(a is not b_ for a, b_ in zip(self._maps_src, z)):
             self._maps = [t.detach().float().permute(0, 2, 3, 1).contiguous() for t in z]
             self._maps_key = key
+            self._maps_src = list(z)
         return self._maps
 
     def _projected_maps(self, maps: List[Tensor], device):
@@ -331,18 +201,201 @@ class RenderEngine:
             self._steps[k] = torch.linspace(a, b_, P).to(device)      # CPU linspace, like the reference's values
         return self._steps[k]
 
+    def _round2_weights(self, device):
+        """query_repeat_embed[:, 128:] and query_repeat_embed_2 packed for csrc/car_round2.hip (device-side packer of the C ABI)."""
+        m = self.m
+        ps = (m.query_repeat_embed.weight, m.query_repeat_embed.bias, m.query_repeat_embed_2.weight, m.query_repeat_embed_2.bias)
+        key = tuple((t.data_ptr(), t._version) for t in ps) + (str(device),)
+        if key != self._round2_key:
+            lib = self.lib
+            f = [t.detach().to(device=device, dtype=torch.float32).reshape(t.shape[0], -1).contiguous() for t in ps]
+            w = torch.empty(lib.car_round2_packed_floats(), device=device, dtype=torch.float32)
+            bz = torch.empty(lib.car_round2_bias_floats(), device=device, dtype=torch.float32)
+            _lib.check(lib.car_round2_pack(_ptr(f[0]), _ptr(f[1]), _ptr(f[2]), _ptr(f[3]), _ptr(w), _ptr(bz), _stream()), "car_round2_pack")
+            self._round2, self._round2_key = (w, bz), key
+        return self._round2
+
+    # ------------------------------------------------------------------ the one-call route (default configuration)
+    def _dims(self, b: int, R: int, z: List[Tensor]) -> "_lib.CarDims":
+        m = self.m
+        d = _lib.CarDims()
+        d.b, d.V, d.R, d.P, d.H, d.W = b, m.n_view, R, m.npoints, m.H, m.W
+        d.n_levels = len(z)
+        for l, t in enumerate(z):
+            d.level_c[l], d.level_h[l], d.level_w[l] = t.shape[1], t.shape[2], t.shape[3]
+        d.repeat_attention = int(m.repeat_attention)
+        return d
+
+    def _plan_for(self, d, device) -> Tensor:
+        """car_plan_build: every layer packed for the kernels, once per set of parameter values."""
+        m, lib = self.m, self.lib
+        names = list(_lib.WEIGHT_FIELDS[0]) + [f"phi.lin_z.{i}" for i in range(3)] + [f"phi.blocks.{i}.fc_0" for i in range(3)] \
+            + [f"phi.blocks.{i}.fc_1" for i in range(3)]
+        sd = dict(m.named_parameters())
+        key = (str(device), d.P, tuple(d.level_c[:d.n_levels])) + tuple(
+            (sd[n + k].data_ptr(), sd[n + k]._version) for n in names for k in (".weight", ".bias"))
+        if key == self._plan_key:
+            return self._plan
+        keep: List[Tensor] = []
+
+        def dev(name):
+            t = sd[name].detach().to(device=device, dtype=torch.float32)
+            t = t.reshape(t.shape[0], -1).contiguous() if t.dim() > 1 else t.contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        w = _lib.CarWeights()
+        for n in _lib.WEIGHT_FIELDS[0]:
+            setattr(w, f"{n.replace('.', '_')}_w", dev(n + ".weight"))
+            setattr(w, f"{n.replace('.', '_')}_b", dev(n + ".bias"))
+        for i in range(3):
+            w.phi_lin_z_w[i], w.phi_lin_z_b[i] = dev(f"phi.lin_z.{i}.weight"), dev(f"phi.lin_z.{i}.bias")
+            w.phi_fc_0_w[i], w.phi_fc_0_b[i] = dev(f"phi.blocks.{i}.fc_0.weight"), dev(f"phi.blocks.{i}.fc_0.bias")
+            w.phi_fc_1_w[i], w.phi_fc_1_b[i] = dev(f"phi.blocks.{i}.fc_1.weight"), dev(f"phi.blocks.{i}.fc_1.bias")
+        nbytes = lib.car_plan_bytes(ctypes.byref(d))
+        if nbytes == 0:
+            _lib.check(-1, "car_plan_bytes")
+        plan = torch.empty(nbytes // 4, device=device, dtype=torch.float32)
+        _lib.check(lib.car_plan_build(ctypes.byref(d), ctypes.byref(w), _ptr(plan), _stream()), "car_plan_build")
+        self._plan, self._plan_key, self._plan_keep = plan, key, keep
+        self._pair_key = None
+        return plan
+
+    def _pair_for(self, d, plan: Tensor, z: List[Tensor], device) -> Tensor:
+        """car_project_maps: the first point-MLP layer applied per texel of the pyramid, once per stereo pair (and weights)."""
+        maps = self._channel_last(z)
+        key = (self._maps_key, self._plan_key)
+        if key != self._pair_key or self._pair is None:
+            lib = self.lib
+            self._pair = None                                # release the previous pair's maps before allocating
+            pair = torch.empty(lib.car_gmaps_floats(ctypes.byref(d)), device=device, dtype=torch.float32)
+            ptrs = (ctypes.c_void_p * len(maps))(*[t.data_ptr() for t in maps])
+            _lib.check(lib.car_project_maps(ctypes.byref(d), _ptr(plan), ptrs, _ptr(pair), _stream()), "car_project_maps")
+            self._pair, self._pair_key = pair, key
+        return self._pair
+
+    def _workspace_budget(self, device) -> int:
+        if self.max_workspace_bytes is not None:
+            return int(self.max_workspace_bytes)
+        free, _ = torch.cuda.mem_get_info(device)
+        cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        mine = self._work.numel() * 4 if self._work is not None else 0
+        return int(0.85 * (free + cached + mine))
+
+    def _render_one_call(self, inp, z, poses, uv, steps, b, V, R, P, H, W, debug) -> Dict[str, Tensor]:
+        m, lib = self.m, self.lib
+        dev = uv.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        n = b * V
+        d_all = self._dims(b, R, z)
+        plan = self._plan_for(d_all, dev)
+        pair = self._pair_for(d_all, plan, z, dev)
+        level_off = [lib.car_gmaps_level_offset(ctypes.byref(d_all), l) for l in range(3)]
+        level_scene = [V * z[l].shape[2] * z[l].shape[3] * 576 for l in range(3)]                # floats per scene
+        gmeta_ptr = pair.data_ptr() + 4 * lib.car_gmeta_offset(ctypes.byref(d_all))
+
+        # scenes per call: a projected level must stay below 4 GiB (32-bit texel offsets in the fused kernel); rays per call: the
+        # workspace (~0.44 MB per ray at 64 samples) must fit the free memory.  Rays are independent, so the split is exact.
+        gs = max(1, min(b, min(self.max_level_bytes // (4 * ls) for ls in level_scene)))
+        budget = self._workspace_budget(dev)
+
+        def ws_bytes(nb, nr):
+            return lib.car_workspace_bytes(ctypes.byref(self._dims(nb, nr, z)))
+
+        while gs > 1 and ws_bytes(gs, R) > budget:
+            gs = (gs + 1) // 2
+        rc = R
+        if ws_bytes(gs, R) > budget:
+            per_ray = ws_bytes(gs, 4800) / 4800.0
+            rc = int(budget / per_ray) // 48 * 48            # whole sample groups of the fused kernel (48 rays)
+            if rc < 48:
+                raise RuntimeError(f"forward: {budget / 2**20:.0f} MiB of workspace cannot hold even 48 rays "
+                                   f"({ws_bytes(gs, 48) / 2**20:.0f} MiB needed): free device memory")
+        need = ws_bytes(gs, min(rc, R))
+        if self._work is None or self._work.numel() * 4 < need:
+            self._work = None
+            self._work = torch.empty(need // 4, **f32)
+        work = self._work
+
+        out = {"rgb": torch.empty(b, 1, R, 3, **f32), "valid_mask": torch.empty(b, R, 1, **f32), "depth_ray": torch.empty(b, R, 1, **f32),
+               "at_wt": torch.empty(n, R, P, **f32), "at_wt_max": torch.empty(n, R, 1, device=dev, dtype=torch.int32),
+               "coords": torch.empty(n, R, 9, **f32), "pixel_val": torch.empty(n, R, P, 2, **f32)}
+        lead = {"rgb": 1, "valid_mask": 1, "depth_ray": 1, "at_wt": V, "at_wt_max": V, "coords": V, "pixel_val": V}   # rows per scene
+        order = ("rgb", "valid_mask", "depth_ray", "at_wt", "at_wt_max", "coords", "pixel_val")
+        st = _stream()
+        calls = 0
+        d_last = None
+        for s0 in range(0, b, gs):
+            s1 = min(b, s0 + gs)
+            for r0 in range(0, R, rc):
+                r1 = min(R, r0 + rc)
+                d = self._dims(s1 - s0, r1 - r0, z)
+                whole = (r0 == 0 and r1 == R)
+                if whole:
+                    tgt = {k: out[k][s0 * lead[k]:s1 * lead[k]] for k in order}            # contiguous scene slices: written in place
+                    uv_c = uv[s0:s1]
+                else:
+                    tgt = {k: torch.empty((s1 - s0) * lead[k], r1 - r0, *out[k].shape[2 if k != "rgb" else 3:],
+                                          device=dev, dtype=out[k].dtype) for k in order}
+                    uv_c = uv[s0:s1, r0:r1].contiguous()
+                ci = _lib.CarInputs()
+                ci.poses = poses.data_ptr() + 4 * 96 * s0 * V
+                ci.uv = uv_c.data_ptr()
+                for l in range(3):
+                    ci.gmaps[l] = pair.data_ptr() + 4 * (level_off[l] + s0 * level_scene[l])
+                ci.gmeta = gmeta_ptr
+                ci.steps = steps.data_ptr()
+                co = _lib.CarOutputs(*[tgt[k].data_ptr() for k in order])
+                _lib.check(lib.car_render_forward(ctypes.byref(d), _ptr(plan), ctypes.byref(ci), ctypes.byref(co),
+                                                  _ptr(work), work.numel() * 4, st), "car_render_forward")
+                if not whole:
+                    for k in order:
+                        dst = out[k][:, 0] if k == "rgb" else out[k]
+                        dst[s0 * lead[k]:s1 * lead[k], r0:r1] = tgt[k]
+                calls += 1
+                d_last = d
+        self.last_calls = calls
+        res = {
+            "rgb": out["rgb"], "valid_mask": out["valid_mask"], "depth_ray": out["depth_ray"], "at_wt": out["at_wt"],
+            "at_wts": [out["at_wt"]], "at_wt_max": out["at_wt_max"].long(), "coords": out["coords"], "uv": inp["query"]["uv"],
+            # the reference returns pixel_val on the CPU (models.py:570), forcing a device sync on every call; here it stays on the
+            # device unless debug is set
+            "pixel_val": out["pixel_val"].cpu() if debug else out["pixel_val"], "z": z,
+        }
+        if debug:
+            if calls != 1:
+                raise RuntimeError("debug=True needs the forward to fit one car_render_forward call (intermediates live in its workspace)")
+
+            def ws(name, *shape):
+                off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+                _lib.check(lib.car_workspace_find(ctypes.byref(d_last), name.encode(), ctypes.byref(off), ctypes.byref(cnt)), "car_workspace_find")
+                return work[off.value:off.value + cnt.value].view(*shape).clone()
+            res["stages"] = {"rays": ws("rays", n, R, 12), "pt": ws("pt", n, R, P, 3), "local_coords": None,
+                             "g": ws("g", n, R, P, 16), "interp_val": ws("e", n, R, P, 576),
+                             "z_final": ws("zrep", b * R, 576)[:, :288].reshape(b, R, 288),
+                             "at_wt2": ws("at_wt2", n, R, P) if m.repeat_attention else None, "poses": poses}
+        return res
+
+    # ------------------------------------------------------------------ stage timing (csrc/car_render.hip)
+    def profile(self, on: bool) -> None:
+        """Brackets every stage of the one-call route with HIP events on the launch stream (no synchronisation)."""
+        self.lib.car_profile_enable(1 if on else 0)
+
+    def stage_times(self) -> List[tuple]:
+        """[(stage name, milliseconds)] of everything recorded since profile(True) / the last call; synchronises on the events."""
+        lib = self.lib
+        rows = []
+        for i in range(lib.car_profile_count()):
+            name, ms = ctypes.c_char_p(), ctypes.c_float()
+            _lib.check(lib.car_profile_read(i, ctypes.byref(name), ctypes.byref(ms)), "car_profile_read")
+            rows.append((name.value.decode(), ms.value))
+        lib.car_profile_reset()
+        return rows
+
     # ------------------------------------------------------------------ kernels
     def linear(self, x: Tensor, ldx: int, layer: PackedLinear, y: Tensor, ldy: int, M: int, flags: int = 0):
-        ev = None
-        if self.timing is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
         _lib.check(self.lib.car_linear(_ptr(x), ldx, _ptr(layer.packed), layer.K, layer.N, _ptr(y), ldy, M,
                                        flags | self.linear_flags, _stream()), "car_linear")
-        if ev is not None:
-            ev[1].record()
-            self.timing.setdefault(layer.name, []).append(
-                (ev[0], ev[1], 2.0 * M * (layer.K + 1) * layer.N, f"linear_kernel {layer.name}: {layer.K}->{layer.N} on {M} rows"))
 
     def gather(self, maps: List[Tensor], grid: Tensor, pts: int, mode: int, place: int, V: int, out: Tensor,
                ld_out: int, col_out: int):
@@ -357,13 +410,19 @@ class RenderEngine:
     # ------------------------------------------------------------------ the forward pass
     @torch.no_grad()
     def render(self, inp, z: List[Tensor], debug: bool = False) -> Dict[str, Tensor]:
+        dev = inp["query"]["uv"].device
+        if dev.type != "cuda":
+            raise RuntimeError("CrossAttentionRenderer.forward runs on the HIP engine only: move the model, the input "
+                               "dict and z to a ROCm device (there is no CPU fallback)")
+        # kernels are launched on the current device's current stream: make the tensors' device current for the call
+        with torch.cuda.device(dev):
+            return self._render(inp, z, debug)
+
+    def _render(self, inp, z: List[Tensor], debug: bool) -> Dict[str, Tensor]:
         m, lib = self.m, self.lib
         ctx, qry = inp["context"], inp["query"]
         uv_in = qry["uv"]
         dev = uv_in.device
-        if dev.type != "cuda":
-            raise RuntimeError("CrossAttentionRenderer.forward runs on the HIP engine only: move the model, the input "
-                               "dict and z to a ROCm device (there is no CPU fallback)")
         b, V = ctx["rgb"].shape[:2]
         n_qry, R = uv_in.shape[1:3]
         if n_qry != 1:
@@ -374,15 +433,20 @@ class RenderEngine:
         n, S = b * V, b * V * R * P
         st = _stream()
         f32 = dict(device=dev, dtype=torch.float32)
-        pk = self._weights(dev)
-        maps = self._channel_last(z)
-        C = sum(t.shape[3] for t in maps)
-        Dl = m.latent_dim
-
         # a3: pose algebra on the host, exactly the reference's torch calls
         poses = self._poses(inp, H, n, dev)
         uv = uv_in.detach().reshape(b, R, 2).float().contiguous()
         steps = self._linspace(0.1, 10.0, P, dev) if m.no_sample else self._linspace(0.0, 1.0, P, dev)
+
+        concat2 = (V == 2 and not m.no_latent_concat)
+        if (self.fuse_samples and self.project_maps and concat2 and not m.no_sample and len(z) == 3
+                and sum(t.shape[1] for t in z) == 576 and m.hidden_dim == 128 and m.phi.n_blocks == 3 and m.phi.d_hidden == 128):
+            return self._render_one_call(inp, z, poses, uv, steps, b, V, R, P, H, W, debug)
+
+        pk = self._weights(dev)
+        maps = self._channel_last(z)
+        C = sum(t.shape[3] for t in maps)
+        Dl = m.latent_dim
 
         # a4-a6: rays
         rays = torch.empty(n, R, 12, **f32)
@@ -391,12 +455,6 @@ class RenderEngine:
         phi_x = torch.zeros(b * R, ld_phi, **f32)
         _lib.check(lib.car_ray_setup(_ptr(poses), _ptr(uv), b, V, R, H, W, P, int(m.no_sample), _ptr(steps),
                                      _ptr(rays), _ptr(coords9), _ptr(phi_x), ld_phi, st), "car_ray_setup")
-
-        concat2 = (V == 2 and not m.no_latent_concat)
-        fused = (self.fuse_samples and self.project_maps and concat2 and not m.no_sample and len(maps) == 3 and C == 576
-                 and m.hidden_dim == 128)
-        if fused:
-            return self._render_fused(inp, z, maps, poses, rays, coords9, phi_x, ld_phi, steps, b, V, R, P, H, W, debug)
 
         # a6, a8, a9, a13: samples
         pixel_val = torch.empty(n, R, P, 2, **f32)
@@ -471,8 +529,7 @@ class RenderEngine:
         q = torch.empty(S, 128, **f32)
         self.linear(k1, 128, pk["query_embed_2"], q, 128, S)
 
-        return self._finish(inp, z, b, V, R, P, Ce, Dl, e, key, q, None, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi,
-                            debug)
+        return self._finish(inp, z, b, V, R, P, Ce, Dl, e, key, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug)
 
     def _encode_three_views(self, maps, poses, pixel_val, ptenc, pt_in, b, R, P, H, W, C, pk):
         """Cross-view exchange for three context views (models.py:345-475), restated literally: for the samples of context c
@@ -515,68 +572,9 @@ class RenderEngine:
         # channel index = ch*3 + k (torch.cat on dim 2 then flatten(1, 2), models.py:446)
         return enc.view(S, 3, C // 2).permute(0, 2, 1).contiguous().view(S, 3 * (C // 2))
 
-    def _render_fused(self, inp, z, maps, poses, rays, coords9, phi_x, ld_phi, steps, b, V, R, P, H, W, debug):
-        m, lib = self.m, self.lib
-        dev = poses.device
-        f32 = dict(device=dev, dtype=torch.float32)
-        S = b * V * R * P
-        gmaps, wpt = self._projected_maps(maps, dev)
-        key = tuple((p_.data_ptr(), p_._version) for p_ in (
-            m.query_encode_latent_2.weight, m.query_encode_latent_2.bias, m.query_embed.weight, m.query_embed.bias,
-            m.query_embed_2.weight, m.query_embed_2.bias, m.query_repeat_embed.weight, m.query_repeat_embed.bias,
-            m.key_map.weight, m.key_map.bias, m.key_map_2.weight, m.key_map_2.bias)) + (str(dev), self.split_fp16, self.fused_version)
-        version = self.fused_version
-        # the 16x16x32 kernels address texel rows by 32-bit byte offsets inside a level: a level of 4 GiB or more (more than 14 scenes
-        # of two 256x256 views in one call) goes through the first-generation kernel, which uses 64-bit addresses
-        if version in (2, 4) and max(t.numel() * 4 for t in gmaps) >= 1 << 32:
-            version = 1
-        key = key[:-1] + (version,)
-        v4 = version == 4
-        v2 = version == 2 or v4
-        if key != self._fused_key:
-            self._fused = pack_fused2_weights(m, dev) if v2 else pack_fused_weights(m, dev, self.split_fp16)
-            assert self._fused[0].numel() == (lib.car_fused2_blob_floats() if v2 else lib.car_fused_blob_floats())
-            assert self._fused[1].numel() == lib.car_fused_bias_floats()
-            self._fused_key = key
-        blob, bias = self._fused
-        e = torch.empty(S, 576, **f32)
-        q = torch.empty(S, 128, **f32)
-        ug = torch.empty(S, 128, **f32)
-        logit = torch.empty(S, **f32)
-        pt = torch.empty(S, 3, **f32)
-        pixel_val = torch.empty(S, 2, **f32)
-        L = 3
-        ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in gmaps])
-        hs = (ctypes.c_int * L)(*[t.shape[1] for t in gmaps])
-        ws = (ctypes.c_int * L)(*[t.shape[2] for t in gmaps])
-        ev = None
-        if self.timing is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-        if v2:
-            _lib.check((lib.car_fused_samples_v4 if v4 else lib.car_fused_samples_v2)(_ptr(poses), _ptr(rays), _ptr(steps), ptrs, hs, ws, L, 576, _ptr(wpt), _ptr(blob),
-                                                _ptr(bias), b, V, R, P, H, W, _ptr(e), _ptr(q), _ptr(ug), _ptr(logit), _ptr(pt),
-                                                _ptr(pixel_val), _stream()), "car_fused_samples_v4" if v4 else "car_fused_samples_v2")
-        else:
-            _lib.check(lib.car_fused_samples(_ptr(poses), _ptr(rays), _ptr(steps), ptrs, hs, ws, L, 576, _ptr(wpt), _ptr(blob),
-                                             _ptr(bias), b, V, R, P, H, W, _ptr(e), _ptr(q), _ptr(ug), _ptr(logit), _ptr(pt),
-                                             _ptr(pixel_val), int(self.split_fp16), _stream()), "car_fused_samples")
-        if ev is not None:
-            ev[1].record()
-            # algorithmic MACs per sample on the matrix pipe: 2 x 576x288 (e), 576x128 + 128x128 (key), 16x128 + 128x128 (qry),
-            # 16x128 (ug); the gather FMAs and the geometry are not counted
-            macs = 2 * 576 * 288 + 576 * 128 + 128 * 128 + 16 * 128 + 128 * 128 + 16 * 128
-            pipe = "f16 matrix pipe, fp16 hi/lo split x3" if (self.split_fp16 or v2) else "fp32 matrix pipe"
-            kname = "fused4_kernel" if v4 else "fused2_kernel" if v2 else "fused_sample_kernel"
-            self.timing.setdefault("fused_samples", []).append(
-                (ev[0], ev[1], 2.0 * S * macs, f"{kname} on {S} samples (e, key, qry, ug, logits; {pipe})"))
-        return self._finish(inp, z, b, V, R, P, 576, m.latent_dim, e, None, q, logit, ug, pt, pixel_val, poses, rays, coords9,
-                            phi_x, ld_phi, debug, ug_ready=True)
-
-    def _finish(self, inp, z, b, V, R, P, Ce, Dl, e, key, q, logit, g_or_ug, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi,
-                debug, ug_ready=False):
-        """Attention rounds, decoder and output dict.  Either (key, q) or precomputed round-1
-        logits are given; ``g_or_ug`` is the geometric query g [S,16] or, with ug_ready, Wr1[:,128:] g + br1 [S,128]."""
+    def _finish(self, inp, z, b, V, R, P, Ce, Dl, e, key, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug):
+        """Attention rounds, decoder and output dict of the staged route; ``g`` is the geometric
+        query local_coords [S,16]."""
         m, lib = self.m, self.lib
         dev = e.device
         f32 = dict(device=dev, dtype=torch.float32)
@@ -585,15 +583,13 @@ class RenderEngine:
         n, S = b * V, b * V * R * P
         n_qry = 1
         qry = inp["query"]
-        k1 = torch.empty(S, 128, **f32) if not ug_ready else g_or_ug
         # a14 + a16: attention round 1, depth read-out
         at_wt = torch.empty(n, R, P, **f32)
         depth = torch.empty(b, R, **f32)
         amax = torch.empty(n, R, dtype=torch.int32, device=dev)
         rep = m.repeat_attention
         ebar = torch.empty(b * R, Ce, **f32)
-        _lib.check(lib.car_attend(_ptr(key) if logit is None else _ptr(logit), _ptr(q) if logit is None else None, 128,
-                                  _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt), _ptr(ebar),
+        _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt), _ptr(ebar),
                                   Ce, 1, _ptr(pt), _ptr(poses), _ptr(depth), _ptr(amax), st), "car_attend")
         zrep = torch.empty(b * R, V * Dl, **f32)
         at_wt2 = None
@@ -605,24 +601,18 @@ class RenderEngine:
             self.linear(z1, Dl, pk["encode_latent"], hb, 128, b * R)
             uh = torch.empty(b * R, 128, **f32)
             self.linear(hb, 128, pk["query_repeat_embed.h"], uh, 128, b * R)
-            if not ug_ready:
-                self.linear(g_or_ug, 16, pk["query_repeat_embed.g"], k1, 128, S)
             at_wt2 = torch.empty(n, R, P, **f32)
             if self.fuse_round2:
-                # q2 = Wr2 relu(ug + uh) + b and <q2, qry>/16 in one kernel: q2 is never written
-                w = m.query_repeat_embed_2.weight
-                rk = (w.data_ptr(), w._version, m.query_repeat_embed_2.bias._version, str(dev))
-                if rk != self._round2_key:
-                    self._round2 = pack_round2_weights(m, dev)
-                    self._round2_key = rk
+                # ug = Wr1[:,128:] g + br1, q2 = Wr2 relu(ug + uh) + b and <q2, qry>/16 in one kernel: neither is written
+                r2w, r2b = self._round2_weights(dev)
                 logit2 = torch.empty(S, **f32)
-                _lib.check(lib.car_round2_logits(_ptr(k1), _ptr(uh), _ptr(q), _ptr(self._round2[0]), _ptr(self._round2[1]),
+                _lib.check(lib.car_round2_logits(_ptr(g), _ptr(uh), _ptr(q), _ptr(r2w), _ptr(r2b),
                                                  b, V, R, P, _ptr(logit2), st), "car_round2_logits")
                 _lib.check(lib.car_attend(_ptr(logit2), None, 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt2),
                                           _ptr(ebar), Ce, 1, None, None, None, None, st), "car_attend")
             else:
-                if key is None:
-                    key = torch.empty(S, 128, **f32)
+                k1 = torch.empty(S, 128, **f32)
+                self.linear(g, 16, pk["query_repeat_embed.g"], k1, 128, S)
                 _lib.check(lib.car_add_ray_bias_relu(_ptr(k1), _ptr(uh), b, V, R, P, 128, st), "car_add_ray_bias_relu")
                 self.linear(k1, 128, pk["query_repeat_embed_2"], key, 128, S)
                 _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt2),
@@ -670,6 +660,6 @@ class RenderEngine:
         }
         if debug:
             out["stages"] = {"rays": rays, "pt": pt.view(n, R, P, 3),
-                             "local_coords": None if ug_ready else g_or_ug.view(n, R, P, 16), "interp_val": e.view(n, R, P, Ce),
+                             "local_coords": g.view(n, R, P, 16), "interp_val": e.view(n, R, P, Ce),
                              "z_final": zrep[:, :Dl].reshape(b, R, Dl), "at_wt2": at_wt2, "poses": poses}
         return out

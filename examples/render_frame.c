@@ -92,7 +92,11 @@ int main(int argc, char** argv) {
     void* ws = NULL;
     const size_t ws_bytes = car_workspace_bytes(&d);
     CHECK_HIP(hipMalloc(&ws, ws_bytes));
-    car_inputs in = {poses, uv, gmaps, NULL};
+    car_inputs in;
+    memset(&in, 0, sizeof in);
+    in.poses = poses; in.uv = uv;
+    for (int l = 0; l < d.n_levels; ++l) in.gmaps[l] = gmaps + car_gmaps_level_offset(&d, l);
+    in.gmeta = gmaps + car_gmeta_offset(&d);
     car_outputs out;
     memset(&out, 0, sizeof out);
     CHECK_HIP(hipMalloc((void**)&out.rgb, (size_t)d.R * 3 * sizeof(float)));

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAR_VERSION 100           /* 0.1.0 */
+#define CAR_VERSION 200           /* 0.2.0 */
 
 #define CAR_OK            0
 #define CAR_E_ARG        (-1)     /* invalid argument (null pointer, bad size, unsupported shape) */
@@ -117,35 +117,21 @@ int car_gather_encode(const float* const* gmaps, const int* level_h, const int* 
                       int n_maps, int V, long pts, float* out, int ld_out, void* stream);
 
 /* ---- a6-a13 + logits of a14 in ONE kernel for the default configuration (V = 2, three pyramid levels, C = 576, hidden
- * 128): geometry, per-texel-projected encode (car_gather_encode), 576->288 per source, key MLP, query MLP, round-2
- * local query half and the round-1 logits, with e / key / qry chained through the MFMA accumulator registers
- * (csrc/car_fused.hip).  `blob` / `bias` are the layer weights in the kernel's operand order; their sizes are given by
- * car_fused_blob_floats() / car_fused_bias_floats() and their layout is documented in csrc/car_fused.hip (the Python
- * host packs them in engine.pack_fused_weights).  Outputs: e [S,576], qry [S,128], ug [S,128], logit [S], pt [S,3],
- * pixel_val [S,2] with S = b*V*R*P.  prec 0: every layer on the fp32 matrix pipe; prec 1: the 576->288 layer on the f16 pipe
- * with both operands split into fp16 high/low halves (3 products per term, fp32-class accuracy; `blob` must be packed for it). */
+ * 128): geometry, per-texel-projected encode (car_gather_encode), 576->288 per source, key MLP, query MLP and the round-1
+ * logits, with e / key / qry chained through the MFMA accumulator registers (csrc/car_fused.hip; models.py:261-344, 487-532).
+ * Every layer runs on the f16 matrix pipe with both operands split into fp16 high/low halves (three products per term,
+ * fp32-class accuracy).  `blob` / `bias` are the layer weights in the kernel's operand order: car_fused_blob_floats() /
+ * car_fused_bias_floats() floats, written by car_plan_build (layout: csrc/car_fused_mma.h; the fp16 halves of each layer carry
+ * a power of two chosen from the layer's largest weight, recorded in `bias`).  `gmeta` [n_levels]: max |G_l| of every projected
+ * level (car_project_maps writes it), from which the kernel derives the power of two that keeps the activations of the first
+ * layer inside fp16's range.  Outputs: e [S,576], qry [S,128], g [S,16] (the geometric query local_coords, models.py:528),
+ * logit [S], pt [S,3], pixel_val [S,2] with S = b*V*R*P.  A level's projected map must stay below 4 GiB per call. */
 size_t car_fused_blob_floats(void);
 size_t car_fused_bias_floats(void);
 int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                      const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
+                      const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt,
                       const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                      float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, int prec, void* stream);
-
-/* Same stage, same inputs/outputs, second-generation CDNA4 mapping (csrc/car_fused2.hip): 8 waves x 16 samples per workgroup,
- * v_mfma_f32_16x16x32_f16 with fp16 hi/lo operand splits for every layer, two waves per SIMD.  `blob` is packed by
- * engine.pack_fused2_weights (car_fused2_blob_floats() floats); `bias` is the table of car_fused_bias_floats(). */
-size_t car_fused2_blob_floats(void);
-int car_fused_samples_v2(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                         const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
-                         const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                         float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, void* stream);
-
-/* Same stage, same blob and bias table as car_fused_samples_v2, three waves per SIMD (csrc/car_fused4.hip): 12 waves x 16 samples
- * per workgroup (48 consecutive rays x 4 consecutive steps), at most 168 registers per wave. */
-int car_fused_samples_v4(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                         const int* level_h, const int* level_w, int n_levels, int C, const float* wpt,
-                         const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                         float* e, float* qry, float* ug, float* logit, float* pt, float* pixel_val, void* stream);
+                      float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream);
 
 /* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
  *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).
@@ -167,11 +153,15 @@ int car_attend(const float* qa, const float* qb, int dq, const float* val, int D
                const float* zprev, float zprev_scale, float* w_out, float* z_out, int ld_z, int reps,
                const float* pt, const float* poses, float* depth, int32_t* w_argmax, void* stream);
 
-/* ---- a15, per-sample half in one kernel: logit[row] = <Wr2 relu(ug[row] + uh[ray(row)]) + br2, qry[row]> / 16
- * (models.py:552-555).  ug, qry [b*V,R,P,128]; uh [b,R,128]; wpacked: query_repeat_embed_2.weight (128x128) in MFMA
- * operand order, 4 chunks x 4 tiles, fp16 hi/lo halves scaled by 2^8 (engine.pack_round2_weights), no folded bias;
- * bias [128].  The second-round query q2 is never written. */
-int car_round2_logits(const float* ug, const float* uh, const float* qry, const float* wpacked, const float* bias,
+/* ---- a15, per-sample half in one kernel (models.py:549-555):
+ *     logit[row] = < Wr2 relu(Wr1[:,128:] g[row] + br1 + uh[ray(row)]) + br2 , qry[row] > / 16
+ * g [b*V,R,P,16] (local_coords), qry [b*V,R,P,128]; uh [b,R,128] = Wr1[:,:128] encode_latent(z1) (no bias).
+ * wpacked: car_round2_packed_floats() floats = query_repeat_embed_2.weight (128x128) then query_repeat_embed.weight[:,128:]
+ * (128x16) in MFMA operand order with fp16 hi/lo halves; bias: car_round2_bias_floats() floats = br1 [128], br2 [128], the two
+ * layers' 2^-shift, 0, 0 (both written by car_plan_build).  Neither the 128-wide local query half nor q2 is ever written. */
+size_t car_round2_packed_floats(void);
+size_t car_round2_bias_floats(void);
+int car_round2_logits(const float* g, const float* uh, const float* qry, const float* wpacked, const float* bias,
                       int b, int V, int R, int P, float* logit, void* stream);
 
 /* r[row, c] = relu(r[row, c] + u[ray(row), c]) with ray(row) = scene b, ray r of the sample row (models.py:549-553:
@@ -219,7 +209,10 @@ typedef struct car_weights {
 typedef struct car_inputs {
     const float* poses;            /* [b*V, CAR_POSE_FLOATS]  from car_pose_setup, or filled by the host (poses.py)        */
     const float* uv;               /* [b, R, 2] pixel coordinates (x = column, y = row)                                     */
-    const float* gmaps;            /* projected maps from car_project_maps: levels back to back, [b*V, Hl, Wl, 576] each     */
+    const float* gmaps[CAR_MAX_LEVELS];   /* projected level l of THESE b scenes, [b*V, Hl, Wl, 576] (car_project_maps fills one buffer
+                                      with the levels back to back, car_gmaps_level_offset() gives each level's start; a host that
+                                      renders a sub-range of scenes offsets every pointer by scene0 * V * Hl * Wl * 576 floats)          */
+    const float* gmeta;            /* [CAR_MAX_LEVELS] max |G_l| per level, the last floats of car_project_maps' buffer (car_gmeta_offset) */
     const float* steps;            /* optional [P]: sample positions along the epipolar segment.  NULL = the plan's linspace(0,1,P)
                                       (car_linspace).  torch.linspace itself differs in the last ulp between hosts (its vectorised
                                       kernel depends on the CPU's vector width), so a host that wants torch's exact values passes them. */
@@ -235,14 +228,37 @@ typedef struct car_outputs {       /* the tensors of the reference's output dict
     float* pixel_val;              /* [b*V, R, P, 2]                                                                         */
 } car_outputs;
 
+/* The two split-fp16 packers car_plan_build is made of, exported for hosts that drive the stage entries themselves:
+ *   car_fused_pack : blob [car_fused_blob_floats()], bias [car_fused_bias_floats()], wpt [576*4] for car_fused_samples / car_gather_encode
+ *                    (only the first six layer pairs of car_weights are read);
+ *   car_round2_pack: wr1 = query_repeat_embed.weight (128, 144), wr2 = query_repeat_embed_2.weight (128, 128) ->
+ *                    wpacked [car_round2_packed_floats()], bias [car_round2_bias_floats()] for car_round2_logits. */
+int car_fused_pack(const car_weights* weights, float* blob, float* bias, float* wpt, void* stream);
+int car_round2_pack(const float* wr1, const float* br1, const float* wr2, const float* br2, float* wpacked, float* bias, void* stream);
+
 size_t car_plan_bytes(const car_dims* dims);
 int car_plan_build(const car_dims* dims, const car_weights* weights, void* plan, void* stream);
-size_t car_gmaps_floats(const car_dims* dims);
+size_t car_gmaps_floats(const car_dims* dims);                 /* all levels + CAR_MAX_LEVELS floats of gmeta                   */
+size_t car_gmaps_level_offset(const car_dims* dims, int level);  /* float offset of level l inside that buffer                   */
+size_t car_gmeta_offset(const car_dims* dims);                 /* float offset of gmeta inside that buffer                      */
 /* maps[l]: level l of the encoder's pyramid, channel-last [b*V, Hl, Wl, Cl] (`maps` is a host array of device pointers). */
 int car_project_maps(const car_dims* dims, const void* plan, const float* const* maps, float* gmaps, void* stream);
 size_t car_workspace_bytes(const car_dims* dims);
 int car_render_forward(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* Where a named intermediate lives inside the workspace after car_render_forward (tests, debugging, profiling): one of
+ * "rays" "e" "qry" "g" "logit" "logit2" "pt" "at_wt2" "ebar" "z1" "uh" "zrep" "out3".  Returns 0 and the float offset / count. */
+int car_workspace_find(const car_dims* dims, const char* name, size_t* offset_floats, size_t* n_floats);
+
+/* ---- stage timing (the reference's only hooks are record_function labels, resnet_block_fc.py:54, 139, and one time.time() pair,
+ * eval_realestate10k.py:151-164).  With profiling on, car_render_forward brackets every stage it launches with a pair of HIP
+ * events on the caller's stream (no synchronisation, a few microseconds of host time per stage); car_profile_read synchronises on
+ * the recorded events and returns the stages' times.  Per host thread. */
+void car_profile_enable(int on);                               /* also drops the recorded stages                                 */
+int car_profile_count(void);                                   /* stages recorded since enable / the last read                   */
+int car_profile_read(int i, const char** name, float* ms);     /* stage i; CAR_E_ARG when out of range                            */
+void car_profile_reset(void);
+
 /* host helper: linspace(a, b, n) the way torch's scalar CPU kernel computes it (models.py:261): step = (b-a)/(n-1), first half
  * a + step*i, second half b - step*(n-1-i); `out` is a HOST array.  Equal to torch.linspace for n < 16, within 1 ulp otherwise. */
 void car_linspace(float a, float b, int n, float* out);

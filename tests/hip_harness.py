@@ -34,14 +34,21 @@ def to_device(inp, device):
 
 
 def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_poses=False, project_maps=True,
-             fuse_samples=True, split_fp16=True, fuse_round2=True, fused_version=None):
+             fuse_samples=True, fuse_round2=True, engine_setup=None, sd_edit=None, z_edit=None, poses=None):
     """Returns (config, fixture, oracle output dict (CPU), HIP output dict (tensors moved to CPU)).
 
     fixture_poses=True: both sides use the relative-pose matrices stored in the fixture (the ones the reference
-    computed in the build container) instead of running torch.inverse on this host."""
+    computed in the build container) instead of running torch.inverse on this host; ``poses`` (b*V, 96): explicit records for
+    both sides.  sd_edit / z_edit: functions applied to the case's state_dict / feature pyramid before either side sees them;
+    engine_setup(engine): last-minute engine knobs."""
     from cross_attention_renderer_amd.engine import RenderEngine
     c, inp, z, sd, fx = load_case(name)
-    poses = torch.as_tensor(fx["poses"]) if fixture_poses else None
+    if sd_edit is not None:
+        sd = sd_edit(dict(sd))
+    if z_edit is not None:
+        z = z_edit(z)
+    if poses is None:
+        poses = torch.as_tensor(fx["poses"]) if fixture_poses else None
     with torch.no_grad():
         ora = O.render_forward(sd, inp, z, oracle_cfg(c), debug=True, poses96=poses)
     m = build_module(c, sd, device)
@@ -50,10 +57,9 @@ def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_pos
     m._engine.pose_records = poses
     m._engine.project_maps = project_maps
     m._engine.fuse_samples = fuse_samples
-    m._engine.split_fp16 = split_fp16
     m._engine.fuse_round2 = fuse_round2
-    if fused_version is not None:
-        m._engine.fused_version = fused_version
+    if engine_setup is not None:
+        engine_setup(m._engine)
     with torch.no_grad():
         out = m(to_device(inp, device), z=[t.to(device) for t in z], debug=debug)
     torch.cuda.synchronize()
@@ -67,25 +73,6 @@ def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_pos
             return [cpu(x) for x in v]
         return v
     return c, fx, ora, cpu(out)
-
-
-def run_native(name: str, device="cuda:0", fixture_poses=False):
-    """The same case through the one-call C ABI (car_plan_build / car_project_maps / car_render_forward) and through the
-    Python engine: returns (engine output, native output), tensors on the CPU."""
-    from cross_attention_renderer_amd.engine import RenderEngine
-    from cross_attention_renderer_amd.native import NativeRenderer
-    c, inp, z, sd, fx = load_case(name)
-    poses = torch.as_tensor(fx["poses"]) if fixture_poses else None
-    m = build_module(c, sd, device)
-    m._engine = RenderEngine(m)
-    m._engine.pose_records = poses
-    dinp, dz = to_device(inp, device), [t.to(device) for t in z]
-    with torch.no_grad():
-        eng = m(dinp, z=dz)
-        nat = NativeRenderer(m, device).forward(dinp, dz, poses96=poses)
-    torch.cuda.synchronize()
-    keys = ("rgb", "valid_mask", "depth_ray", "at_wt", "at_wt_max", "coords", "pixel_val")
-    return {k: eng[k].detach().cpu() for k in keys}, {k: nat[k].detach().cpu() for k in keys}
 
 
 def err_stats(a, b) -> Dict[str, float]:
@@ -104,3 +91,15 @@ def ray_err(a, b, ray_dim: int):
     e = (a - b).abs() / b.abs().clamp_min(1.0)
     dims = [d for d in range(e.dim()) if d > ray_dim]
     return e.amax(dim=dims) if dims else e
+
+
+def argmax_exact_where_decided(got_idx, want_w, margin=1e-6):
+    """the per-view argmax of the attention weights must be exact on every ray whose decision margin (largest minus
+    second-largest reference weight of that view) exceeds ``margin``; closer calls are ties the last ulp may flip.  Returns
+    (number of decided rays, number of disagreements among them)."""
+    w = torch.as_tensor(np.asarray(want_w)).double()
+    top2 = w.topk(2, dim=-1).values
+    decided = (top2[..., 0] - top2[..., 1]) > margin
+    got = torch.as_tensor(np.asarray(got_idx)).reshape(w.shape[:-1])
+    want = w.argmax(dim=-1)
+    return int(decided.sum()), int(((got != want) & decided).sum())

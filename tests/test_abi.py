@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.car_version() == 100
+    assert lib.car_version() == 200
 
 
 def test_bad_arguments_return_codes_not_crashes(lib):
@@ -88,9 +88,15 @@ def test_one_call_abi_host_side(lib):
     for l, (c, h) in enumerate(((256, 64), (256, 128), (64, 256))):
         d.level_c[l], d.level_h[l], d.level_w[l] = c, h, h
     S = 2 * 8192 * 64
-    assert lib.car_workspace_bytes(ctypes.byref(d)) >= 4 * S * (576 + 128 + 128)          # e, qry, ug dominate
-    assert lib.car_plan_bytes(ctypes.byref(d)) >= 4 * lib.car_fused2_blob_floats()
-    assert lib.car_gmaps_floats(ctypes.byref(d)) == 2 * (64 * 64 + 128 * 128 + 256 * 256) * 576
+    assert lib.car_workspace_bytes(ctypes.byref(d)) >= 4 * S * (576 + 128 + 16)           # e, qry, g dominate
+    assert lib.car_plan_bytes(ctypes.byref(d)) >= 4 * (lib.car_fused_blob_floats() + lib.car_round2_packed_floats())
+    texels = 2 * (64 * 64 + 128 * 128 + 256 * 256)
+    assert lib.car_gmaps_floats(ctypes.byref(d)) == texels * 576 + 4                         # the levels + gmeta
+    assert lib.car_gmaps_level_offset(ctypes.byref(d), 1) == 2 * 64 * 64 * 576 and lib.car_gmeta_offset(ctypes.byref(d)) == texels * 576
+    off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.car_workspace_find(ctypes.byref(d), b"e", ctypes.byref(off), ctypes.byref(cnt)) == 0 and cnt.value == S * 576
+    assert lib.car_workspace_find(ctypes.byref(d), b"nope", ctypes.byref(off), ctypes.byref(cnt)) == -1
+    assert lib.car_profile_count() == 0
     d.V = 3                                                                                 # not covered by the one-call entry
     assert lib.car_workspace_bytes(ctypes.byref(d)) == 0 and b"n_view = 2" in lib.car_last_error()
     assert lib.car_render_forward(ctypes.byref(d), None, None, None, None, 0, None) == -1

@@ -1,84 +1,22 @@
-"""CPU check of the operand packing consumed by csrc/car_fused.hip: evaluating a layer exactly the way the kernel walks
-the packed tiles (chunk, tile, MFMA step, lane half) must reproduce W x for the standard and the chained K mappings."""
+"""Operand packing consumed by csrc/car_fused.hip and csrc/car_round2.hip.
+
+CPU: evaluating a layer exactly the way the MFMA contracts the packed tiles (K step, tile, lane group, element) must reproduce
+W x for the standard, bias-folded and chained K mappings (tests/pack_reference.py is the layout's reference statement).
+GPU: the device packers of the C ABI (car_fused_pack / car_round2_pack, csrc/car_render.hip) must emit exactly those bytes."""
+import ctypes
+
+import pytest
 import torch
 
+import pack_reference as PR
 from cross_attention_renderer_amd import synthetic as S
-from cross_attention_renderer_amd.engine import pack_fused_weights
 from cross_attention_renderer_amd.models import CrossAttentionRenderer
 
 
-def _walk(tiles, x_of):
-    """tiles (chunks, n_tiles, 4, 64, 4); x_of(chunk, r, h) -> scalar B operand of lane half h at MFMA step r."""
-    chunks, nt = tiles.shape[:2]
-    y = torch.zeros(32 * nt, dtype=torch.float64)
-    for c in range(chunks):
-        for j4 in range(4):
-            for e in range(4):
-                r = 4 * j4 + e
-                for h in range(2):
-                    a = tiles[c, :, j4, 32 * h:32 * h + 32, e].double().reshape(-1)      # outputs 0..32*nt-1
-                    y += a * x_of(c, r, h)
-    return y
-
-
-def test_fused_blob_layout():
-    from cross_attention_renderer_amd import _lib
+def _module(seed):
     m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=8).eval()
-    S.perturb_parameters(m, seed=1)
-    blob, bias = pack_fused_weights(m, "cpu")
-    lib = _lib.load()
-    assert blob.numel() == lib.car_fused_blob_floats() and bias.numel() == lib.car_fused_bias_floats()
-    g = torch.Generator().manual_seed(0)
-    T = 1024
-    perm = lambda r, h: (r & 3) + 8 * (r >> 2) + 4 * h
-    # W2: standard mapping, 18 chunks x 9 tiles
-    x = torch.randn(576, generator=g).double()
-    y = _walk(blob[:162 * T].reshape(18, 9, 4, 64, 4), lambda c, r, h: x[32 * c + 16 * h + r])
-    want = m.query_encode_latent_2.weight.detach().reshape(288, 576).double() @ x
-    assert (y - want).abs().max() < 1e-5
-    # Q1: standard, one chunk, bias folded at k = 16 (upper lane half, step 0 carries the constant 1)
-    gq = torch.randn(16, generator=g).double()
-    y = _walk(blob[162 * T:166 * T].reshape(1, 4, 4, 64, 4), lambda c, r, h: gq[r] if h == 0 else (1.0 if r == 0 else 0.0))
-    want = m.query_embed.weight.detach().reshape(128, 16).double() @ gq + m.query_embed.bias.detach().double()
-    assert (y - want).abs().max() < 1e-5
-    # Q2 / K2: chained over a 128-wide accumulator
-    for off, layer in ((166, m.query_embed_2), (258, m.key_map_2)):
-        x = torch.randn(128, generator=g).double()
-        y = _walk(blob[off * T:(off + 16) * T].reshape(4, 4, 4, 64, 4), lambda c, r, h: x[32 * c + perm(r, h)])
-        assert (y - layer.weight.detach().reshape(128, 128).double() @ x).abs().max() < 1e-5
-    # UG: standard with folded bias, the local_coords half of query_repeat_embed
-    y = _walk(blob[182 * T:186 * T].reshape(1, 4, 4, 64, 4), lambda c, r, h: gq[r] if h == 0 else (1.0 if r == 0 else 0.0))
-    wr = m.query_repeat_embed.weight.detach().reshape(128, 144).double()
-    assert (y - (wr[:, 128:] @ gq + m.query_repeat_embed.bias.detach().double())).abs().max() < 1e-5
-    # K1: chained over [e_0 ; e_1], 18 chunks x 4 tiles
-    x = torch.randn(576, generator=g).double()
-    y = _walk(blob[186 * T:258 * T].reshape(18, 4, 4, 64, 4), lambda c, r, h: x[288 * (c // 9) + 32 * (c % 9) + perm(r, h)])
-    assert (y - m.key_map.weight.detach().reshape(128, 576).double() @ x).abs().max() < 1e-5
-    # bias table order
-    assert torch.equal(bias[:288], m.query_encode_latent_2.bias.detach()) and torch.equal(bias[416:544], m.key_map.bias.detach())
-
-
-def test_split_fp16_packing_reconstructs_the_weights():
-    """hi + lo of the packed fp16 halves reproduces W * 2^8 to ~2^-21 relative, in the [K group][hi|lo][lane][8] order."""
-    from cross_attention_renderer_amd.engine import W_SHIFT, _pack_tiles_f16_split, _std_k
-    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=8).eval()
-    S.perturb_parameters(m, seed=2)
-    W = m.query_encode_latent_2.weight.detach().reshape(288, 576)
-    tiles = _pack_tiles_f16_split(W, 9, _std_k(18)).view(torch.float16).reshape(18, 9, 2, 2, 64, 8).float()
-    rec = (tiles[:, :, :, 0] + tiles[:, :, :, 1]) / float(1 << W_SHIFT)        # (chunk, tile, kg, lane, e)
-    for c, t, kg, lane, e in [(0, 0, 0, 0, 0), (3, 2, 1, 37, 5), (17, 8, 1, 63, 7), (9, 4, 0, 31, 3)]:
-        n, k = 32 * t + lane % 32, 32 * c + 16 * (lane // 32) + 8 * kg + e
-        assert abs(rec[c, t, kg, lane, e].item() - W[n, k].item()) <= 2e-6 * abs(W[n, k].item()) + 1e-9
-    # thanks to the 2^8 scale most low halves are normal fp16 numbers; the subnormal ones belong to residuals that are tiny
-    # anyway (absolute error <= 2^-25 in scaled units)
-    lo = tiles[:, :, :, 1].abs()
-    assert (lo[lo > 0] >= 6.1e-5).float().mean() > 0.9
-    n_idx = 32 * torch.arange(9)[:, None] + (torch.arange(64) % 32)[None, :]
-    for c in (0, 7, 17):
-        for kg in (0, 1):
-            k_idx = 32 * c + 16 * (torch.arange(64) // 32)[:, None] + 8 * kg + torch.arange(8)[None, :]      # (lane, e)
-            want = W[n_idx[:, :, None].expand(9, 64, 8), k_idx[None].expand(9, 64, 8)]
-            assert (rec[c, :, kg] - want).abs().max() <= 4e-7 * W.abs().max()
+    S.perturb_parameters(m, seed=seed)
+    return m
 
 
 def _walk16(tiles, x_of):
@@ -94,40 +32,133 @@ def _walk16(tiles, x_of):
     return y
 
 
-def test_fused2_blob_layout():
-    """Operand packing of csrc/car_fused2.hip: standard, bias-folded and chained K mappings of the 16x16x32 tiles."""
+def test_fused_blob_layout():
+    """Standard, bias-folded and chained K mappings of the 16x16x32 tiles, every layer with its own power of two."""
     from cross_attention_renderer_amd import _lib
-    from cross_attention_renderer_amd.engine import W_SHIFT, pack_fused2_weights
-    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=8).eval()
-    S.perturb_parameters(m, seed=1)
-    blob, bias = pack_fused2_weights(m, "cpu")
+    m = _module(1)
+    blob, bias, wpt = PR.pack_fused(m)
     lib = _lib.load()
-    assert blob.numel() == lib.car_fused2_blob_floats() and bias.numel() == lib.car_fused_bias_floats()
+    assert blob.numel() == lib.car_fused_blob_floats() and bias.numel() == lib.car_fused_bias_floats()
     T = 512
-    sc = float(1 << W_SHIFT)
+    down = {n: bias[672 + i].double().item() for i, n in enumerate(PR.LAYERS)}
     g = torch.Generator().manual_seed(0)
     halves = lambda a, b_, ks, nt: blob[a * T:b_ * T].view(torch.float16).reshape(ks, nt, 2, 64, 8).float()
     chained = lambda x, base=0: (lambda m_, q, e: x[base + 16 * (2 * m_ + e // 4) + 4 * q + e % 4])
     # W2: 18 K steps x 18 tiles, standard
     x = torch.randn(576, generator=g).double()
-    y = _walk16(halves(0, 324, 18, 18), lambda m_, q, e: x[32 * m_ + 8 * q + e]) / sc
+    y = _walk16(halves(0, 324, 18, 18), lambda m_, q, e: x[32 * m_ + 8 * q + e]) * down["W2"]
     want = m.query_encode_latent_2.weight.detach().reshape(288, 576).double() @ x
     assert (y - want).abs().max() < 1e-5
-    # Q1 / UG: one K step, lane group 2 element 0 carries the constant 1 of the folded bias
+    # Q1: one K step, lane group 2 element 0 carries the constant 1 of the folded bias
     gq = torch.randn(16, generator=g).double()
     gin = lambda m_, q, e: gq[8 * q + e] if q < 2 else (1.0 if (q == 2 and e == 0) else 0.0)
-    y = _walk16(halves(324, 332, 1, 8), gin) / sc
+    y = _walk16(halves(324, 332, 1, 8), gin) * down["Q1"]
     want = m.query_embed.weight.detach().reshape(128, 16).double() @ gq + m.query_embed.bias.detach().double()
     assert (y - want).abs().max() < 1e-5
-    wr = m.query_repeat_embed.weight.detach().reshape(128, 144).double()
-    y = _walk16(halves(364, 372, 1, 8), gin) / sc
-    assert (y - (wr[:, 128:] @ gq + m.query_repeat_embed.bias.detach().double())).abs().max() < 1e-5
     # Q2 / K2: chained over a 128-wide accumulator set (8 source tiles, 4 K steps)
-    for off, layer in ((332, m.query_embed_2), (516, m.key_map_2)):
+    for off, layer, name in ((332, m.query_embed_2, "Q2"), (508, m.key_map_2, "K2")):
         x = torch.randn(128, generator=g).double()
-        y = _walk16(halves(off, off + 32, 4, 8), chained(x)) / sc
+        y = _walk16(halves(off, off + 32, 4, 8), chained(x)) * down[name]
         assert (y - layer.weight.detach().reshape(128, 128).double() @ x).abs().max() < 1e-5
     # K1: chained over [e_0 ; e_1], 9 K steps per source
     x = torch.randn(576, generator=g).double()
-    y = sum(_walk16(halves(372 + 72 * sv, 372 + 72 * (sv + 1), 9, 8), chained(x, 288 * sv)) for sv in range(2)) / sc
+    y = sum(_walk16(halves(364 + 72 * sv, 364 + 72 * (sv + 1), 9, 8), chained(x, 288 * sv)) for sv in range(2)) * down["K1"]
     assert (y - m.key_map.weight.detach().reshape(128, 576).double() @ x).abs().max() < 1e-5
+    # bias table order, the point / bias bound of h
+    assert torch.equal(bias[:288], m.query_encode_latent_2.bias.detach()) and torch.equal(bias[416:544], m.key_map.bias.detach())
+    w1 = m.query_encode_latent.weight.detach().reshape(576, 579)
+    assert bias[677] >= (w1[:, 576:].abs().sum(1) + m.query_encode_latent.bias.detach().abs()).max() * (1 - 1e-6)
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-4, 3e3])
+def test_layer_scale_keeps_the_fp16_halves_normal(scale):
+    """Whatever the magnitude of a layer's weights, its packed high halves sit below 2^14 and hi + lo reproduces W 2^shift to
+    fp32 accuracy (absolute error below 2^-22 of the largest weight)."""
+    m = _module(2)
+    with torch.no_grad():
+        m.query_encode_latent_2.weight.mul_(scale)
+    W = m.query_encode_latent_2.weight.detach().reshape(288, 576)
+    p = PR.pow2_scale(W.abs().max().item())
+    assert 2 ** 13 <= W.abs().max().item() * p < 2 ** 14
+    tiles = PR.pack_tiles16(W, None, 18, PR.std16_k(18), p).view(torch.float16).reshape(18, 18, 2, 64, 8).float()
+    assert torch.isfinite(tiles).all() and tiles[:, :, 0].abs().max() < 2 ** 14
+    rec = (tiles[:, :, 0] + tiles[:, :, 1]) / p                               # (K step, tile, lane, e)
+    n_idx = 16 * torch.arange(18)[:, None] + (torch.arange(64) % 16)[None, :]
+    for ks in (0, 7, 17):
+        k_idx = 32 * ks + 8 * (torch.arange(64) // 16)[:, None] + torch.arange(8)[None, :]
+        want = W[n_idx[:, :, None].expand(18, 64, 8), k_idx[None].expand(18, 64, 8)]
+        assert (rec[ks] - want).abs().max() <= 2 ** -22 * W.abs().max()
+
+
+def test_round2_packing_layout():
+    """csrc/car_round2.hip: Wr2 in the accumulator ("chained") K order of the layer before it, then Wr1[:, 128:]; 32x32x16 tiles:
+    lane l = 32 h + i holds A[i][8 h + e] and B[8 h + e][.] of a K step (chunk, group kg)."""
+    m = _module(3)
+    packed, bias = PR.pack_round2(m)
+    from cross_attention_renderer_amd import _lib
+    lib = _lib.load()
+    assert packed.numel() == lib.car_round2_packed_floats() and bias.numel() == lib.car_round2_bias_floats()
+    g = torch.Generator().manual_seed(1)
+    w2 = packed[:16384].view(torch.float16).reshape(4, 4, 2, 2, 64, 8).double()      # (c, t, kg, hl, lane, e)
+    w2 = w2[:, :, :, 0] + w2[:, :, :, 1]
+    x = torch.randn(128, generator=g).double()
+    y = torch.zeros(128, dtype=torch.float64)
+    for c in range(4):
+        for kg in range(2):
+            for h in range(2):
+                for e in range(8):
+                    # B element e of lane half h in K step (c, kg) = accumulator register 8 kg + e of source tile c
+                    k = 32 * c + (e & 3) + 8 * (2 * kg + (e >> 2)) + 4 * h
+                    y += w2[c, :, kg, 32 * h:32 * h + 32, e].reshape(-1) * x[k]
+    want = m.query_repeat_embed_2.weight.detach().reshape(128, 128).double() @ x
+    assert (y * bias[257].double() - want).abs().max() < 1e-5
+    w1 = packed[16384:].view(torch.float16).reshape(4, 2, 64, 8).double()              # (t, hl, lane, e)
+    w1 = w1[:, 0] + w1[:, 1]
+    gq = torch.randn(16, generator=g).double()
+    y = torch.zeros(128, dtype=torch.float64)
+    for h in range(2):
+        for e in range(8):
+            y += w1[:, 32 * h:32 * h + 32, e].reshape(-1) * gq[8 * h + e]
+    want = m.query_repeat_embed.weight.detach().reshape(128, 144)[:, 128:].double() @ gq
+    assert (y * bias[256].double() - want).abs().max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1.0, 2e-4, 5e3])
+def test_device_packers_emit_the_reference_bytes(scale):
+    from cross_attention_renderer_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    m = _module(4)
+    with torch.no_grad():
+        for p_ in (m.query_encode_latent_2.weight, m.key_map.weight, m.query_embed.bias, m.query_repeat_embed_2.weight):
+            p_.mul_(scale)
+    blob, bias, wpt = PR.pack_fused(m)
+    r2w, r2b = PR.pack_round2(m)
+    keep = []
+
+    def d(t):
+        t = t.detach().float().reshape(t.shape[0], -1).contiguous().to(dev) if t.dim() > 1 else t.detach().float().contiguous().to(dev)
+        keep.append(t)
+        return t.data_ptr()
+    w = _lib.CarWeights()
+    for n in _lib.WEIGHT_FIELDS[0]:
+        mod = m
+        for part in n.split("."):
+            mod = getattr(mod, part)
+        setattr(w, f"{n.replace('.', '_')}_w", d(mod.weight))
+        setattr(w, f"{n.replace('.', '_')}_b", d(mod.bias))
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dblob, dbias, dwpt = torch.empty_like(blob, device=dev), torch.empty_like(bias, device=dev), torch.empty(576 * 4, device=dev)
+    rc = lib.car_fused_pack(ctypes.byref(w), dblob.data_ptr(), dbias.data_ptr(), dwpt.data_ptr(), st)
+    assert rc == 0, lib.car_last_error()
+    dr2w, dr2b = torch.empty_like(r2w, device=dev), torch.empty_like(r2b, device=dev)
+    rc = lib.car_round2_pack(w.query_repeat_embed_w, w.query_repeat_embed_b, w.query_repeat_embed_2_w, w.query_repeat_embed_2_b,
+                             dr2w.data_ptr(), dr2b.data_ptr(), st)
+    assert rc == 0, lib.car_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(dblob.cpu().view(torch.int32), blob.view(torch.int32))
+    assert torch.equal(dbias.cpu(), bias)
+    assert torch.equal(dwpt.cpu().view(576, 4), wpt)
+    assert torch.equal(dr2w.cpu().view(torch.int32), r2w.view(torch.int32))
+    assert torch.equal(dr2b.cpu(), r2b)

@@ -14,7 +14,7 @@ import torch
 
 import cases as C
 from golden_util import load_case, rel_err
-from hip_harness import run_native, build_module, err_stats, oracle_cfg, run_case, to_device
+from hip_harness import argmax_exact_where_decided, build_module, err_stats, oracle_cfg, run_case, to_device
 from oracle import car_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -131,8 +131,9 @@ def _check_outputs(got, want_of, what, frac=0.0, worst=TOL):
         e = err_stats(got[k], want_of(k))
         assert e["f1e-4"] <= frac and e["max"] <= worst, f"{what} {k}: {e}"
     assert (np.asarray(got["valid_mask"]) == np.asarray(want_of("valid_mask"))).all(), what
-    same = (np.asarray(got["at_wt_max"]) == np.asarray(want_of("at_wt_max"))).mean()
-    assert same > 0.995, f"{what} at_wt_max agreement {same}"
+    # argmax: exact wherever the reference's own weights decide it by more than 1e-6; the rest are ties
+    decided, wrong = argmax_exact_where_decided(got["at_wt_max"], want_of("at_wt"))
+    assert decided > 0 and wrong == 0, f"{what} at_wt_max: {wrong} of {decided} decided rays differ"
 
 
 @pytest.mark.parametrize("name", HIP_CASES)
@@ -180,68 +181,33 @@ def test_literal_gather_gemm_pipeline_matches_oracle(name):
     assert err_stats(out["stages"]["interp_val"], out2["stages"]["interp_val"])["max"] < 5e-5
 
 
-@pytest.mark.parametrize("version", [4, 2, 1])
-@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c3", "t2_c5"])
-def test_fused_sample_kernel_matches_stage_pipeline(name, version):
-    """A/B of csrc/car_fused2.hip / car_fused.hip (geometry + encode + e + key/query MLPs + logits in one kernel, everything
-    chained through the MFMA accumulators) against the stage-by-stage kernels; both against the oracle at 1e-4."""
-    c, fx, ora, fused = run_case(name, fuse_samples=True, fused_version=version)
-    assert fused["stages"]["local_coords"] is None, "the fused kernel was not selected"
+@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c3", "t2_c4", "t2_c5"])
+def test_one_call_route_matches_stage_pipeline(name):
+    """A/B of the product route (one-call C ABI: csrc/car_render.hip sequencing csrc/car_fused.hip — geometry + encode + e +
+    key/query MLPs + logits in one kernel on the f16 matrix pipe with fp16 hi/lo splits — and csrc/car_round2.hip) against the
+    stage-by-stage kernels of engine.py (every layer on the fp32 matrix pipe); both against the oracle at 1e-4."""
+    c, fx, ora, fused = run_case(name, fuse_samples=True)
+    assert fused["stages"]["local_coords"] is None, "the one-call route was not selected"
     _, _, _, staged = run_case(name, fuse_samples=False)
+    assert staged["stages"]["local_coords"] is not None
     assert rel_err(fused["stages"]["pt"], staged["stages"]["pt"]) < 1e-6
+    assert rel_err(fused["stages"]["g"], staged["stages"]["local_coords"]) < 1e-6
     assert rel_err(fused["pixel_val"], staged["pixel_val"]) < 1e-6
-    assert err_stats(fused["stages"]["interp_val"], staged["stages"]["interp_val"])["max"] < 5e-5
+    e = err_stats(fused["stages"]["interp_val"], staged["stages"]["interp_val"])
+    assert e["max"] < 5e-6, e                                         # split-fp16 is fp32 class: far inside the 1e-4 contract
     assert rel_err(fused["at_wt"], staged["at_wt"]) < 1e-5
+    assert rel_err(fused["stages"]["at_wt2"], staged["stages"]["at_wt2"]) < 1e-5
     assert rel_err(fused["rgb"], staged["rgb"]) < 2e-5
-    _check_outputs(fused, lambda k: ora[k], "fused vs oracle")
-
-
-@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c3", "t2_c5"])
-def test_split_fp16_layer_is_fp32_class(name):
-    """The 576->288 layer on the f16 matrix pipe with fp16 hi/lo operand splits (three exact products per term) against the
-    same kernel on the fp32 pipe: the per-sample features must agree to ~1e-6, i.e. far inside the 1e-4 contract."""
-    c, fx, ora, a = run_case(name, split_fp16=True, fused_version=1)
-    _, _, _, b_ = run_case(name, split_fp16=False, fused_version=1)
-    e = err_stats(a["stages"]["interp_val"], b_["stages"]["interp_val"])
-    assert e["max"] < 5e-6, e
-    assert rel_err(a["rgb"], b_["rgb"]) < 1e-5
-    _check_outputs(a, lambda k: ora[k], "split-fp16 vs oracle")
-    _check_outputs(b_, lambda k: ora[k], "fp32 pipe vs oracle")
-
-
-@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c3", "t2_c4"])
-def test_fused_v4_equals_v2(name):
-    """Three waves per SIMD (csrc/car_fused4.hip) against two (car_fused2.hip): same arithmetic per sample; only the order in which
-    the very first chunk adds its pyramid levels and the order of the key layer's two halves (e_1 first) differ, i.e. rounding."""
-    c, fx, ora, a = run_case(name, fused_version=4)
-    _, _, _, b_ = run_case(name, fused_version=2)
-    assert torch.equal(a["stages"]["pt"], b_["stages"]["pt"])
-    assert err_stats(a["stages"]["interp_val"], b_["stages"]["interp_val"])["max"] < 2e-6
-    assert rel_err(a["at_wt"], b_["at_wt"]) < 1e-5
-    assert rel_err(a["rgb"], b_["rgb"]) < 1e-5
-    _check_outputs(a, lambda k: ora[k], "fused v4 vs oracle")
-
-
-@pytest.mark.parametrize("name", ["t1_c1", "t2_c2", "t2_c4"])
-def test_fused_v2_matches_fp32_pipe_v1(name):
-    """The two-waves-per-SIMD kernel (16x16x32 f16 tiles, every layer split-fp16) against the first-generation kernel on the
-    fp32 matrix pipe: per-sample features to ~1e-6, attention weights and colours to 1e-5."""
-    c, fx, ora, a = run_case(name, fused_version=2)
-    _, _, _, b_ = run_case(name, fused_version=1, split_fp16=False)
-    assert rel_err(a["stages"]["pt"], b_["stages"]["pt"]) == 0
-    e = err_stats(a["stages"]["interp_val"], b_["stages"]["interp_val"])
-    assert e["max"] < 5e-6, e
-    assert rel_err(a["at_wt"], b_["at_wt"]) < 1e-5
-    assert rel_err(a["rgb"], b_["rgb"]) < 1e-5
-    _check_outputs(a, lambda k: ora[k], "fused v2 vs oracle")
+    _check_outputs(fused, lambda k: ora[k], "one-call route vs oracle")
+    _check_outputs(staged, lambda k: ora[k], "staged route vs oracle")
 
 
 @pytest.mark.parametrize("name", ["t0_default", "t0_p5", "t0_nview1", "t0_nview3", "t1_c1", "t2_c3"])
 def test_round2_logit_kernel_matches_stage_kernels(name):
-    """csrc/car_round2.hip (second-round query layer + logits, q2 never stored) against add_ray_bias_relu + car_linear +
-    the logits phase of car_attend."""
-    c, fx, ora, a = run_case(name, fuse_round2=True)
-    _, _, _, b_ = run_case(name, fuse_round2=False)
+    """csrc/car_round2.hip (local half of query_repeat_embed from g, second-round query layer and logits in one kernel, nothing of
+    it stored) against car_linear + add_ray_bias_relu + car_linear + the logits phase of car_attend, on the staged route."""
+    c, fx, ora, a = run_case(name, fuse_round2=True, fuse_samples=False)
+    _, _, _, b_ = run_case(name, fuse_round2=False, fuse_samples=False)
     assert rel_err(a["stages"]["at_wt2"], b_["stages"]["at_wt2"]) < 1e-5
     assert rel_err(a["rgb"], b_["rgb"]) < 1e-5
     _check_outputs(a, lambda k: ora[k], "fused round 2 vs oracle")
@@ -326,21 +292,28 @@ def test_whole_frame_call_equals_chunked_calls():
             assert rel_err(part["depth_ray"].cpu(), keep["depth_ray"][:, c0:c0 + 8192]) < 1e-5
             assert rel_err(part["at_wt"].cpu(), keep["at_wt"][:, c0:c0 + 8192]) < 1e-5
             assert torch.equal(part["valid_mask"].cpu(), keep["valid_mask"][:, c0:c0 + 8192])
-            assert (part["at_wt_max"].cpu() == keep["at_wt_max"][:, c0:c0 + 8192]).float().mean() > 0.999
+            assert torch.equal(part["at_wt_max"].cpu(), keep["at_wt_max"][:, c0:c0 + 8192])
     assert torch.isfinite(keep["rgb"]).all()
 
 
 
-@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c3", "t2_c4", "t2_c5"])
-def test_one_call_c_abi_equals_python_engine(name):
-    """car_plan_build + car_project_maps + car_render_forward (csrc/car_render.hip: weights packed on the device, the launch sequence
-    issued from C++) against the Python engine on the same module and inputs: same kernels in the same order, so every output tensor
-    is identical bit for bit — the C ABI is a complete boundary for the default configuration, not a helper of the Python host."""
-    eng, nat = run_native(name)
-    for k in eng:
-        assert eng[k].shape == nat[k].shape, k
-        assert torch.equal(eng[k], nat[k]), f"{name} {k}: max abs diff {(eng[k].double() - nat[k].double()).abs().max().item()}"
+@pytest.mark.parametrize("name,ws_mib,level_mib", [("t2_c3", 30, None), ("t2_c3", None, 200), ("t1_c1", 24, 4), ("t2_c2", 20, None)])
+def test_forward_split_into_several_calls_is_bit_identical(name, ws_mib, level_mib):
+    """The engine splits a forward into several car_render_forward calls when the workspace would not fit the free memory (ray
+    chunks) or a projected pyramid level would reach 4 GiB (scene groups, the fused kernel's 32-bit texel offsets).  Rays are
+    independent and every call sees whole sample groups, so the result must not change by a single bit.  The limits are shrunk
+    here to force the split on small cases."""
+    c, fx, ora, one = run_case(name, debug=False)
 
+    def setup(eng):
+        eng.max_workspace_bytes = None if ws_mib is None else ws_mib << 20
+        if level_mib is not None:
+            eng.max_level_bytes = level_mib << 20
+    calls = {}
+    _, _, _, many = run_case(name, debug=False, engine_setup=lambda e: (setup(e), calls.setdefault("eng", e)))
+    assert calls["eng"].last_calls > 1, "the limits did not force a split"
+    for k in ("rgb", "valid_mask", "depth_ray", "at_wt", "at_wt_max", "coords", "pixel_val"):
+        assert torch.equal(one[k], many[k]), f"{name} {k}: max abs diff {(one[k].double() - many[k].double()).abs().max().item()}"
 
 
 @pytest.mark.parametrize("R,P,b", [(37, 13, 1), (16, 8, 2), (131, 70, 1), (96, 32, 5)])
@@ -370,15 +343,15 @@ def test_fused_path_ragged_sizes_against_the_oracle(R, P, b):
         e = err_stats(out[k].cpu(), ora[k])
         assert e["max"] <= TOL, (k, e)
     assert torch.equal(out["valid_mask"].cpu(), ora["valid_mask"])
-    assert (out["at_wt_max"].cpu() == ora["at_wt_max"]).float().mean() > 0.99
+    decided, wrong = argmax_exact_where_decided(out["at_wt_max"].cpu(), ora["at_wt"])
+    assert decided > 0 and wrong == 0
 
 
 
 def test_one_call_c_abi_without_second_round():
-    """repeat_attention=False (models.py:547) through car_render_forward, the Python engine and the oracle at real widths."""
+    """repeat_attention=False (models.py:547) through car_render_forward and the oracle at real widths."""
     from cross_attention_renderer_amd import synthetic as S
     from cross_attention_renderer_amd.models import CrossAttentionRenderer
-    from cross_attention_renderer_amd.native import NativeRenderer
     dev = torch.device("cuda:0")
     H, P, R = 64, 32, 200
     torch.manual_seed(0)
@@ -393,9 +366,157 @@ def test_one_call_c_abi_without_second_round():
         md = m.to(dev)
         dinp, dz = to_device(inp, dev), [t.to(dev) for t in z]
         eng = md(dinp, z=dz)
-        nat = NativeRenderer(md, dev).forward(dinp, dz)
     torch.cuda.synchronize()
-    for k in ("rgb", "depth_ray", "at_wt", "valid_mask", "at_wt_max"):
-        assert torch.equal(eng[k].cpu(), nat[k].cpu()), k
     for k in ("rgb", "depth_ray", "at_wt"):
         assert err_stats(eng[k].cpu(), ora[k])["max"] <= TOL, k
+
+
+# ----------------------------------------------------------------------------------------------------------
+# dynamic range of the split-fp16 arithmetic (csrc/car_fused_mma.h): fp16 halves keep 11 bits only between 2^-14 and 65504
+# ----------------------------------------------------------------------------------------------------------
+def _rescale(sd, s):
+    """Moves every intermediate of the sample path by the factor s without changing the function: a layer feeding a ReLU is
+    scaled by s (weights and bias), the layer consuming it by 1/s.  h, k1, q1 and the round-2 hidden layer end up s times larger."""
+    sd = dict(sd)
+    for first, second in (("query_encode_latent", "query_encode_latent_2"), ("key_map", "key_map_2"), ("query_embed", "query_embed_2"),
+                          ("query_repeat_embed", "query_repeat_embed_2")):
+        sd[first + ".weight"] = sd[first + ".weight"] * s
+        sd[first + ".bias"] = sd[first + ".bias"] * s
+        sd[second + ".weight"] = sd[second + ".weight"] / s
+    return sd
+
+
+@pytest.mark.parametrize("name", ["t1_c1", "t2_c2"])
+@pytest.mark.parametrize("s", [1e-4, 1e-2, 1e2, 1e4])
+def test_split_fp16_dynamic_range_of_activations(name, s):
+    """Hidden activations 1e-4 ... 1e4 times their usual size (and the consuming weights the inverse): in plain fp16 halves the
+    small end sinks into subnormals and the large end overflows 65504; with the power-of-two operand scaling the one-call route
+    stays inside the 1e-4 contract, on the per-sample features as well as on the outputs."""
+    c, fx, ora, out = run_case(name, sd_edit=lambda sd: _rescale(sd, s))
+    assert out["stages"]["local_coords"] is None
+    _check_outputs(out, lambda k: ora[k], f"activations x{s:g}")
+    e = err_stats(out["stages"]["interp_val"], ora["stages"]["interp_val"])
+    assert e["max"] <= TOL, e
+    assert err_stats(out["stages"]["at_wt2"], ora["stages"]["at_wt2"])["max"] <= TOL
+
+
+@pytest.mark.parametrize("s", [1e-4, 1e4])
+def test_split_fp16_dynamic_range_of_the_feature_maps(s):
+    """The pyramid itself s times larger with the first layer's feature columns 1/s: same function, other operand ranges for the
+    per-texel projection and the gather."""
+    def sd_edit(sd):
+        w = sd["query_encode_latent.weight"].clone()
+        w[:, :576] = w[:, :576] / s
+        return dict(sd, **{"query_encode_latent.weight": w})
+    c, fx, ora, out = run_case("t1_c1", sd_edit=sd_edit, z_edit=lambda z: [t * s for t in z])
+    _check_outputs(out, lambda k: ora[k], f"feature maps x{s:g}")
+    assert err_stats(out["stages"]["interp_val"], ora["stages"]["interp_val"])["max"] <= TOL
+
+
+def test_split_fp16_with_outliers_in_the_feature_maps():
+    """A handful of 1e5 outliers in an otherwise N(0,1) pyramid: the launch-wide power of two of the first layer is set by the
+    outliers, the ordinary texels must keep their accuracy.  Errors are measured against the size of the values, as everywhere."""
+    def z_edit(z):
+        g = torch.Generator().manual_seed(11)
+        z = [t.clone() for t in z]
+        for t in z:
+            idx = torch.randint(0, t.numel(), (12,), generator=g)
+            t.view(-1)[idx] = 1e5 * torch.sign(torch.randn(12, generator=g))
+        return z
+    c, fx, ora, out = run_case("t1_c1", z_edit=z_edit)
+    _check_outputs(out, lambda k: ora[k], "outliers")
+    assert err_stats(out["stages"]["interp_val"], ora["stages"]["interp_val"])["max"] <= TOL
+
+
+# ----------------------------------------------------------------------------------------------------------
+# a3 on the device: car_pose_setup (fp64 Gauss-Jordan) against the host pose algebra (torch.inverse, the reference's call)
+# ----------------------------------------------------------------------------------------------------------
+def _device_poses(inp, H):
+    lib = _lib()
+    dev = torch.device("cuda:0")
+    ctx, q = inp["context"], inp["query"]
+    b, V = ctx["cam2world"].shape[:2]
+    t = [x.float().contiguous().to(dev) for x in (ctx["cam2world"], q["cam2world"][:, 0], ctx["intrinsics"], q["intrinsics"][:, 0])]
+    poses = torch.empty(b * V, 96, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.car_pose_setup(_ptr(t[0]), _ptr(t[1]), _ptr(t[2]), _ptr(t[3]), b, V, H, _ptr(poses), st)
+    assert rc == 0, lib.car_last_error()
+    torch.cuda.synchronize()
+    return poses.cpu()
+
+
+@pytest.mark.parametrize("name", HIP_CASES)
+def test_device_pose_records_match_the_host_algebra(name):
+    """Every one of the 96 floats of every camera of every fixture: the device's records (what a C host gets) against
+    poses.pack_poses (the reference's torch.inverse / matmul on this host) and against the matrices the reference itself
+    computed in the build container (stored in the fixture): a few ulp of the matrix scale."""
+    from cross_attention_renderer_amd.poses import pack_poses
+    from golden_util import load_case
+    c, inp, z, sd, fx = load_case(name)
+    got = _device_poses(inp, c["H"])
+    host = pack_poses(inp, c["H"])
+    ref = torch.as_tensor(fx["poses"]).float()
+    V = c["n_view"]
+    used = torch.ones(96, dtype=torch.bool)
+    used[89:] = False                                   # padding
+    used[24 + 12 * V:60] = False                        # T[s] of views that do not exist
+    for want, what in ((host, "host algebra"), (ref, "reference's matrices")):
+        err = (got - want).abs()[:, used]
+        scale = want.abs()[:, used].clamp_min(1.0)
+        assert (err / scale).max() < 2e-6, f"{name} vs {what}: {(err / scale).max().item()}"
+
+
+@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c3", "t2_c5"])
+def test_forward_on_device_made_poses(name):
+    """The whole forward on car_pose_setup's records: strict against the oracle fed the same records, and against the reference's
+    own outputs with the outlier budget of test_forward_host_poses_vs_reference (last-ulp pose differences move the few samples
+    whose pixel ray is nearly parallel to the query ray)."""
+    from golden_util import load_case
+    c, inp, z, sd, fx = load_case(name)
+    poses = _device_poses(inp, c["H"])
+    c, fx, ora, out = run_case(name, poses=poses)
+    _check_outputs(out, lambda k: ora[k], "device poses vs oracle")
+    for k in ("rgb", "depth_ray", "at_wt"):
+        e = err_stats(out[k], fx["out_" + k])
+        assert e["f1e-4"] <= OUTLIER_FRAC and e["max"] <= OUTLIER_MAX, f"device poses vs reference fixture {k}: {e}"
+    assert (np.asarray(out["valid_mask"]) == fx["out_valid_mask"]).all()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# config C3 at its size: 12 scenes per call
+# ----------------------------------------------------------------------------------------------------------
+def test_c3_twelve_scenes_at_full_size():
+    """BASELINE config 3 (batch_size 12 at 256x256, 64 samples): one forward over 12 scenes x 8192 rays — the per-GPU share when
+    the frame's rays are banded over 8 ranks — through the one-call route (12.6 M samples, 36 GB of workspace, level maps of
+    3.6 GB: just below the 4 GiB a call may address), 64 rays of every scene against the oracle."""
+    from cross_attention_renderer_amd import synthetic as S
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    dev = torch.device("cuda:0")
+    H, P, R, b = 256, 64, 8192, 12
+    torch.manual_seed(0)
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P).eval()
+    S.perturb_parameters(m, seed=0)
+    m.H = m.W = H
+    uv = S.pixel_grid(H, H)[64 * H:64 * H + R].contiguous()
+    inp = S.stereo_scene(H, b=b, uv=uv, seed=21, alpha=0.4)
+    z = S.feature_maps(b, 2, H, seed=8)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(dev)
+    with torch.no_grad():
+        out = m(to_device(inp, dev), z=[t.to(dev) for t in z])
+    torch.cuda.synchronize()
+    assert m._engine.last_calls == 1
+    assert torch.isfinite(out["rgb"]).all()
+    idx = torch.linspace(0, R - 1, 64).long()
+    sub = {"context": inp["context"], "query": dict(inp["query"], uv=inp["query"]["uv"][:, :, idx].contiguous())}
+    with torch.no_grad():
+        ora = O.render_forward(sd, sub, z, O.RenderConfig(n_view=2, npoints=P, H=H, W=H))
+    for k, got in (("rgb", out["rgb"][:, :, idx]), ("depth_ray", out["depth_ray"][:, idx]), ("at_wt", out["at_wt"][:, idx])):
+        e = err_stats(got.cpu(), ora[k])
+        assert e["max"] <= TOL, (k, e)
+    assert torch.equal(out["valid_mask"][:, idx].cpu(), ora["valid_mask"])
+    decided, wrong = argmax_exact_where_decided(out["at_wt_max"][:, idx].cpu(), ora["at_wt"])
+    assert wrong == 0
+    # 15 scenes would put the finest projected level at 4.5 GB: the engine renders them in two groups
+    eng = m._engine
+    assert min(eng.max_level_bytes // (4 * 2 * 256 * 256 * 576), 15) == 14

@@ -1,46 +1,93 @@
-"""Times the fused per-sample kernel (the engine's default csrc/car_fused4.hip; CAR_FUSED_VERSION=2 / 1: car_fused2.hip / car_fused.hip) alone (one 8192-ray chunk at 256x256x64) for each CAR_FUSED_ABLATE variant.  Timing only:
-variants > 0 compute wrong results by construction.  Usage (GPU box): python tools/bench_fused.py [variants...]"""
+"""Times the fused per-sample kernel (csrc/car_fused.hip) alone on one 8192-ray chunk of the bench frame (256x256x64), for the
+product kernel (variant 0) and the timing-only ablation variants of the development build (tools/build_dev.py; results of
+variants > 0 are wrong by construction):
+  1 no tap loads | 2 no gather work | 3 = 2 + no weight DMA / barriers | 5 the gather alone
+  texture-address probes on top of 5:  6 odd rows masked off | 7 odd channel quads masked off | 8 lanes in the MFMA's B-operand
+  order | 9 no level-0 taps | 10 level-2 taps only in the first two chunks
+Usage (GPU box): python tools/bench_fused.py [variants...]"""
+import ctypes
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 
 import bench  # noqa: E402
+from build_dev import build_dev  # noqa: E402
+from cross_attention_renderer_amd import _lib  # noqa: E402
 from cross_attention_renderer_amd.engine import RenderEngine  # noqa: E402
+
+P_ = ctypes.c_void_p
 
 
 def main():
-    import __graft_entry__ as ge
-    ge.build()
+    dev_lib = ctypes.CDLL(build_dev())
+    fn = dev_lib.car_fused_samples_ablate
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int] + _lib.SIGNATURES["car_fused_samples"][1]
+    lib = _lib.load()
     dev = torch.device("cuda:0")
     model = bench.build_model(dev)
-    model._engine = RenderEngine(model)
-    if "CAR_FUSED_VERSION" in os.environ:
-        model._engine.fused_version = int(os.environ["CAR_FUSED_VERSION"])     # 1: car_fused.hip, 2: car_fused2.hip, 4: car_fused4.hip
+    eng = model._engine = RenderEngine(model)
     inp, z = bench.make_frame(0.5, dev)
-    uv = inp["query"]["uv"][:, :, 96 * 256: 96 * 256 + 8192].contiguous()
+    R = 8192
+    uv = inp["query"]["uv"][:, :, 96 * 256: 96 * 256 + R].contiguous()
     if "CAR_BENCH_TILE" in os.environ:                 # experiment: rays in 2-D tiles of (rows x cols) pixels instead of row strips
         th, tw = [int(x) for x in os.environ["CAR_BENCH_TILE"].split("x")]
         g = uv.view(1, 1, 32, 256, 2)                  # 32 image rows x 256 columns
-        g = g.view(1, 1, 32 // th, th, 256 // tw, tw, 2).permute(0, 1, 2, 4, 3, 5, 6).reshape(1, 1, 8192, 2)
-        uv = g.contiguous()
+        uv = g.view(1, 1, 32 // th, th, 256 // tw, tw, 2).permute(0, 1, 2, 4, 3, 5, 6).reshape(1, 1, R, 2).contiguous()
     chunk = {"context": inp["context"], "query": dict(inp["query"], uv=uv)}
-    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 4]
     with torch.no_grad():
-        for v in variants:
-            os.environ["CAR_FUSED_ABLATE"] = str(v)
-            model(chunk, z=z)                           # warm-up (also packs weights / projects maps the first time)
-            model._engine.timing = {}
-            for _ in range(5):
-                model(chunk, z=z)
-            torch.cuda.synchronize()
-            evs = model._engine.timing["fused_samples"]
-            lat = sorted(a.elapsed_time(b) for a, b, *_ in evs)
-            flop = evs[0][2]
-            print(f"ABL={v}: fused kernel median {lat[len(lat)//2]:.3f} ms  min {lat[0]:.3f} ms  -> {flop / lat[len(lat)//2] / 1e9:.1f} TFLOP/s (nominal flops)")
-    os.environ["CAR_FUSED_ABLATE"] = "0"
+        model(chunk, z=z)                              # plan, projected maps, workspace (and the rays of this chunk inside it)
+    torch.cuda.synchronize()
+    d = eng._dims(1, R, z)
+    off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+
+    def ws(name):
+        _lib.check(lib.car_workspace_find(ctypes.byref(d), name.encode(), ctypes.byref(off), ctypes.byref(cnt)), name)
+        return eng._work.data_ptr() + 4 * off.value
+    # the fused layers, packed once more into buffers of our own (the plan's offsets are private)
+    keep = []
+
+    def dptr(t):
+        t = t.detach().float().reshape(t.shape[0], -1).contiguous() if t.dim() > 1 else t.detach().float().contiguous()
+        keep.append(t)
+        return t.data_ptr()
+    w = _lib.CarWeights()
+    sd = dict(model.named_parameters())
+    for n in _lib.WEIGHT_FIELDS[0]:
+        setattr(w, f"{n.replace('.', '_')}_w", dptr(sd[n + ".weight"]))
+        setattr(w, f"{n.replace('.', '_')}_b", dptr(sd[n + ".bias"]))
+    blob = torch.empty(lib.car_fused_blob_floats(), device=dev)
+    bias = torch.empty(lib.car_fused_bias_floats(), device=dev)
+    wpt = torch.empty(576 * 4, device=dev)
+    st = P_(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.car_fused_pack(ctypes.byref(w), blob.data_ptr(), bias.data_ptr(), wpt.data_ptr(), st), "car_fused_pack")
+    gm = (P_ * 3)(*[eng._pair.data_ptr() + 4 * lib.car_gmaps_level_offset(ctypes.byref(d), l) for l in range(3)])
+    hs = (ctypes.c_int * 3)(*[t.shape[2] for t in z])
+    wss = (ctypes.c_int * 3)(*[t.shape[3] for t in z])
+    gmeta = eng._pair.data_ptr() + 4 * lib.car_gmeta_offset(ctypes.byref(d))
+    steps = eng._linspace(0.0, 1.0, bench.P, dev)
+    pixel_val = torch.empty(2 * R * bench.P * 2, device=dev)
+    S = 2 * R * bench.P
+    flop = 2.0 * S * bench.FUSED_MACS
+    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 5, 6, 7, 8, 9, 10]
+    for v in variants:
+        lat = []
+        for it in range(7):
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn(v, eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), gm, hs, wss, 3, 576, gmeta, wpt.data_ptr(), blob.data_ptr(),
+                    bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
+                    pixel_val.data_ptr(), st)
+            b_.record()
+            assert rc == 0, dev_lib.car_last_error()
+            lat.append((a, b_))
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b_) for a, b_ in lat[2:])
+        print(f"ABL={v}: fused kernel median {ms[len(ms) // 2]:.3f} ms  min {ms[0]:.3f} ms  -> {flop / ms[len(ms) // 2] / 1e9:.1f} TFLOP/s (nominal flops)", flush=True)
 
 
 if __name__ == "__main__":

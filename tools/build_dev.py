@@ -1,0 +1,31 @@
+"""Development build of the HIP library with the timing-only ablation variants of the fused per-sample kernel compiled in
+(-DCAR_ABLATION: ``car_fused_samples_ablate``).  Never part of the product: ``__graft_entry__.build()`` does not know this file,
+the release library has no such symbol and reads no environment variable.  Output: tools/_dev/libcar_dev.so."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+DEV_DIR = os.path.join(ROOT, "tools", "_dev")
+DEV_LIB = os.path.join(DEV_DIR, "libcar_dev.so")
+
+
+def build_dev() -> str:
+    import __graft_entry__ as ge
+    ge.build()
+    os.makedirs(DEV_DIR, exist_ok=True)
+    obj = os.path.join(DEV_DIR, "car_fused_dev.o")
+    src = os.path.join(ge.CSRC, "car_fused.hip")
+    deps = [src] + [os.path.join(ge.CSRC, f) for f in os.listdir(ge.CSRC) if f.endswith(".h")]
+    if ge._stale(obj, deps):
+        subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCAR_ABLATION", "-c", src, "-o", obj,
+                               "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS["car_fused.hip"]])
+    objs = [os.path.join(ge.CSRC, "_obj", u.replace(".hip", ".o")) for u in ge.UNITS if u != "car_fused.hip"] + [obj]
+    if ge._stale(DEV_LIB, objs):
+        subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", DEV_LIB, *objs])
+    return DEV_LIB
+
+
+if __name__ == "__main__":
+    print(build_dev())
