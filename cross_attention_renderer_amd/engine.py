@@ -179,15 +179,27 @@ class RenderEngine:
                                               _stream()), "car_gather_encode")
 
     def _poses(self, inp, H: int, n: int, dev) -> Tensor:
-        """Device pose records for this input.  The host pose algebra needs the camera matrices on the CPU (one small D2H
-        sync); a frame is rendered as several chunks with the SAME cameras (render_realestate10k_traj.py:118-137), so the
-        records are cached on the identity/version of the four camera tensors and the sync happens once per frame."""
+        """Device pose records (``struct CarPose``) for this input (models.py:207-211, 285-286).  The 4x4 algebra runs where the
+        camera matrices live, as ``torch.inverse`` / ``matmul`` would in the reference:
+          * cameras on the GPU (the reference's scripts move the whole input dict there, render_realestate10k_traj.py:85):
+            ``car_pose_setup`` on the device — no host round trip, nothing to wait for between frames;
+          * cameras on the CPU: the reference's own calls on the host (poses.pack_poses) and one small upload, cached on the
+            identity/version of the four camera tensors (a frame rendered in chunks uploads once).
+        The two differ in the last ulp of the matrices (fp64 Gauss-Jordan vs LAPACK in fp32), which the fp64 Pluecker intersection
+        amplifies on the few samples whose pixel ray is nearly parallel to the query ray — as it does between two LAPACK builds."""
         if self.pose_records is not None:
             poses = self.pose_records.float().contiguous()
             if tuple(poses.shape) != (n, 96):
                 raise ValueError(f"pose records must have shape ({n}, 96)")
             return poses.to(dev, non_blocking=True)
         ts = (inp["context"]["cam2world"], inp["context"]["intrinsics"], inp["query"]["cam2world"], inp["query"]["intrinsics"])
+        if all(t.is_cuda for t in ts):
+            b, V = ts[0].shape[:2]
+            c2w, Kc, c2w_q, Kq = [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in ts]
+            poses = torch.empty(n, 96, device=dev, dtype=torch.float32)
+            _lib.check(self.lib.car_pose_setup(_ptr(c2w), _ptr(c2w_q), _ptr(Kc), _ptr(Kq), b, V, H, _ptr(poses), _stream()),
+                       "car_pose_setup")
+            return poses
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts) + (H, str(dev))
         if key != self._pose_key:
             self._pose_dev = pack_poses(inp, H).to(dev, non_blocking=True)

@@ -29,17 +29,24 @@ def build_module(c, sd, device):
     return m.to(device)
 
 
-def to_device(inp, device):
-    return {k: {kk: vv.to(device) for kk, vv in v.items()} for k, v in inp.items()}
+CAMERA_KEYS = ("cam2world", "intrinsics")
+
+
+def to_device(inp, device, cameras_on_host=False):
+    """Moves the input dict to the device; with cameras_on_host the 4x4 camera matrices stay CPU tensors, which makes the engine
+    run the reference's own torch.inverse / matmul on the host (engine._poses) instead of car_pose_setup on the device."""
+    return {k: {kk: (vv if (cameras_on_host and kk in CAMERA_KEYS) else vv.to(device)) for kk, vv in v.items()} for k, v in inp.items()}
 
 
 def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_poses=False, project_maps=True,
-             fuse_samples=True, fuse_round2=True, engine_setup=None, sd_edit=None, z_edit=None, poses=None):
+             fuse_samples=True, fuse_round2=True, engine_setup=None, sd_edit=None, z_edit=None, poses=None, cameras_on_host=True):
     """Returns (config, fixture, oracle output dict (CPU), HIP output dict (tensors moved to CPU)).
 
     fixture_poses=True: both sides use the relative-pose matrices stored in the fixture (the ones the reference
     computed in the build container) instead of running torch.inverse on this host; ``poses`` (b*V, 96): explicit records for
-    both sides.  sd_edit / z_edit: functions applied to the case's state_dict / feature pyramid before either side sees them;
+    both sides; otherwise cameras_on_host=True keeps the cameras on the CPU so that the engine computes them with the same
+    torch calls as the oracle (strict comparisons), False leaves them on the GPU (car_pose_setup: budgeted comparisons).
+    sd_edit / z_edit: functions applied to the case's state_dict / feature pyramid before either side sees them;
     engine_setup(engine): last-minute engine knobs."""
     from cross_attention_renderer_amd.engine import RenderEngine
     c, inp, z, sd, fx = load_case(name)
@@ -61,7 +68,7 @@ def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_pos
     if engine_setup is not None:
         engine_setup(m._engine)
     with torch.no_grad():
-        out = m(to_device(inp, device), z=[t.to(device) for t in z], debug=debug)
+        out = m(to_device(inp, device, cameras_on_host), z=[t.to(device) for t in z], debug=debug)
     torch.cuda.synchronize()
 
     def cpu(v):
