@@ -48,7 +48,7 @@ def build_model(device):
     from cross_attention_renderer_amd import synthetic as S
     from cross_attention_renderer_amd.models import CrossAttentionRenderer
     torch.manual_seed(0)
-    m = CrossAttentionRenderer(model="midas_vit", n_view=V, npoints=P).eval()
+    m = CrossAttentionRenderer(model="midas_vit", n_view=V, npoints=P, with_encoder=False).eval()
     S.perturb_parameters(m, seed=0, scale=0.02)
     m.H = m.W = H
     return m.to(device)

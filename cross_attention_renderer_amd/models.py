@@ -49,17 +49,16 @@ class ResnetFC(nn.Module):
 
 
 class EncoderNotBuilt(nn.Module):
-    """Placeholder for the multi-view DPT-hybrid image encoder (reference midas/, vit_models.py).
-
-    The encoder runs once per stereo pair outside the hot loop and is out of scope for this round
-    (SURVEY.md §8f row 2).  Assign any module with ``forward(rgb, rel_pose16, n_view) -> [path_2, path_1]``
-    to ``renderer.encoder`` to make ``get_z`` work; ``forward(input, z=z)`` never touches it.
+    """Placeholder used when the module is built with ``with_encoder=False`` (renderer-only use: tests, benchmarks and hosts that
+    feed precomputed feature maps through ``forward(input, z=z)``) or for the reference's other ``model=`` strings, whose encoders
+    (ResNet34 ``SpatialEncoder``, MiDaS-small, the broken ``UNetEncoder``; models.py:63-81, 97-99) are not built here.  Assign any
+    module with ``forward(rgb, rel_pose16, n_view) -> [path_2, path_1]`` to ``renderer.encoder`` to make ``get_z`` work.
     """
 
     def forward(self, *a, **k):
         raise NotImplementedError(
-            "image encoder not built: pass precomputed feature maps via forward(input, z=z) or assign "
-            "renderer.encoder = <module returning [path_2 (256@H/4), path_1 (256@H/2)]>")
+            "image encoder not built: construct CrossAttentionRenderer(model='midas_vit', with_encoder=True), pass precomputed "
+            "feature maps via forward(input, z=z), or assign renderer.encoder = <module returning [path_2 (256@H/4), path_1 (256@H/2)]>")
 
 
 def _feature_dim(model: str) -> int:
@@ -74,7 +73,7 @@ def _feature_dim(model: str) -> int:
 class CrossAttentionRenderer(nn.Module):
     def __init__(self, no_sample=False, no_latent_concat=False, no_multiview=False, no_high_freq=False,
                  model="midas_vit", uv=None, repeat_attention=True, n_view=1, npoints=64,
-                 num_hidden_units_phi=128, encoder: Optional[nn.Module] = None):
+                 num_hidden_units_phi=128, encoder: Optional[nn.Module] = None, with_encoder: bool = True):
         super().__init__()
         self.n_view = n_view
         self.npoints = 64 if n_view in (1, 2) else 48
@@ -88,7 +87,15 @@ class CrossAttentionRenderer(nn.Module):
         self.model = model
         self.num_hidden_units_phi = num_hidden_units_phi
 
-        self.encoder = encoder if encoder is not None else EncoderNotBuilt()
+        # reference: DPTDepthModel(backbone="vitb_rn50_384") with its stem convolution replaced (models.py:82-94).  ``encoder=`` and
+        # ``with_encoder=`` are additions of this repo: the 123 M-parameter encoder is only needed by get_z.
+        if encoder is not None:
+            self.encoder = encoder
+        elif with_encoder and model == "midas_vit":
+            from .encoder import MultiViewDPTEncoder
+            self.encoder = MultiViewDPTEncoder()
+        else:
+            self.encoder = EncoderNotBuilt()
         self.latent_dim = _feature_dim(model)
         self.feature_dim = self.latent_dim
         if model == "midas_vit":
@@ -171,5 +178,5 @@ class CrossAttentionRenderer(nn.Module):
 
 def renderer_param_shapes(model="midas_vit", n_view=2, no_latent_concat=False) -> Dict[str, tuple]:
     """name -> shape of every renderer parameter except the image encoder's."""
-    m = CrossAttentionRenderer(model=model, n_view=n_view, no_latent_concat=no_latent_concat)
+    m = CrossAttentionRenderer(model=model, n_view=n_view, no_latent_concat=no_latent_concat, with_encoder=False)
     return {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.startswith("encoder.")}

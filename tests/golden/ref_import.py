@@ -96,8 +96,9 @@ class _DummyEncoder(torch.nn.Module):
 _REF = None
 
 
-def load_reference():
-    """Returns the reference's ``models``, ``geometry``, ``epipolar`` modules (cached)."""
+def load_reference(real_encoder: bool = False):
+    """Returns the reference's ``models``, ``geometry``, ``epipolar`` modules (cached).  ``real_encoder``: keep the reference's own
+    DPTDepthModel (needs ``timm_stub.install()`` beforehand) instead of the inert holder used for the render-forward fixtures."""
     global _REF
     if _REF is not None:
         return _REF
@@ -112,7 +113,8 @@ def load_reference():
         models = importlib.import_module("models")
     finally:
         sys.path.remove(REFERENCE_ROOT)
-    models.dpt_depth.DPTDepthModel = _DummyEncoder
+    if not real_encoder:
+        models.dpt_depth.DPTDepthModel = _DummyEncoder
     models.UNetEncoder = _DummyEncoder
     _REF = types.SimpleNamespace(models=models, geometry=geometry, epipolar=epipolar)
     return _REF

@@ -22,7 +22,7 @@ def oracle_cfg(c) -> O.RenderConfig:
 def build_module(c, sd, device):
     from cross_attention_renderer_amd.models import CrossAttentionRenderer
     m = CrossAttentionRenderer(model=c["model"], n_view=c["n_view"], npoints=c["P"], no_sample=c["no_sample"],
-                               no_latent_concat=c["no_latent_concat"], repeat_attention=c["repeat_attention"]).eval()
+                               no_latent_concat=c["no_latent_concat"], repeat_attention=c["repeat_attention"], with_encoder=False).eval()
     missing = m.load_state_dict(sd, strict=False)
     assert not missing.unexpected_keys and not missing.missing_keys, missing
     m.H = m.W = c["H"]

@@ -14,7 +14,7 @@ from cross_attention_renderer_amd.models import CrossAttentionRenderer
 
 
 def _module(seed):
-    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=8).eval()
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=8, with_encoder=False).eval()
     S.perturb_parameters(m, seed=seed)
     return m
 

@@ -229,7 +229,7 @@ def test_full_size_properties():
     dev = torch.device("cuda:0")
     H, P, R = 256, 64, 8192
     torch.manual_seed(0)
-    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P).eval()
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).eval()
     S.perturb_parameters(m, seed=0)
     m.H = m.W = H
     m = m.to(dev)
@@ -274,7 +274,7 @@ def test_whole_frame_call_equals_chunked_calls():
     dev = torch.device("cuda:0")
     H, P = 256, 64
     torch.manual_seed(0)
-    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P).eval()
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).eval()
     S.perturb_parameters(m, seed=0)
     m.H = m.W = H
     m = m.to(dev)
@@ -325,7 +325,7 @@ def test_fused_path_ragged_sizes_against_the_oracle(R, P, b):
     dev = torch.device("cuda:0")
     H = 64
     torch.manual_seed(0)
-    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P).eval()
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).eval()
     S.perturb_parameters(m, seed=4)
     m.H = m.W = H
     uv = C.select_rays(H, R)
@@ -355,7 +355,7 @@ def test_one_call_c_abi_without_second_round():
     dev = torch.device("cuda:0")
     H, P, R = 64, 32, 200
     torch.manual_seed(0)
-    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, repeat_attention=False).eval()
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, repeat_attention=False, with_encoder=False).eval()
     S.perturb_parameters(m, seed=6)
     m.H = m.W = H
     inp = S.stereo_scene(H, b=1, uv=C.select_rays(H, R), seed=9, alpha=0.6)
@@ -425,7 +425,13 @@ def test_split_fp16_with_outliers_in_the_feature_maps():
         return z
     c, fx, ora, out = run_case("t1_c1", z_edit=z_edit)
     _, _, _, staged = run_case("t1_c1", z_edit=z_edit, fuse_samples=False)
-    assert err_stats(out["stages"]["interp_val"], ora["stages"]["interp_val"])["max"] <= TOL
+    # per-sample features: a sample next to an outlier sums terms of ~1e2-1e3 per channel, so single channels that cancel to O(1)
+    # cannot be reproduced to 1e-4 of THEMSELVES by any fp32 evaluation order; the error is measured against the sample's largest
+    # feature instead (ordinary samples: O(1-10), i.e. the usual bar)
+    want = ora["stages"]["interp_val"].double()
+    scale = want.abs().amax(dim=-1, keepdim=True).clamp_min(1.0)
+    for got, what in ((out["stages"]["interp_val"], "one-call"), (staged["stages"]["interp_val"], "staged")):
+        assert ((got.double() - want).abs() / scale).max() <= TOL, what
     # samples next to an outlier carry features of ~1e3-1e4, which the later layers difference away: the colours are
     # ill-conditioned in fp32 itself.  The split-fp16 route must not be worse than the route that runs every layer on the fp32
     # matrix pipe (both against the oracle's own fp32).
@@ -505,7 +511,7 @@ def test_c3_twelve_scenes_at_full_size():
     dev = torch.device("cuda:0")
     H, P, R, b = 256, 64, 8192, 12
     torch.manual_seed(0)
-    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P).eval()
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).eval()
     S.perturb_parameters(m, seed=0)
     m.H = m.W = H
     uv = S.pixel_grid(H, H)[64 * H:64 * H + R].contiguous()
