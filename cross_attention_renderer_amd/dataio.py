@@ -97,3 +97,103 @@ def get_camera_pose(scene_path, all_pose_dir, uv: torch.Tensor, views: int = 1) 
     query = pack(list(range(1, n_render)))
     query["uv"] = uv.view(-1, 2)[None, None].expand(1, n_render - 1, -1, -1)
     return {"query": query, "context": pack(ctx_ids)}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Evaluation items (reference RealEstate10kVis / ACIDVis, realestate10k_dataio.py:469-719, acid_dataio.py:504-): one scene ->
+# (model_input, query) with the first / last (/ middle) of the first 129 frames as context and one random in-between frame as query.
+# ----------------------------------------------------------------------------------------------------------------------
+def parse_pose(pose_rows: np.ndarray, timestep: int) -> Camera:
+    """The camera of frame ``timestep`` from the rows of a ``.mat`` pose table (one row per frame, same 19 numbers as a line of a
+    camera file; timestamps are matched after rounding, realestate10k_dataio.py:95-101)."""
+    mask = (np.around(pose_rows[:, :1]) == timestep)[:, 0]
+    return Camera(pose_rows[mask][0])
+
+
+def square_crop_img(img: np.ndarray) -> np.ndarray:
+    """Centre crop to the shorter side (utils/data_util.py:116-121; for an odd difference the crop is one pixel short, as there)."""
+    m = int(np.amin(img.shape[:2]))
+    c = np.array(img.shape[:2]) // 2
+    return img[c[0] - m // 2:c[0] + m // 2, c[1] - m // 2:c[1] + m // 2]
+
+
+class RealEstate10kVis:
+    """Evaluation dataset of the reference's eval scripts (eval_realestate10k.py:101-105, eval_acid.py): ``img_root`` holds one
+    directory per scene with a ``*.npz`` of frames, ``pose_root`` is a ``.mat`` file mapping scene name -> pose table.  Frames are
+    expected at the reference's working size 256 x 455 (its 360-line sources are resized with cv2 when the data is downloaded;
+    cv2 is not available here, so a scene that still needs that resize is rejected) and centre-cropped to 256 x 256."""
+
+    H, W = 256, 455
+
+    def __init__(self, img_root, pose_root, num_ctxt_views: int, num_query_views: int = 1, query_sparsity=None, max_num_scenes=None,
+                 square_crop: bool = True, augment: bool = False, lpips: bool = False):
+        from scipy.io import loadmat
+        if augment or query_sparsity is not None or lpips:
+            raise ValueError("RealEstate10kVis here is the evaluation reader: augment / query_sparsity / lpips are training-time options")
+        if num_ctxt_views not in (1, 2, 3):
+            raise ValueError("More than 3 context views not supported")
+        self.num_ctxt_views = num_ctxt_views
+        self.all_pose = loadmat(str(pose_root))
+        self.all_scenes = sorted(p for p in Path(img_root).glob("*/") if p.is_dir())
+        if max_num_scenes:
+            self.all_scenes = self.all_scenes[:max_num_scenes]
+        self.square_crop = square_crop
+        short = min(self.H, self.W)
+        self.xscale, self.yscale = self.W / short, self.H / short
+        if square_crop:
+            ys, xs = torch.meshgrid(torch.arange(0, short), torch.arange(0, short), indexing="ij")
+        else:
+            ys, xs = torch.meshgrid(torch.arange(0, self.H), torch.arange(0, self.W), indexing="ij")
+        self.uv = torch.stack([xs.float(), ys.float()], dim=-1).reshape(-1, 2)          # (x = column, y = row), row-major
+
+    def __len__(self) -> int:
+        return len(self.all_scenes)
+
+    def _frame(self, data, name, pose, stamp):
+        rgb = data[name]
+        if rgb.shape[0] == 360:
+            raise NotImplementedError("frame of 360 lines: resize the scene to 256 x 455 first (the reference uses cv2.resize, not available here)")
+        if self.square_crop:
+            rgb = square_crop_img(rgb)
+        cam = parse_pose(pose, stamp)
+        K = unnormalize_intrinsics(cam.intrinsics, self.H, self.W)
+        if self.square_crop:
+            K[0, 2] = K[0, 2] / self.xscale
+            K[1, 2] = K[1, 2] / self.yscale
+        return rgb.astype(np.float32) / 127.5 - 1, K, cam.c2w_mat
+
+    def __getitem__(self, idx):
+        import random
+        retry = lambda: self.__getitem__(random.randint(0, len(self.all_scenes) - 1))       # the reference's answer to a bad scene
+        scene = self.all_scenes[idx]
+        files = sorted(scene.glob("*.npz"))
+        if scene.name not in self.all_pose or not files:
+            return retry()
+        pose = self.all_pose[scene.name]
+        try:
+            data = np.load(files[0])
+        except Exception:
+            return retry()
+        names = list(data.keys())
+        if len(names) <= 10:
+            return retry()
+        stamps = np.array([int(n.split(".")[0]) for n in names])
+        order = np.argsort(stamps)
+        names, stamps = np.array(names)[order], stamps[order]
+        end = min(len(names) - 1, MAX_FRAMES)
+        id_feat = {1: [0], 2: [0, end], 3: [0, end // 2, end]}[self.num_ctxt_views]
+        candidates = [i for i in range(0, end) if np.abs(np.array(id_feat) - i).min() > 10]
+        if not candidates:
+            return retry()
+        q = random.choice(candidates)
+        rgb, K, c2w = self._frame(data, names[q], pose, stamps[q])
+        query = {"rgb": torch.from_numpy(rgb.reshape(-1, 3)[None]).float(), "cam2world": torch.from_numpy(c2w[None]).float(),
+                 "intrinsics": torch.from_numpy(K[None]).float(), "uv": self.uv[None].float(), "mask": 0.0}
+        ctx = [self._frame(data, names[i], pose, stamps[i]) for i in id_feat]
+        context = {"rgb": torch.from_numpy(np.stack([c[0] for c in ctx])).float(),
+                   "cam2world": torch.from_numpy(np.stack([c[2] for c in ctx])).float(),
+                   "intrinsics": torch.from_numpy(np.stack([c[1] for c in ctx])).float()}
+        return {"query": query, "context": context}, query
+
+
+ACIDVis = RealEstate10kVis          # acid_dataio.py:504- is the same reader over the ACID download (eval_acid.py)

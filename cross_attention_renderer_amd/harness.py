@@ -39,14 +39,16 @@ def render_frame(model, model_input, z, chunk_rays: int = CHUNK_RAYS, rank: int 
 
 
 def trajectory(inp, n_frames: int) -> List[Dict]:
-    """Query poses interpolated between the two context cameras (load_video_superglue.py:83-111): one input dict per frame."""
+    """One input dict per frame of a camera path between the first and the last context camera of every scene:
+    ``trajectory.linear_interpolate`` (the reference's load_video_superglue.linear_interpolate: rotation by slerp, position on the
+    segment), ``n_frames`` poses including both ends."""
+    from . import trajectory as T
     c2w = inp["context"]["cam2world"]
     b = c2w.shape[0]
+    paths = [T.linear_interpolate(c2w[s, [0, -1]].double().cpu().numpy(), max(n_frames, 2)) for s in range(b)]
     frames = []
     for i in range(n_frames):
-        alpha = i / max(n_frames - 1, 1)
-        q = torch.stack([synthetic.interpolate_pose(c2w[s, 0].double().cpu(), c2w[s, -1].double().cpu(), alpha).float()
-                         for s in range(b)])[:, None]
+        q = torch.stack([torch.from_numpy(paths[s][i]).float() for s in range(b)])[:, None]
         frames.append({"context": inp["context"], "query": dict(inp["query"], cam2world=q.to(c2w.device))})
     return frames
 

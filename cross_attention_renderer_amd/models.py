@@ -151,7 +151,7 @@ class CrossAttentionRenderer(nn.Module):
             mean = rgb.new_tensor([0.485, 0.456, 0.406])[None, :, None, None]
             std = rgb.new_tensor([0.229, 0.224, 0.225])[None, :, None, None]
             rgb = (rgb - mean) / std
-        pose16 = rel_cam2world.reshape(-1, 16)
+        pose16 = rel_cam2world.reshape(-1, 16).to(rgb.device)       # the cameras may live on the host (engine._poses)
         if self.no_multiview:
             pose16 = torch.zeros_like(pose16)
         z = list(self.encoder.forward(rgb, pose16, self.n_view))

@@ -37,25 +37,40 @@ def parser(description: str) -> argparse.ArgumentParser:
     p.add_argument("--no_high_freq", action="store_true", default=False)
     p.add_argument("--reconstruct", action="store_true", default=False)
     p.add_argument("--synthetic", action="store_true", default=False)
+    p.add_argument("--with_encoder", action="store_true", default=False,
+                   help="build the DPT encoder and run get_z on the context images even without a checkpoint (random weights)")
     p.add_argument("--n_frames", type=int, default=8, help="frames of the rendered trajectory")
     p.add_argument("--out_dir", type=str, default=None)
     p.add_argument("--port", type=int, default=1492)          # the reference rendezvous port (eval_realestate10k.py:97)
     return p
 
 
-def build_model(opt, device):
+def build_model(opt, device, with_encoder=None):
+    """The renderer; with a checkpoint (or --with_encoder) the multi-view DPT encoder is built too, so that ``get_z`` runs on the
+    context images.  Loading follows the reference (strict unless --reconstruct, eval_realestate10k.py:110-118) and FAILS on keys that
+    do not match instead of silently leaving layers at their initial values."""
     import torch
     from cross_attention_renderer_amd import synthetic
     from cross_attention_renderer_amd.models import CrossAttentionRenderer
     torch.manual_seed(0)
+    if with_encoder is None:
+        with_encoder = bool(opt.checkpoint_path) or getattr(opt, "with_encoder", False)
     model = CrossAttentionRenderer(no_sample=opt.no_sample, no_latent_concat=opt.no_latent_concat,
                                    no_multiview=opt.no_multiview, no_high_freq=opt.no_high_freq, model=opt.model,
-                                   n_view=opt.views).eval()
+                                   n_view=opt.views, with_encoder=with_encoder).eval()
     if opt.checkpoint_path:
         state = torch.load(opt.checkpoint_path, map_location="cpu")["model"]
-        model.load_state_dict(state, strict=False)      # encoder.* keys are not built yet
+        res = model.load_state_dict(state, strict=False)
+        bad = [k for k in res.missing_keys if not opt.reconstruct] + list(res.unexpected_keys)
+        if bad:
+            raise SystemExit(f"checkpoint {opt.checkpoint_path} does not match the model: {len(res.missing_keys)} missing, "
+                             f"{len(res.unexpected_keys)} unexpected keys, e.g. {bad[:6]}")
     else:
-        synthetic.perturb_parameters(model, seed=0)      # un-trained weights: fc_1 is zero-initialised otherwise
+        with torch.no_grad():                            # un-trained weights: fc_1 is zero-initialised otherwise (resnet_block_fc.py:39)
+            g = torch.Generator().manual_seed(0)
+            for n_, p_ in model.named_parameters():
+                if not n_.startswith("encoder."):
+                    p_.add_(0.02 * torch.randn(p_.shape, generator=g))
     model.H = model.W = opt.img_sidelength
     return model.to(device)
 

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import common  # noqa: E402
 
 
-def _scene_inputs(opt, H, dev):
+def _scene_inputs(opt, H, dev, model):
     """(name, model_input with every query frame, z) per scene: real cameras from --data_root / --pose_root
     (cross_attention_renderer_amd/dataio.py) or one seeded synthetic pair."""
     import torch
@@ -38,9 +38,14 @@ def _scene_inputs(opt, H, dev):
                    "query": {"cam2world": full["query"]["cam2world"][:, i:i + 1], "intrinsics": full["query"]["intrinsics"][:, i:i + 1],
                              "uv": full["query"]["uv"][:, i:i + 1].contiguous(), "rgb": full["query"]["rgb"][:, i:i + 1]}}
                   for i in range(nq)]
-        # The DPT encoder (get_z) is not part of this path: without a user-supplied model.encoder the feature
-        # pyramid is the seeded synthetic one, i.e. geometry and timing are real, colours are not.
-        z = [t.to(dev) for t in synthetic.feature_maps(1, opt.views, H, seed=1)]
+        # get_z on the context images when the encoder is built (checkpoint or --with_encoder) and the frames have the 256 x 256 the
+        # multi-view encoder needs; otherwise the seeded synthetic pyramid (geometry and timing real, colours not)
+        from cross_attention_renderer_amd.models import EncoderNotBuilt
+        if not isinstance(model.encoder, EncoderNotBuilt) and tuple(full["context"]["rgb"].shape[2:4]) == (256, 256) and H == 256:
+            with torch.no_grad():
+                z = model.get_z(full)
+        else:
+            z = [t.to(dev) for t in synthetic.feature_maps(1, opt.views, H, seed=1)]
         yield scene, frames, z
 
 
@@ -52,7 +57,7 @@ def render(rank, opt):
     H = opt.img_sidelength
     out_root = opt.out_dir or os.path.join(opt.logging_root, opt.experiment_name, "renders")
     t0, n_done = time.time(), 0
-    for scene, frames, z in _scene_inputs(opt, H, dev):
+    for scene, frames, z in _scene_inputs(opt, H, dev, model):
         out_dir = out_root if scene == "synthetic" else os.path.join(out_root, scene)
         if rank == 0:
             os.makedirs(out_dir, exist_ok=True)

@@ -55,6 +55,53 @@ def main():
                 out[f"v{views}.{part}.{k}"] = v.numpy()
     np.savez(os.path.join(HERE, "dataio_expected.npz"), uv=uv.numpy(), **out)
     print("wrote", len(out), "arrays")
+    make_vis(ref)
+
+
+VIS_ROOT = os.path.join(HERE, "dataio_scene_vis")
+
+
+def write_vis_scene(n_frames=50):
+    """A scene in the evaluation layout: frames at the reference's working size 256 x 455 (a smooth pattern, so the npz stays small)
+    and a .mat pose table keyed by scene name."""
+    from scipy.io import savemat
+    ys, xs = np.meshgrid(np.arange(256), np.arange(455), indexing="ij")
+    frames, rows = {}, []
+    for k in range(n_frames):
+        t = 200200 + 33367 * k
+        frames[f"{t}.png"] = np.stack([(xs // 16 * 3 + ys // 16 + 7 * k) % 256, (xs // 8 + ys // 32 * 2 + 11 * k) % 256, ((xs // 16) * (ys // 16) + 5 * k) % 256], axis=-1).astype(np.uint8)
+        a = 0.03 * k
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        tv = np.array([0.05 * k, 0.01 * k, -0.02 * k])
+        rows.append([t + 0.3, 0.49 + 0.001 * k, 0.87, 0.5, 0.5 + 0.001 * k, 0.0, 0.0] + list(np.concatenate([R, tv[:, None]], axis=1).reshape(-1)))
+    os.makedirs(os.path.join(VIS_ROOT, "scenes", "sceneA"), exist_ok=True)
+    np.savez_compressed(os.path.join(VIS_ROOT, "scenes", "sceneA", "data.npz"), **frames)
+    savemat(os.path.join(VIS_ROOT, "poses.mat"), {"sceneA": np.asarray(rows, dtype=np.float64)})
+
+
+def make_vis(ref):
+    """What the reference's RealEstate10kVis returns for that scene (eval_realestate10k.py:101-105: augment=False), for 1 / 2 / 3
+    context views and two seeds of the query draw."""
+    import random
+    write_vis_scene()
+    out = {}
+    for views in (1, 2, 3):
+        ds = ref.RealEstate10kVis(img_root=os.path.join(VIS_ROOT, "scenes"), pose_root=os.path.join(VIS_ROOT, "poses.mat"),
+                                  num_ctxt_views=views, num_query_views=1, augment=False)
+        for seed in (0, 1):
+            random.seed(seed)
+            item, gt = ds[0]
+            for part in ("query", "context"):
+                for k, v in item[part].items():
+                    v = np.asarray(v)
+                    if k == "rgb":                       # bulky: a strided probe and a checksum
+                        out[f"v{views}.s{seed}.{part}.rgb_sum"] = np.asarray([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum()])
+                        v = v.reshape(-1, 3)[::997]
+                    if k == "uv":
+                        v = v.reshape(-1, 2)[::257]
+                    out[f"v{views}.s{seed}.{part}.{k}"] = v
+    np.savez(os.path.join(HERE, "dataio_vis_expected.npz"), **out)
+    print("wrote", len(out), "arrays (vis)")
 
 
 if __name__ == "__main__":

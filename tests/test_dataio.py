@@ -34,3 +34,45 @@ def test_pose_file_parsing():
     assert np.isclose(K[0, 0], c.intrinsics[0, 0] * 456) and np.isclose(K[1, 2], c.intrinsics[1, 2] * 256)
     with pytest.raises(ValueError):
         dataio.get_camera_pose(SCENE, POSES, torch.zeros(2, 2), views=4)
+
+
+# ---- evaluation items: RealEstate10kVis / ACIDVis (realestate10k_dataio.py:469-719) --------------------------------------------
+VIS = os.path.join(HERE, "golden", "dataio_scene_vis")
+
+
+@pytest.mark.parametrize("views", [1, 2, 3])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_eval_item_matches_reference(views, seed):
+    """One item of the evaluation reader against what the reference's RealEstate10kVis returns for the committed scene (50 frames at
+    256 x 455, .mat pose table; tests/golden/make_dataio_golden.py): context = first / middle / last frame, the query drawn with
+    random.choice from the frames more than 10 away from every context frame, centre crop, intrinsics, cameras, pixel grid."""
+    import random
+    want = np.load(os.path.join(HERE, "golden", "dataio_vis_expected.npz"))
+    ds = dataio.RealEstate10kVis(os.path.join(VIS, "scenes"), os.path.join(VIS, "poses.mat"), num_ctxt_views=views, num_query_views=1, augment=False)
+    assert len(ds) == 1
+    random.seed(seed)
+    item, gt = ds[0]
+    assert gt is item["query"] and item["query"]["mask"] == 0.0
+    for part in ("query", "context"):
+        for k, v in item[part].items():
+            if k == "mask":
+                continue
+            v = v.numpy()
+            ref = want[f"v{views}.s{seed}.{part}.{k}"]
+            if k == "rgb":
+                s2 = np.asarray([v.astype(np.float64).sum(), np.abs(v.astype(np.float64)).sum()])
+                assert np.array_equal(s2, want[f"v{views}.s{seed}.{part}.rgb_sum"]), (part, k)
+                v = v.reshape(-1, 3)[::997]
+            if k == "uv":
+                v = v.reshape(-1, 2)[::257]
+            assert v.shape == ref.shape and v.dtype == ref.dtype, (part, k, v.shape, ref.shape)
+            assert np.array_equal(v, ref), (part, k, np.abs(v - ref).max())
+    assert tuple(item["context"]["rgb"].shape) == (views, 256, 256, 3) and tuple(item["query"]["rgb"].shape) == (1, 65536, 3)
+
+
+def test_eval_reader_rejects_training_options_and_unresized_frames():
+    with pytest.raises(ValueError, match="training-time"):
+        dataio.RealEstate10kVis(os.path.join(VIS, "scenes"), os.path.join(VIS, "poses.mat"), num_ctxt_views=2, augment=True)
+    img = np.zeros((256, 455, 3), np.uint8)
+    assert dataio.square_crop_img(img).shape == (256, 256, 3)
+    assert dataio.ACIDVis is dataio.RealEstate10kVis

@@ -59,9 +59,9 @@ def test_entry_points_run_on_gpu(script, extra, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     if script.startswith("render"):
         assert (tmp_path / "frame_0001.png").exists()
-        assert "rays/s" in out.stdout
+        assert "rays/s" in out.stdout or "rendered 2 frames" in out.stdout
     else:
-        psnr = float(out.stdout.split("psnr vs unchunked render")[1].split("dB")[0])
+        psnr = float(out.stdout.split("psnr vs un-chunked render")[1].split("dB")[0])
         assert psnr > 100.0, out.stdout          # chunking must not change the image
 
 
@@ -78,3 +78,18 @@ def test_render_script_reads_a_scene_directory(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / "out" / "scene0" / "frame_0001.png").exists() and "rendered 2 frames" in out.stdout
+
+
+@pytest.mark.gpu
+def test_eval_script_reads_the_dataset_and_runs_get_z(tmp_path):
+    """eval_realestate10k.py on the committed evaluation scene (tests/golden/dataio_scene_vis: frames at 256 x 455 + .mat poses): the
+    item comes from dataio.RealEstate10kVis, get_z runs the multi-view DPT encoder on the two context frames (random weights: no
+    checkpoint offline), the 65 536 query rays are rendered in 9 chunks and a PSNR against the ground-truth frame is reported."""
+    vis = os.path.join(ROOT, "tests", "golden", "dataio_scene_vis")
+    cmd = [sys.executable, os.path.join(ROOT, "experiment_scripts", "eval_realestate10k.py"), "--experiment_name", "t", "--views", "2",
+           "--data_root", os.path.join(vis, "scenes"), "--pose_root", os.path.join(vis, "poses.mat"), "--logging_root", str(tmp_path)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "item 0:" in out.stdout and "mean psnr" in out.stdout
+    psnr = float(out.stdout.split("mean psnr")[1].split()[0])
+    assert 0.0 < psnr < 60.0                      # an untrained model: a finite, unremarkable number

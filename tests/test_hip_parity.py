@@ -537,3 +537,35 @@ def test_c3_twelve_scenes_at_full_size():
     # 15 scenes would put the finest projected level at 4.5 GB: the engine renders them in two groups
     eng = m._engine
     assert min(eng.max_level_bytes // (4 * 2 * 256 * 256 * 576), 15) == 14
+
+
+def test_forward_without_z_runs_get_z_on_the_device():
+    """``model(input)`` with z=None (the reference's training / validation call, training.py:92): get_z — ImageNet normalisation, the
+    multi-view DPT-hybrid encoder, conv_map — runs on the GPU in stock PyTorch-ROCm ops, its pyramid goes straight into the HIP
+    render.  The pyramid is compared with the same module's CPU get_z (summation-order noise only), the render with the oracle fed
+    that very pyramid (1e-4)."""
+    import encoder_cases as EC
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    dev = torch.device("cuda:0")
+    P, R = 32, 96
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P).eval()
+    sd = EC.seeded_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=11)
+    m.load_state_dict(sd, strict=True)
+    inp = EC.context_pair()
+    inp["query"]["uv"] = C.select_rays(EC.H, R)[None, None].contiguous()
+    with torch.no_grad():
+        z_cpu = m.get_z(inp)
+        md = m.to(dev)
+        out = md(to_device(inp, dev, cameras_on_host=True))
+    torch.cuda.synchronize()
+    z_gpu = [t.cpu() for t in out["z"]]
+    for a, b_ in zip(z_gpu, z_cpu):
+        assert a.shape == b_.shape
+        assert (a - b_).abs().max() <= 2e-3 * b_.pow(2).mean().sqrt() + 1e-5
+    with torch.no_grad():
+        ora = O.render_forward({k: v for k, v in sd.items() if not k.startswith("encoder.")}, inp, z_gpu,
+                               O.RenderConfig(n_view=2, npoints=P, H=EC.H, W=EC.H))
+    for k in ("rgb", "depth_ray", "at_wt"):
+        e = err_stats(out[k].cpu(), ora[k])
+        assert e["max"] <= TOL, (k, e)
+    assert torch.equal(out["valid_mask"].cpu(), ora["valid_mask"])
