@@ -55,6 +55,8 @@ struct FusedArgs {
     float* logit;
     float* pt;
     float* pixel_val;
+    const int* redo;           // NULL, or the sample groups car_fused_tex.hip handed back: [0] count, [1 + k] index of a group of
+                               // 32 rays x 4 steps (that kernel's group: two bundles), rendered here with the third bundle idle
 };
 
 // chunk order:  W2 x18 (source 0) | W2 x18 (source 1) | K1 over e_1 x5 (2,2,2,2,1 K steps) | K1 over e_0 x5 | K2 x2 | Q1 | Q2 x2
@@ -87,17 +89,23 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     const int s = lane & 15, q4 = lane >> 4;
     const int nblk = gridDim.x;
     int blk = blockIdx.x;
-    {   // workgroup b runs on XCD b % 8 (observed, speed only): give every XCD a contiguous band of sample groups so that the
+    const bool redo = a.redo != nullptr;
+    if (redo) {
+        if (blk >= a.redo[0]) return;
+        blk = a.redo[1 + blk];
+    } else {
+        // workgroup b runs on XCD b % 8 (observed, speed only): give every XCD a contiguous band of sample groups so that the
         // texel rows its workgroups share stay in one L2
         const int q8 = nblk / 8, r8 = nblk % 8, xcd = blk % 8, idx = blk / 8;
         blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
+    const int group_rays = redo ? 2 * kRows : kBundles * kRows;       // rays per sample group
     // 192 samples = 48 consecutive rays x 4 consecutive steps: wave = (bundle of 16 rays, step), lane & 15 = ray of the bundle, so the
     // 16 rows a wave gathers together are the same step of neighbouring rays (shared texel rows)
-    const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + kBundles * kRows - 1) / (kBundles * kRows);
+    const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + group_rays - 1) / group_rays;
     const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
-    const int ray_i = bun * (kBundles * kRows) + (wave / kStepsPerGroup) * kRows + s, pp = pg * kStepsPerGroup + wave % kStepsPerGroup;
-    const bool live = ray_i < a.R && pp < a.P;
+    const int ray_i = bun * group_rays + (wave / kStepsPerGroup) * kRows + s, pp = pg * kStepsPerGroup + wave % kStepsPerGroup;
+    const bool live = ray_i < a.R && pp < a.P && (wave / kStepsPerGroup) * kRows < group_rays;
     const long i = ((long)nn * a.R + (ray_i < a.R ? ray_i : a.R - 1)) * a.P + (pp < a.P ? pp : a.P - 1);
 
     for (int k = tid; k < kC; k += 768) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
@@ -110,8 +118,8 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     const int P = a.P, V = a.V;
     if (wave < kGroup / 64) {
         const int sg = wave * 64 + lane, gwv = sg >> 4, gs = sg & 15;     // sample sg belongs to row gs of matrix wave gwv
-        const int g_ray = bun * (kBundles * kRows) + (gwv / kStepsPerGroup) * kRows + gs, g_pp = pg * kStepsPerGroup + gwv % kStepsPerGroup;
-        const bool g_live = g_ray < a.R && g_pp < a.P;
+        const int g_ray = bun * group_rays + (gwv / kStepsPerGroup) * kRows + gs, g_pp = pg * kStepsPerGroup + gwv % kStepsPerGroup;
+        const bool g_live = g_ray < a.R && g_pp < a.P && (gwv / kStepsPerGroup) * kRows < group_rays;
         const long gi = ((long)nn * a.R + (g_ray < a.R ? g_ray : a.R - 1)) * a.P + (g_pp < a.P ? g_pp : a.P - 1);
         const int p = (int)(gi % P);
         const long nr = gi / P;
@@ -360,7 +368,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
 
 int launch_fused(int abl, const float* poses, const float* rays, const float* steps, const float* const* gmaps, const int* level_h,
                  const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,
-                 int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+                 int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, const int* redo, void* stream) {
     CAR_REQUIRE(poses && rays && steps && gmaps && level_h && level_w && gmeta && wpt && blob && bias, "car_fused_samples: null input");
     CAR_REQUIRE(e && qry && g && logit && pt && pixel_val, "car_fused_samples: null output");
     CAR_REQUIRE(n_levels == 3 && C == kC && V == 2, "car_fused_samples: built for 3 pyramid levels, C = %d, V = 2 (got %d, %d, %d)", kC, n_levels, C, V);
@@ -376,8 +384,9 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     a.gmeta = gmeta; a.wpt = wpt; a.blob = blob; a.bias = bias;
     a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
     a.S = (long)b * V * R * P;
-    a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
-    const long groups = (long)b * V * car_div_up(R, kBundles * kRows) * car_div_up(P, kStepsPerGroup);
+    a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val; a.redo = redo;
+    // redo mode: one workgroup per group the texel-cache kernel could have handed back (most exit at once: the list is short)
+    const long groups = (long)b * V * car_div_up(R, redo ? 2 * kRows : kBundles * kRows) * car_div_up(P, kStepsPerGroup);
     void (*kern)(const FusedArgs) = fused_kernel<0>;
 #ifdef CAR_ABLATION
     switch (abl) {
@@ -402,12 +411,37 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
 extern "C" size_t car_fused_blob_floats(void) { return (size_t)kBlobTiles * kTile; }
 extern "C" size_t car_fused_bias_floats(void) { return (size_t)kBiasFloats; }
 
+extern "C" int car_fused_samples_tex(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                                     const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
+                                     const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                                     float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* redo, void* stream);
+
+extern "C" size_t car_fused_scratch_ints(int b, int V, int R, int P) {
+    return (size_t)b * V * car_div_up(R, 2 * kRows) * car_div_up(P, kStepsPerGroup) + 1;
+}
+
+// The stage as the product runs it: the texel-cache kernel (car_fused_tex.hip) over every sample group, then this file's kernel over
+// the groups it handed back (`scratch`: car_fused_scratch_ints() ints, the hand-back list).
 extern "C" int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
                                  const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
                                  const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                                 float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+                                 float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* scratch, void* stream) {
+    CAR_REQUIRE(scratch, "car_fused_samples: null scratch");
+    if (hipMemsetAsync(scratch, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) { car_set_error("car_fused_samples: memset failed"); return CAR_E_LAUNCH; }
+    int rc = car_fused_samples_tex(poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
+                                   logit, pt, pixel_val, scratch, stream);
+    if (rc != CAR_OK) return rc;
     return launch_fused(0, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
-                        logit, pt, pixel_val, stream);
+                        logit, pt, pixel_val, scratch, stream);
+}
+
+// This file's kernel alone (every tap through the texture-address path): the A/B partner of the texel-cache kernel.
+extern "C" int car_fused_samples_direct(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                                        const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
+                                        const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                                        float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+    return launch_fused(0, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
+                        logit, pt, pixel_val, nullptr, stream);
 }
 
 #ifdef CAR_ABLATION
@@ -417,6 +451,6 @@ extern "C" int car_fused_samples_ablate(int abl, const float* poses, const float
                                         const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
                                         float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
     return launch_fused(abl, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
-                        logit, pt, pixel_val, stream);
+                        logit, pt, pixel_val, nullptr, stream);
 }
 #endif

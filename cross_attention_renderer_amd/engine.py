@@ -83,6 +83,9 @@ class RenderEngine:
         # stage-by-stage pipeline of this module (A/B and stage tests)
         self.fuse_samples = True
         self.fuse_round2 = True        # staged route: round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
+        # one-call route: the fused stage's direct kernel (every tap from global memory, csrc/car_fused.hip) instead of the LDS
+        # texel-cache kernel with hand-back (csrc/car_fused_tex.hip); bit-identical results (A/B)
+        self.fused_direct = False
         # sizing of the one-call route (tests shrink them to force several calls)
         self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
         self.max_level_bytes = (1 << 32) - 1               # a projected level of one call: the fused kernel's 32-bit texel offsets
@@ -236,6 +239,7 @@ class RenderEngine:
         for l, t in enumerate(z):
             d.level_c[l], d.level_h[l], d.level_w[l] = t.shape[1], t.shape[2], t.shape[3]
         d.repeat_attention = int(m.repeat_attention)
+        d.fused_direct = int(self.fused_direct)
         return d
 
     def _plan_for(self, d, device) -> Tensor:
@@ -385,7 +389,10 @@ class RenderEngine:
             res["stages"] = {"rays": ws("rays", n, R, 12), "pt": ws("pt", n, R, P, 3), "local_coords": None,
                              "g": ws("g", n, R, P, 16), "interp_val": ws("e", n, R, P, 576),
                              "z_final": ws("zrep", b * R, 576)[:, :288].reshape(b, R, 288),
-                             "at_wt2": ws("at_wt2", n, R, P) if m.repeat_attention else None, "poses": poses}
+                             "at_wt2": ws("at_wt2", n, R, P) if m.repeat_attention else None, "poses": poses,
+                             "qry": ws("qry", n, R, P, 128), "logit": ws("logit", n, R, P),
+                             # sample groups (32 rays x 4 steps) the texel-cache kernel handed back to the direct kernel
+                             "handed_back": None if self.fused_direct else int(ws("redo", -1).view(torch.int32)[0])}
         return res
 
     # ------------------------------------------------------------------ stage timing (csrc/car_render.hip)

@@ -41,6 +41,9 @@ def main():
     chunk = {"context": inp["context"], "query": dict(inp["query"], uv=uv)}
     with torch.no_grad():
         model(chunk, z=z)                              # plan, projected maps, workspace (and the rays of this chunk inside it)
+    if eng._pose_dev is None:                          # cameras on the GPU: the engine made the records with car_pose_setup
+        from cross_attention_renderer_amd.poses import pack_poses
+        eng._pose_dev = pack_poses({k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in chunk.items()}, bench.H).to(dev)
     torch.cuda.synchronize()
     d = eng._dims(1, R, z)
     off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
@@ -73,7 +76,25 @@ def main():
     pixel_val = torch.empty(2 * R * bench.P * 2, device=dev)
     S = 2 * R * bench.P
     flop = 2.0 * S * bench.FUSED_MACS
-    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 5, 6, 7, 8, 9, 10]
+    # the product: texel-cache kernel (csrc/car_fused_tex.hip) + the direct kernel over what it hands back
+    scratch = torch.zeros(lib.car_fused_scratch_ints(1, 2, R, bench.P), dtype=torch.int32, device=dev)
+    for name, fn2 in (("texel cache + hand-back (product)", lib.car_fused_samples), ("texel cache alone", lib.car_fused_samples_tex)):
+        lat = []
+        for it in range(7):
+            scratch[:1].zero_()
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn2(eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), gm, hs, wss, 3, 576, gmeta, wpt.data_ptr(), blob.data_ptr(),
+                     bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
+                     pixel_val.data_ptr(), scratch.data_ptr(), st)
+            b_.record()
+            _lib.check(rc, name)
+            lat.append((a, b_))
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b_) for a, b_ in lat[2:])
+        print(f"{name}: median {ms[len(ms) // 2]:.3f} ms  min {ms[0]:.3f} ms  -> {flop / ms[len(ms) // 2] / 1e9:.1f} TFLOP/s; "
+              f"{int(scratch[0])} of {scratch.numel() - 1} groups handed back", flush=True)
+    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 5]
     for v in variants:
         lat = []
         for it in range(7):
