@@ -63,6 +63,8 @@ SIGNATURES = {
                                   _P, _P, _P, _P, _P, _P, _P, _P]),
     "car_fused_samples_direct": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                          _P, _P, _P, _P, _P, _P, _P]),
+    "car_fused_samples_texfirst": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                           _P, _P, _P, _P, _P, _P, _P, _P]),
     "car_fused_samples_tex": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                       _P, _P, _P, _P, _P, _P, _P, _P]),
     "car_linear_packed_floats": (c_size_t, [c_int, c_int]),

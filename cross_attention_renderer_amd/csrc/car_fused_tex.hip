@@ -149,6 +149,10 @@ __device__ __forceinline__ void chained_layer1(f32x4 (&acc)[kTD], const f32x4 (&
     }
 }
 
+// ABL > 0: variants of the development build.  Timing only (wrong results): 1 no tap reads / blends, 2 no cache DMA, 3 = 1 + 2,
+// 4 no MFMAs in the e passes, 5 no barriers / weight DMA in the e passes (with 3).  6: the full kernel without the scheduling
+// barriers between the slots of the e passes (correct results)
+template <int ABL>
 __global__ void __launch_bounds__(kThreads) fused_tex_kernel(const TexArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave index in an SGPR
@@ -274,6 +278,7 @@ __global__ void __launch_bounds__(kThreads) fused_tex_kernel(const TexArgs a) {
     auto cache_issue = [&](int sv, int c, int buf, int k) {
         const int ins = sub + 4 * k;
         const int used = used_sv[sv];
+        if constexpr (ABL == 2 || ABL == 3 || ABL == 5) return;
         if (ins >= kDmaPerBundle || 8 * ins >= used) return;           // wave-uniform
         const int sl = 8 * ins + (lane >> 3);
         const int slc = sl < used ? sl : used - 1;                     // unused tail of the last instruction: a harmless duplicate
@@ -282,10 +287,35 @@ __global__ void __launch_bounds__(kThreads) fused_tex_kernel(const TexArgs a) {
         dma_1k(src, lds_addr(lds + kLdsCache + buf * kCacheBuf + (bundle * kPool + 8 * ins) * kSlice));
     };
 
-    // ---- gather: lane (s, q4) blends channels 8 q4 .. 8 q4 + 7 of chunk c for its sample, tap by tap -----------------------------
+    // ---- gather: lane (s, q4) blends channels 8 q4 .. 8 q4 + 7 of chunk c for its sample, tap by tap.  Where a tap lives and what it
+    //      weighs does not depend on the chunk: the 12 LDS offsets (or, for a finest level that is gathered direct, global offsets)
+    //      and weights of the sample are decoded once per source pass into registers. ------------------------------------------------
     float hacc[8];
     f32x4 tap[2];
     const int srow = wave * kRows + s;
+    unsigned toff[12];         // tap k = 0..11: level 2 - k / 4 (finest first, as car_fused.hip adds them), corner k % 4 (nw, ne, sw, se)
+    float tw[12];
+    auto load_taps = [&](int sv) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const unsigned info = reinterpret_cast<const unsigned*>(lds + kLdsTapI)[(srow * 2 + sv) * 3 + l];
+            const float4 w4 = *reinterpret_cast<const float4*>(lds + kLdsTapW + (srow * 2 + sv) * 12 + 4 * l);
+            const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+            const bool cached = l < 2 || l2c_sv[sv];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = 4 * (2 - l) + t;
+                tw[k] = ww[t];
+                if (cached) {                                          // byte offset inside a cache buffer: slice of the bundle pool, swizzled piece
+                    const unsigned slot = (info & 1023u) + ((t & 1) ? (info >> 10 & 1u) : 0u) + ((t & 2) ? (info >> 11) : 0u);
+                    toff[k] = ((unsigned)(bundle * kPool) + slot) * 128u + 16u * ((2u * q4) ^ ((slot >> 1 & 3u) << 1));
+                } else {                                               // byte offset inside the level (chunk 0)
+                    toff[k] = (info & ~3u) + ((t & 1) && (info & 1u) ? (unsigned)(kC * 4) : 0u) + ((t & 2) && (info & 2u) ? (unsigned)a.gw[l] * (kC * 4) : 0u)
+                              + 32u * q4;
+                }
+            }
+        }
+    };
     auto affine = [&](int sv, int c) {
         const float4 pe = *reinterpret_cast<const float4*>(lds + kLdsPe + (srow * 2 + sv) * 4);
         const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 4 * (32 * c + 8 * q4));
@@ -295,26 +325,21 @@ __global__ void __launch_bounds__(kThreads) fused_tex_kernel(const TexArgs a) {
             hacc[k] = fmaf(w.z, pe.z, fmaf(w.y, pe.y, w.x * pe.x)) + w.w;
         }
     };
-    // tap number k = 0..11: level 2 - k / 4 (finest first, as car_fused.hip adds them), corner k % 4 (nw, ne, sw, se)
-    auto fetch = [&](int sv, int c, int buf, int k, bool l2_cached) {
-        const int l = 2 - k / 4, t = k % 4;
-        const unsigned info = reinterpret_cast<const unsigned*>(lds + kLdsTapI)[(srow * 2 + sv) * 3 + l];
-        if (l < 2 || l2_cached) {                                      // wave-uniform (compile-time for the coarse levels): from the cache
-            const unsigned slot = (info & 1023u) + ((t & 1) ? (info >> 10 & 1u) : 0u) + ((t & 2) ? (info >> 11) : 0u);
-            const unsigned piece = (2u * q4) ^ ((slot >> 1 & 3u) << 1);
-            const float* p = lds + kLdsCache + buf * kCacheBuf + (bundle * kPool + slot) * kSlice + 4 * piece;
+    auto fetch = [&](int c, int buf, int k, bool l2_cached) {
+        if constexpr (ABL == 1 || ABL == 3 || ABL == 5) return;
+        if (k >= 4 || l2_cached) {                                     // wave-uniform (compile-time for the coarse levels): from the cache
+            const char* p = reinterpret_cast<const char*>(lds + kLdsCache + buf * kCacheBuf) + toff[k];
             tap[0] = *reinterpret_cast<const f32x4*>(p);
-            tap[1] = *reinterpret_cast<const f32x4*>(p + 4);
-        } else {                                                       // from global memory
-            const char* base = reinterpret_cast<const char*>(a.gmap[l] + 32 * c + 8 * q4);
-            const unsigned o = (info & ~3u) + ((t & 1) && (info & 1u) ? (unsigned)(kC * 4) : 0u) + ((t & 2) && (info & 2u) ? (unsigned)a.gw[l] * (kC * 4) : 0u);
-            tap[0] = *reinterpret_cast<const f32x4*>(base + o);
-            tap[1] = *reinterpret_cast<const f32x4*>(base + o + 16);
+            tap[1] = *reinterpret_cast<const f32x4*>(p + 16);
+        } else {                                                       // the finest level from global memory
+            const char* p = reinterpret_cast<const char*>(a.gmap[2] + 32 * c) + toff[k];
+            tap[0] = *reinterpret_cast<const f32x4*>(p);
+            tap[1] = *reinterpret_cast<const f32x4*>(p + 16);
         }
     };
-    auto blend = [&](int sv, int k) {
-        const int l = 2 - k / 4, t = k % 4;
-        const float w = lds[kLdsTapW + (srow * 2 + sv) * 12 + 4 * l + t];
+    auto blend = [&](int k) {
+        if constexpr (ABL == 1 || ABL == 3 || ABL == 5) return;
+        const float w = tw[k];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { hacc[j] = fmaf(w, tap[0][j], hacc[j]); hacc[4 + j] = fmaf(w, tap[1][j], hacc[4 + j]); }
     };
@@ -342,9 +367,10 @@ __global__ void __launch_bounds__(kThreads) fused_tex_kernel(const TexArgs a) {
     half8 bhi, blo;
     {
         const bool l2c = l2c_sv[0];
+        load_taps(0);
         affine(0, 0);
 #pragma unroll
-        for (int k = 0; k < 12; ++k) { fetch(0, 0, 0, k, l2c); blend(0, k); }
+        for (int k = 0; k < 12; ++k) { fetch(0, 0, k, l2c); blend(k); }
         finish(bhi, blo);
     }
     __syncthreads();                                                   // every wave is done with cache buffer 0 before chunk 2 lands in it
@@ -363,30 +389,31 @@ __global__ void __launch_bounds__(kThreads) fused_tex_kernel(const TexArgs a) {
             const int n2sv = (c + 2 < kKS) ? sv : 1, n2c = (c + 2 < kKS) ? c + 2 : c + 2 - kKS;
             const int nbuf = (m + 1) & 1, n2buf = m & 1;
             const bool l2c = l2c_sv[nsv];
-            // 12 slots (6 per weight half chunk: three tile pairs and three single tiles), one gather tap each: the tap's 32 bytes are
-            // requested before the slot's MFMAs and blended after them; the DMA rides along: the three pieces of the next weight half
-            // chunk in slots 0-2, the next-but-one chunk's cache slices in slots 3-5
+            if (c + 1 == kKS && sv == 0) load_taps(1);                 // the gather moves on to the other source's taps
+            // 10 slots (5 per weight half chunk: four tile pairs and a single tile); the 12 gather taps are dealt over them (two in the
+            // first slot of each half): a tap's 32 bytes are requested before the slot's MFMAs and blended after them.  The DMA rides
+            // along: the three pieces of the next weight half chunk in slots 0-2, the next-but-one chunk's cache slices in slots 2-4.
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const float* wl = lds + kLdsWt + (g & 1) * kWBuf + 4 * lane;
 #pragma unroll
-                for (int qs = 0; qs < 6; ++qs) {
-                    const int k = 6 * half + qs;                       // tap of this slot
-                    if (k == 0) affine(nsv, nc);
-                    fetch(nsv, nc, nbuf, k, l2c);
-                    if (qs < 3) {
+                for (int qs = 0; qs < 5; ++qs) {
+                    const int k = 6 * half + qs + (qs > 0 ? 1 : 0);    // tap of this slot (slot 0: taps 6 half, 6 half + 1)
+                    if (half == 0 && qs == 0) affine(nsv, nc);
+                    if (qs == 0) { fetch(nc, nbuf, k, l2c); blend(k); fetch(nc, nbuf, k + 1, l2c); }
+                    else fetch(nc, nbuf, k, l2c);
+                    if constexpr (ABL != 4) {
                         const float* w0 = wl + (2 * qs * 2) * 256;
-                        mfma_pair(acc[kHalf * half + 2 * qs], acc[kHalf * half + 2 * qs + 1], w0, w0 + 512, bhi, blo);
-                    } else {
-                        mfma_single(acc[kHalf * half + 3 + qs], wl + ((3 + qs) * 2) * 256, bhi, blo);
+                        if (qs < 4) mfma_pair(acc[kHalf * half + 2 * qs], acc[kHalf * half + 2 * qs + 1], w0, w0 + 512, bhi, blo);
+                        else mfma_single(acc[kHalf * half + 8], w0, bhi, blo);
                     }
-                    if (qs < kPieces) weights_issue(a.blob, lds, g + 1, qs, lane, wave);
-                    else if (3 * half + qs - kPieces < kDmaPerWave) cache_issue(n2sv, n2c, n2buf, 3 * half + qs - kPieces);
-                    blend(nsv, k);
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (qs < kPieces) { if constexpr (ABL != 5) weights_issue(a.blob, lds, g + 1, qs, lane, wave); }
+                    if (qs >= 2) cache_issue(n2sv, n2c, n2buf, 3 * half + qs - 2);
+                    blend(qs == 0 ? k + 1 : k);
+                    if constexpr (ABL != 6) __builtin_amdgcn_sched_barrier(0);
                 }
                 if (half == 1) finish(bhi, blo);                       // the next chunk's B operand
-                chunk_sync();
+                if constexpr (ABL != 5) chunk_sync();
                 ++g;
             }
         }
@@ -458,10 +485,10 @@ __global__ void __launch_bounds__(kThreads) fused_tex_kernel(const TexArgs a) {
 
 // First half of car_fused_samples (car_fused.hip): every sample group whose coarse levels fit the texel cache; the others are
 // appended to `redo` (zeroed by the caller: [0] count, [1 + k] group index) for car_fused.hip's kernel.
-extern "C" int car_fused_samples_tex(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                                     const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
-                                     const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                                     float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* redo, void* stream) {
+static int launch_tex(int abl, const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                      const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
+                      const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                      float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* redo, void* stream) {
     CAR_REQUIRE(poses && rays && steps && gmaps && level_h && level_w && gmeta && wpt && blob && bias, "car_fused_samples_tex: null input");
     CAR_REQUIRE(e && qry && g && logit && pt && pixel_val && redo, "car_fused_samples_tex: null output");
     CAR_REQUIRE(n_levels == 3 && C == kC && V == 2, "car_fused_samples_tex: built for 3 pyramid levels, C = %d, V = 2 (got %d, %d, %d)", kC, n_levels, C, V);
@@ -478,10 +505,37 @@ extern "C" int car_fused_samples_tex(const float* poses, const float* rays, cons
     a.S = (long)b * V * R * P;
     a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val; a.redo = redo;
     const long groups = (long)b * V * car_div_up(R, kBundles * kRows) * car_div_up(P, kStepsPerGroup);
-    hipError_t e1 = hipFuncSetAttribute((const void*)fused_tex_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    void (*kern)(const TexArgs) = fused_tex_kernel<0>;
+#ifdef CAR_ABLATION
+    switch (abl) {
+        case 1: kern = fused_tex_kernel<1>; break;   case 2: kern = fused_tex_kernel<2>; break;   case 3: kern = fused_tex_kernel<3>; break;
+        case 4: kern = fused_tex_kernel<4>; break;   case 5: kern = fused_tex_kernel<5>; break;   case 6: kern = fused_tex_kernel<6>; break;
+        default: break;
+    }
+#else
+    (void)abl;
+#endif
+    hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e1 != hipSuccess) { car_set_error("car_fused_samples_tex: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(fused_tex_kernel, dim3((unsigned)groups), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a);
     CAR_CHECK_LAUNCH("car_fused_samples_tex");
     return CAR_OK;
 }
+
+extern "C" int car_fused_samples_tex(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                                     const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
+                                     const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                                     float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* redo, void* stream) {
+    return launch_tex(0, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt,
+                      pixel_val, redo, stream);
+}
+#ifdef CAR_ABLATION
+extern "C" int car_fused_samples_tex_ablate(int abl, const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                                            const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
+                                            const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                                            float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* redo, void* stream) {
+    return launch_tex(abl, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt,
+                      pixel_val, redo, stream);
+}
+#endif

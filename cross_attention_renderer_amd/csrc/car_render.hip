@@ -483,7 +483,11 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
     }
     {   // a6-a13 + round-1 logits: the fused per-sample kernel
         Stage stage("fused_samples", st);
-        if (d.fused_direct)
+        if (d.fused_direct == 2)
+            CAR_TRY(car_fused_samples_texfirst(in->poses, ws + w.rays, steps, in->gmaps, d.level_h, d.level_w, 3, kC, in->gmeta, pl + p.wpt, pl + p.blob,
+                                               pl + p.fbias, b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val,
+                                               reinterpret_cast<int*>(ws + w.redo), stream));
+        else if (d.fused_direct == 1)
             CAR_TRY(car_fused_samples_direct(in->poses, ws + w.rays, steps, in->gmaps, d.level_h, d.level_w, 3, kC, in->gmeta, pl + p.wpt, pl + p.blob,
                                              pl + p.fbias, b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
         else

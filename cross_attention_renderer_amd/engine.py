@@ -83,9 +83,10 @@ class RenderEngine:
         # stage-by-stage pipeline of this module (A/B and stage tests)
         self.fuse_samples = True
         self.fuse_round2 = True        # staged route: round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
-        # one-call route: the fused stage's direct kernel (every tap from global memory, csrc/car_fused.hip) instead of the LDS
-        # texel-cache kernel with hand-back (csrc/car_fused_tex.hip); bit-identical results (A/B)
-        self.fused_direct = False
+        # one-call route, the fused stage (bit-identical results): 0 the product (per-sample geometry in a pre-pass, then
+        # csrc/car_fused.hip), 1 csrc/car_fused.hip with the geometry in its workgroups' prologue, 2 the experimental LDS texel-cache
+        # kernel csrc/car_fused_tex.hip with hand-back
+        self.fused_direct = 0
         # sizing of the one-call route (tests shrink them to force several calls)
         self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
         self.max_level_bytes = (1 << 32) - 1               # a projected level of one call: the fused kernel's 32-bit texel offsets
@@ -392,7 +393,7 @@ class RenderEngine:
                              "at_wt2": ws("at_wt2", n, R, P) if m.repeat_attention else None, "poses": poses,
                              "qry": ws("qry", n, R, P, 128), "logit": ws("logit", n, R, P),
                              # sample groups (32 rays x 4 steps) the texel-cache kernel handed back to the direct kernel
-                             "handed_back": None if self.fused_direct else int(ws("redo", -1).view(torch.int32)[0])}
+                             "handed_back": int(ws("redo", -1).view(torch.int32)[0]) if self.fused_direct == 2 else None}
         return res
 
     # ------------------------------------------------------------------ stage timing (csrc/car_render.hip)

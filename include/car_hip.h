@@ -127,14 +127,18 @@ int car_gather_encode(const float* const* gmaps, const int* level_h, const int* 
  * layer inside fp16's range.  Outputs: e [S,576], qry [S,128], g [S,16] (the geometric query local_coords, models.py:528),
  * logit [S], pt [S,3], pixel_val [S,2] with S = b*V*R*P.  A level's projected map must stay below 4 GiB per call.
  *
- * Two kernels stand behind the stage.  csrc/car_fused_tex.hip keeps the distinct texels of every bundle of 16 rays x 4 steps in an
- * LDS texel cache (filled by LDS-DMA, ~7x fewer bytes through the texture-address path) and hands sample groups whose tap
- * footprint does not fit the cache back through a list; csrc/car_fused.hip fetches every tap from global memory.
- *   car_fused_samples        : the product — texel-cache kernel, then the direct kernel over the handed-back groups;
- *                              `scratch`: car_fused_scratch_ints(b, V, R, P) ints of device memory (the hand-back list);
- *   car_fused_samples_direct : the direct kernel alone (A/B partner; bit-identical results);
- *   car_fused_samples_tex    : the texel-cache kernel alone; `redo` as `scratch` above, zeroed by the caller: on return
- *                              redo[0] groups (indices redo[1..]) are still to be rendered. */
+ * Entry points of the stage (results bit-identical across all of them):
+ *   car_fused_samples          : the product — the per-sample geometry of the whole launch first, one thread per sample
+ *                                (sample_geom_kernel), then the fused kernel (csrc/car_fused.hip), whose workgroups would
+ *                                otherwise compute it in a serial prologue on a quarter of their waves; `scratch`:
+ *                                car_fused_scratch_ints(b, V, R, P) 4-byte words of device memory;
+ *   car_fused_samples_direct   : the fused kernel alone, geometry in its prologue (A/B partner, no scratch);
+ *   car_fused_samples_texfirst : experimental — csrc/car_fused_tex.hip keeps the distinct texels of every bundle of 16 rays x 4
+ *                                steps in an LDS texel cache (LDS-DMA, ~7x fewer bytes through the texture-address path) and
+ *                                hands sample groups whose tap footprint does not fit back to the fused kernel through a list;
+ *                                slower than the product today;
+ *   car_fused_samples_tex      : its first half alone; `redo` (first words of `scratch`, zeroed by the caller): on return
+ *                                redo[0] groups (indices redo[1..]) are still to be rendered. */
 size_t car_fused_blob_floats(void);
 size_t car_fused_bias_floats(void);
 size_t car_fused_scratch_ints(int b, int V, int R, int P);
@@ -146,6 +150,10 @@ int car_fused_samples_direct(const float* poses, const float* rays, const float*
                              const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt,
                              const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
                              float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream);
+int car_fused_samples_texfirst(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
+                               const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt,
+                               const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
+                               float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* scratch, void* stream);
 int car_fused_samples_tex(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
                           const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt,
                           const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
@@ -208,7 +216,7 @@ typedef struct car_dims {
     int n_levels;                  /* pyramid levels (3)                                                                      */
     int level_h[CAR_MAX_LEVELS], level_w[CAR_MAX_LEVELS], level_c[CAR_MAX_LEVELS];   /* e.g. 64x64x256, 128x128x256, 256x256x64 */
     int repeat_attention;          /* second attention round (models.py:547), the reference's default: 1                          */
-    int fused_direct;              /* 0: car_fused_samples (texel-cache kernel + hand-back); 1: car_fused_samples_direct (A/B)       */
+    int fused_direct;              /* fused stage: 0 car_fused_samples (product), 1 car_fused_samples_direct, 2 car_fused_samples_texfirst */
 } car_dims;
 
 /* Parameters in the reference's state_dict layout: row-major [out][in] fp32, 1x1 convolutions flattened (models.py:96-144). */
