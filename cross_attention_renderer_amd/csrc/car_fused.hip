@@ -55,9 +55,6 @@ struct FusedArgs {
     float* logit;
     float* pt;
     float* pixel_val;
-    const float* rec;          // NULL, or the per-sample geometry records of sample_geom_kernel: [S][8] = other-view grid (2), tanh(pt_0/5) (3), tanh(pt_1/5) (3)
-    const int* redo;           // NULL, or the sample groups car_fused_tex.hip handed back: [0] count, [1 + k] index of a group of
-                               // 32 rays x 4 steps (that kernel's group: two bundles), rendered here with the third bundle idle
 };
 
 // chunk order:  W2 x18 (source 0) | W2 x18 (source 1) | K1 over e_1 x5 (2,2,2,2,1 K steps) | K1 over e_0 x5 | K2 x2 | Q1 | Q2 x2
@@ -82,8 +79,7 @@ __device__ __forceinline__ int chunk_tiles(int g) {
 // ABL > 0: timing-only ablations (wrong results), instantiated only in the -DCAR_ABLATION development build (tools/):
 // 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers, 5 the gather alone (no e-path MFMAs, no weight DMA, no
 // barriers); probes of the texture-address path on top of 5: 6 odd rows masked off (whole quads of lanes inactive), 7 odd channel
-// quads masked off (half of every quad of lanes inactive), 9 no level-0 taps, 10 level-2 taps only in the first two chunks;
-// 11 = 1 without the per-sample geometry (what the serial prologue of a workgroup costs)
+// quads masked off (half of every quad of lanes inactive), 9 no level-0 taps, 10 level-2 taps only in the first two chunks
 template <int ABL>
 __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -91,23 +87,17 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     const int s = lane & 15, q4 = lane >> 4;
     const int nblk = gridDim.x;
     int blk = blockIdx.x;
-    const bool redo = a.redo != nullptr;
-    if (redo) {
-        if (blk >= a.redo[0]) return;
-        blk = a.redo[1 + blk];
-    } else {
-        // workgroup b runs on XCD b % 8 (observed, speed only): give every XCD a contiguous band of sample groups so that the
+    {   // workgroup b runs on XCD b % 8 (observed, speed only): give every XCD a contiguous band of sample groups so that the
         // texel rows its workgroups share stay in one L2
         const int q8 = nblk / 8, r8 = nblk % 8, xcd = blk % 8, idx = blk / 8;
         blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
-    const int group_rays = redo ? 2 * kRows : kBundles * kRows;       // rays per sample group
     // 192 samples = 48 consecutive rays x 4 consecutive steps: wave = (bundle of 16 rays, step), lane & 15 = ray of the bundle, so the
     // 16 rows a wave gathers together are the same step of neighbouring rays (shared texel rows)
-    const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + group_rays - 1) / group_rays;
+    const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + kBundles * kRows - 1) / (kBundles * kRows);
     const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
-    const int ray_i = bun * group_rays + (wave / kStepsPerGroup) * kRows + s, pp = pg * kStepsPerGroup + wave % kStepsPerGroup;
-    const bool live = ray_i < a.R && pp < a.P && (wave / kStepsPerGroup) * kRows < group_rays;
+    const int ray_i = bun * (kBundles * kRows) + (wave / kStepsPerGroup) * kRows + s, pp = pg * kStepsPerGroup + wave % kStepsPerGroup;
+    const bool live = ray_i < a.R && pp < a.P;
     const long i = ((long)nn * a.R + (ray_i < a.R ? ray_i : a.R - 1)) * a.P + (pp < a.P ? pp : a.P - 1);
 
     for (int k = tid; k < kC; k += 768) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
@@ -120,8 +110,8 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     const int P = a.P, V = a.V;
     if (wave < kGroup / 64) {
         const int sg = wave * 64 + lane, gwv = sg >> 4, gs = sg & 15;     // sample sg belongs to row gs of matrix wave gwv
-        const int g_ray = bun * group_rays + (gwv / kStepsPerGroup) * kRows + gs, g_pp = pg * kStepsPerGroup + gwv % kStepsPerGroup;
-        const bool g_live = g_ray < a.R && g_pp < a.P && (gwv / kStepsPerGroup) * kRows < group_rays;
+        const int g_ray = bun * (kBundles * kRows) + (gwv / kStepsPerGroup) * kRows + gs, g_pp = pg * kStepsPerGroup + gwv % kStepsPerGroup;
+        const bool g_live = g_ray < a.R && g_pp < a.P;
         const long gi = ((long)nn * a.R + (g_ray < a.R ? g_ray : a.R - 1)) * a.P + (g_pp < a.P ? g_pp : a.P - 1);
         const int p = (int)(gi % P);
         const long nr = gi / P;
@@ -130,26 +120,8 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
         const CarPose& Ps = a.poses[n];
         const CarRay ray = a.rays[nr];
         CarSample smp;
-        float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0;
-        const bool pre = a.rec != nullptr;                                 // the per-sample geometry was computed by sample_geom_kernel
-        if (pre) {
-            rec0 = *reinterpret_cast<const float4*>(a.rec + 8 * gi); rec1 = *reinterpret_cast<const float4*>(a.rec + 8 * gi + 4);
-            smp.grid[0] = a.pixel_val[2 * gi]; smp.grid[1] = a.pixel_val[2 * gi + 1];
-            smp.grid_in[0][0] = smp.grid_in[1][0] = rec0.x; smp.grid_in[0][1] = smp.grid_in[1][1] = rec0.y;
-#pragma unroll
-            for (int k = 0; k < 16; k += 4) {
-                const float4 g4 = *reinterpret_cast<const float4*>(a.g + 16 * gi + k);
-                smp.g[k] = g4.x; smp.g[k + 1] = g4.y; smp.g[k + 2] = g4.z; smp.g[k + 3] = g4.w;
-            }
-        } else {
         for (int k = 0; k < 2; ++k) smp.grid[k] = ray.start[k] + (ray.end[k] - ray.start[k]) * a.steps[p];
-        if constexpr (ABL == 11) {                                         // timing probe: no per-sample geometry (fp64 intersection, projections)
-            for (int k = 0; k < 3; ++k) { smp.pt[k] = ray.d[k]; smp.pt_in[0][k] = smp.pt_in[1][k] = ray.m[k]; }
-            for (int k = 0; k < CAR_G_DIM; ++k) smp.g[k] = ray.d[k % 3];
-            for (int k = 0; k < 2; ++k) { smp.grid_in[0][k] = smp.grid[k]; smp.grid_in[1][k] = -smp.grid[k]; }
-        } else
         car_sample_setup(Ps, a.poses + sc * 2, ray, 2, a.H, a.W, &smp);
-        }
 #pragma unroll
         for (int sv = 0; sv < 2; ++sv) {
             float gx, gy;
@@ -170,11 +142,9 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
             }
             const float px = sv == 0 ? smp.pt_in[0][0] : smp.pt_in[1][0], py = sv == 0 ? smp.pt_in[0][1] : smp.pt_in[1][1],
                         pz = sv == 0 ? smp.pt_in[0][2] : smp.pt_in[1][2];
-            *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) =
-                pre ? (sv == 0 ? make_float4(rec0.z, rec0.w, rec1.x, 0.0f) : make_float4(rec1.y, rec1.z, rec1.w, 0.0f))
-                    : make_float4(tanhf(px / 5.0f), tanhf(py / 5.0f), tanhf(pz / 5.0f), 0.0f);
+            *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f), tanhf(py / 5.0f), tanhf(pz / 5.0f), 0.0f);
         }
-        if (g_live && !pre) {
+        if (g_live) {
             a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1];
             a.pt[3 * gi + 0] = smp.pt[0]; a.pt[3 * gi + 1] = smp.pt[1]; a.pt[3 * gi + 2] = smp.pt[2];
         }
@@ -183,7 +153,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
         for (int k = 0; k < 16; k += 4) {
             const float4 g4 = make_float4(smp.g[k], smp.g[k + 1], smp.g[k + 2], smp.g[k + 3]);
             *reinterpret_cast<float4*>(gl + k) = g4;
-            if (g_live && !pre) *reinterpret_cast<float4*>(a.g + 16 * gi + k) = g4;
+            if (g_live) *reinterpret_cast<float4*>(a.g + 16 * gi + k) = g4;
         }
     }
     __syncthreads();                                                   // tables and tap records visible
@@ -198,7 +168,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     const unsigned row_step[3] = {(unsigned)a.gw[0] * (kC * 4), (unsigned)a.gw[1] * (kC * 4), (unsigned)a.gw[2] * (kC * 4)};
 
     auto issue_row = [&](f32x4 (&tap)[4], int sv, int c, int l, int it) {
-        if constexpr (ABL == 1 || ABL == 2 || ABL == 3 || ABL == 11) return;
+        if constexpr (ABL == 1 || ABL == 2 || ABL == 3) return;
         if constexpr (ABL == 9) { if (l == 0) return; }
         if constexpr (ABL == 10) { if (l == 2 && c >= 2) return; }
         if constexpr (ABL == 6) { if (r0 & 1) return; }
@@ -388,38 +358,9 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
 }
 
 
-// Per-sample geometry (car_geom.h: fp64 Pluecker intersection, cross-view projection, geometric query) for every sample of the
-// launch, one thread per sample: what the workgroups of the fused kernel otherwise compute in a serial prologue on three of their
-// twelve waves.  Writes the stage's outputs pixel_val, pt, g and an 8-float record per sample for the fused kernel.
-__global__ void __launch_bounds__(256) sample_geom_kernel(const CarPose* __restrict__ poses, const CarRay* __restrict__ rays,
-                                                          const float* __restrict__ steps, int V, int R, int P, int H, int W, long S,
-                                                          float* __restrict__ pixel_val, float* __restrict__ pt, float* __restrict__ g,
-                                                          float* __restrict__ rec) {
-    const long gi = (long)blockIdx.x * 256 + threadIdx.x;
-    if (gi >= S) return;
-    const int p = (int)(gi % P);
-    const long nr = gi / P;
-    const int n = (int)(nr / R);
-    const int v = n % V, sc = n / V;
-    const CarRay ray = rays[nr];
-    CarSample smp;
-    for (int k = 0; k < 2; ++k) smp.grid[k] = ray.start[k] + (ray.end[k] - ray.start[k]) * steps[p];
-    car_sample_setup(poses[n], poses + sc * 2, ray, 2, H, W, &smp);
-    pixel_val[2 * gi] = smp.grid[0]; pixel_val[2 * gi + 1] = smp.grid[1];
-    pt[3 * gi + 0] = smp.pt[0]; pt[3 * gi + 1] = smp.pt[1]; pt[3 * gi + 2] = smp.pt[2];
-#pragma unroll
-    for (int k = 0; k < 16; k += 4) *reinterpret_cast<float4*>(g + 16 * gi + k) = make_float4(smp.g[k], smp.g[k + 1], smp.g[k + 2], smp.g[k + 3]);
-    const int o = 1 - v;                                               // the other source view
-    const float pe[6] = {tanhf(smp.pt_in[0][0] / 5.0f), tanhf(smp.pt_in[0][1] / 5.0f), tanhf(smp.pt_in[0][2] / 5.0f),
-                         tanhf(smp.pt_in[1][0] / 5.0f), tanhf(smp.pt_in[1][1] / 5.0f), tanhf(smp.pt_in[1][2] / 5.0f)};
-    *reinterpret_cast<float4*>(rec + 8 * gi) = make_float4(o == 0 ? smp.grid_in[0][0] : smp.grid_in[1][0], o == 0 ? smp.grid_in[0][1] : smp.grid_in[1][1], pe[0], pe[1]);
-    *reinterpret_cast<float4*>(rec + 8 * gi + 4) = make_float4(pe[2], pe[3], pe[4], pe[5]);
-}
-
 int launch_fused(int abl, const float* poses, const float* rays, const float* steps, const float* const* gmaps, const int* level_h,
                  const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,
-                 int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, const int* redo, float* rec,
-                 void* stream) {
+                 int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
     CAR_REQUIRE(poses && rays && steps && gmaps && level_h && level_w && gmeta && wpt && blob && bias, "car_fused_samples: null input");
     CAR_REQUIRE(e && qry && g && logit && pt && pixel_val, "car_fused_samples: null output");
     CAR_REQUIRE(n_levels == 3 && C == kC && V == 2, "car_fused_samples: built for 3 pyramid levels, C = %d, V = 2 (got %d, %d, %d)", kC, n_levels, C, V);
@@ -435,22 +376,14 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     a.gmeta = gmeta; a.wpt = wpt; a.blob = blob; a.bias = bias;
     a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
     a.S = (long)b * V * R * P;
-    a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val; a.redo = redo; a.rec = rec;
-    if (rec && !redo) {
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(sample_geom_kernel, dim3(car_div_up(a.S, 256)), dim3(256), 0, (hipStream_t)stream, a.poses, a.rays, steps, V, R, P, H, W, a.S,
-                           pixel_val, pt, g, rec);
-        CAR_CHECK_LAUNCH("car_fused_samples (geometry)");
-    }
-    // redo mode: one workgroup per group the texel-cache kernel could have handed back (most exit at once: the list is short)
-    const long groups = (long)b * V * car_div_up(R, redo ? 2 * kRows : kBundles * kRows) * car_div_up(P, kStepsPerGroup);
+    a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
+    const long groups = (long)b * V * car_div_up(R, kBundles * kRows) * car_div_up(P, kStepsPerGroup);
     void (*kern)(const FusedArgs) = fused_kernel<0>;
 #ifdef CAR_ABLATION
     switch (abl) {
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 5: kern = fused_kernel<5>; break;   case 6: kern = fused_kernel<6>; break;   case 7: kern = fused_kernel<7>; break;
         case 8: kern = fused_kernel<8>; break;   case 9: kern = fused_kernel<9>; break;   case 10: kern = fused_kernel<10>; break;
-        case 11: kern = fused_kernel<11>; break;
         default: break;
     }
 #else
@@ -469,49 +402,12 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
 extern "C" size_t car_fused_blob_floats(void) { return (size_t)kBlobTiles * kTile; }
 extern "C" size_t car_fused_bias_floats(void) { return (size_t)kBiasFloats; }
 
-extern "C" int car_fused_samples_tex(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                                     const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
-                                     const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                                     float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* redo, void* stream);
-
-static size_t redo_words(int b, int V, int R, int P) {
-    return ((size_t)b * V * car_div_up(R, 2 * kRows) * car_div_up(P, kStepsPerGroup) + 1 + 3) & ~(size_t)3;
-}
-// scratch of the stage, in 4-byte words: the hand-back list of the texel-cache kernel, then 8 floats per sample (geometry records)
-extern "C" size_t car_fused_scratch_ints(int b, int V, int R, int P) { return redo_words(b, V, R, P) + 8 * (size_t)b * V * R * P; }
-
-// The stage as the product runs it: per-sample geometry for the whole launch (sample_geom_kernel), then the direct-gather kernel.
 extern "C" int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
                                  const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
                                  const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                                 float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* scratch, void* stream) {
-    CAR_REQUIRE(scratch, "car_fused_samples: null scratch");
-    float* rec = reinterpret_cast<float*>(scratch + redo_words(b, V, R, P));
+                                 float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
     return launch_fused(0, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
-                        logit, pt, pixel_val, nullptr, rec, stream);
-}
-
-// The same kernel with the geometry computed inside every workgroup's prologue (no scratch): the A/B partner.
-extern "C" int car_fused_samples_direct(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                                        const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
-                                        const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                                        float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
-    return launch_fused(0, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
-                        logit, pt, pixel_val, nullptr, nullptr, stream);
-}
-
-// Texel-cache kernel (car_fused_tex.hip) over every sample group, then this file's kernel over the groups it handed back.
-extern "C" int car_fused_samples_texfirst(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                                          const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
-                                          const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                                          float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* scratch, void* stream) {
-    CAR_REQUIRE(scratch, "car_fused_samples_texfirst: null scratch");
-    if (hipMemsetAsync(scratch, 0, sizeof(int), (hipStream_t)stream) != hipSuccess) { car_set_error("car_fused_samples_texfirst: memset failed"); return CAR_E_LAUNCH; }
-    int rc = car_fused_samples_tex(poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
-                                   logit, pt, pixel_val, scratch, stream);
-    if (rc != CAR_OK) return rc;
-    return launch_fused(0, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
-                        logit, pt, pixel_val, scratch, nullptr, stream);
+                        logit, pt, pixel_val, stream);
 }
 
 #ifdef CAR_ABLATION
@@ -521,6 +417,6 @@ extern "C" int car_fused_samples_ablate(int abl, const float* poses, const float
                                         const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
                                         float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
     return launch_fused(abl, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
-                        logit, pt, pixel_val, nullptr, nullptr, stream);
+                        logit, pt, pixel_val, stream);
 }
 #endif

@@ -14,7 +14,6 @@ extern "C" size_t car_fused_blob_floats(void);
 extern "C" size_t car_fused_bias_floats(void);
 extern "C" size_t car_round2_packed_floats(void);
 extern "C" size_t car_round2_bias_floats(void);
-extern "C" size_t car_fused_scratch_ints(int b, int V, int R, int P);
 
 namespace {
 
@@ -189,7 +188,7 @@ int check_dims(const car_dims* d, const char* who) {
 // ---- workspace layout ----------------------------------------------------------------------------------------------
 struct Work {
     size_t rays, phi_x, e, q, g, logit, logit2, pt, pixel_val, coords, at_wt, at_wt2, amax, depth, ebar, z1, hb, uh, zrep, x, net,
-        out3, valid, redo, total;                                        // offsets in floats
+        out3, valid, total;                                        // offsets in floats
 };
 Work work_layout(const car_dims& d) {
     Work w;
@@ -219,7 +218,6 @@ Work work_layout(const car_dims& d) {
     w.net = take(BR * kD);
     w.out3 = take(BR * 4);
     w.valid = take(BR);
-    w.redo = take(car_fused_scratch_ints(d.b, d.V, d.R, d.P));
     w.total = o;
     return w;
 }
@@ -313,8 +311,7 @@ extern "C" int car_workspace_find(const car_dims* dims, const char* name, size_t
     const struct { const char* name; size_t off, cnt; } tab[] = {
         {"rays", w.rays, n * dims->R * CAR_RAY_FLOATS}, {"e", w.e, S * kC}, {"qry", w.q, S * kD}, {"g", w.g, S * CAR_G_DIM},
         {"logit", w.logit, S}, {"logit2", w.logit2, S}, {"pt", w.pt, S * 3}, {"at_wt2", w.at_wt2, S}, {"ebar", w.ebar, BR * kC},
-        {"z1", w.z1, BR * kE}, {"uh", w.uh, BR * kD}, {"zrep", w.zrep, BR * 2 * kE}, {"out3", w.out3, BR * 4},
-        {"redo", w.redo, car_fused_scratch_ints(dims->b, dims->V, dims->R, dims->P)}};
+        {"z1", w.z1, BR * kE}, {"uh", w.uh, BR * kD}, {"zrep", w.zrep, BR * 2 * kE}, {"out3", w.out3, BR * 4}};
     for (const auto& t : tab)
         if (strcmp(t.name, name) == 0) { *offset_floats = t.off; *n_floats = t.cnt; return CAR_OK; }
     car_set_error("car_workspace_find: unknown tensor '%s'", name);
@@ -483,17 +480,8 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
     }
     {   // a6-a13 + round-1 logits: the fused per-sample kernel
         Stage stage("fused_samples", st);
-        if (d.fused_direct == 2)
-            CAR_TRY(car_fused_samples_texfirst(in->poses, ws + w.rays, steps, in->gmaps, d.level_h, d.level_w, 3, kC, in->gmeta, pl + p.wpt, pl + p.blob,
-                                               pl + p.fbias, b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val,
-                                               reinterpret_cast<int*>(ws + w.redo), stream));
-        else if (d.fused_direct == 1)
-            CAR_TRY(car_fused_samples_direct(in->poses, ws + w.rays, steps, in->gmaps, d.level_h, d.level_w, 3, kC, in->gmeta, pl + p.wpt, pl + p.blob,
-                                             pl + p.fbias, b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
-        else
-            CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->gmaps, d.level_h, d.level_w, 3, kC, in->gmeta, pl + p.wpt, pl + p.blob,
-                                      pl + p.fbias, b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val,
-                                      reinterpret_cast<int*>(ws + w.redo), stream));
+        CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->gmaps, d.level_h, d.level_w, 3, kC, in->gmeta, pl + p.wpt, pl + p.blob,
+                                  pl + p.fbias, b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
     }
     {   // a14 + a16: attention round 1, depth read-out, argmax
         Stage stage("attend_1", st);

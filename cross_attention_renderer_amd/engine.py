@@ -83,10 +83,6 @@ class RenderEngine:
         # stage-by-stage pipeline of this module (A/B and stage tests)
         self.fuse_samples = True
         self.fuse_round2 = True        # staged route: round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
-        # one-call route, the fused stage (bit-identical results): 0 the product (per-sample geometry in a pre-pass, then
-        # csrc/car_fused.hip), 1 csrc/car_fused.hip with the geometry in its workgroups' prologue, 2 the experimental LDS texel-cache
-        # kernel csrc/car_fused_tex.hip with hand-back
-        self.fused_direct = 0
         # sizing of the one-call route (tests shrink them to force several calls)
         self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
         self.max_level_bytes = (1 << 32) - 1               # a projected level of one call: the fused kernel's 32-bit texel offsets
@@ -240,7 +236,6 @@ class RenderEngine:
         for l, t in enumerate(z):
             d.level_c[l], d.level_h[l], d.level_w[l] = t.shape[1], t.shape[2], t.shape[3]
         d.repeat_attention = int(m.repeat_attention)
-        d.fused_direct = int(self.fused_direct)
         return d
 
     def _plan_for(self, d, device) -> Tensor:
@@ -390,10 +385,7 @@ class RenderEngine:
             res["stages"] = {"rays": ws("rays", n, R, 12), "pt": ws("pt", n, R, P, 3), "local_coords": None,
                              "g": ws("g", n, R, P, 16), "interp_val": ws("e", n, R, P, 576),
                              "z_final": ws("zrep", b * R, 576)[:, :288].reshape(b, R, 288),
-                             "at_wt2": ws("at_wt2", n, R, P) if m.repeat_attention else None, "poses": poses,
-                             "qry": ws("qry", n, R, P, 128), "logit": ws("logit", n, R, P),
-                             # sample groups (32 rays x 4 steps) the texel-cache kernel handed back to the direct kernel
-                             "handed_back": int(ws("redo", -1).view(torch.int32)[0]) if self.fused_direct == 2 else None}
+                             "at_wt2": ws("at_wt2", n, R, P) if m.repeat_attention else None, "poses": poses}
         return res
 
     # ------------------------------------------------------------------ stage timing (csrc/car_render.hip)

@@ -125,39 +125,13 @@ int car_gather_encode(const float* const* gmaps, const int* level_h, const int* 
  * a power of two chosen from the layer's largest weight, recorded in `bias`).  `gmeta` [n_levels]: max |G_l| of every projected
  * level (car_project_maps writes it), from which the kernel derives the power of two that keeps the activations of the first
  * layer inside fp16's range.  Outputs: e [S,576], qry [S,128], g [S,16] (the geometric query local_coords, models.py:528),
- * logit [S], pt [S,3], pixel_val [S,2] with S = b*V*R*P.  A level's projected map must stay below 4 GiB per call.
- *
- * Entry points of the stage (results bit-identical across all of them):
- *   car_fused_samples          : the product — the per-sample geometry of the whole launch first, one thread per sample
- *                                (sample_geom_kernel), then the fused kernel (csrc/car_fused.hip), whose workgroups would
- *                                otherwise compute it in a serial prologue on a quarter of their waves; `scratch`:
- *                                car_fused_scratch_ints(b, V, R, P) 4-byte words of device memory;
- *   car_fused_samples_direct   : the fused kernel alone, geometry in its prologue (A/B partner, no scratch);
- *   car_fused_samples_texfirst : experimental — csrc/car_fused_tex.hip keeps the distinct texels of every bundle of 16 rays x 4
- *                                steps in an LDS texel cache (LDS-DMA, ~7x fewer bytes through the texture-address path) and
- *                                hands sample groups whose tap footprint does not fit back to the fused kernel through a list;
- *                                slower than the product today;
- *   car_fused_samples_tex      : its first half alone; `redo` (first words of `scratch`, zeroed by the caller): on return
- *                                redo[0] groups (indices redo[1..]) are still to be rendered. */
+ * logit [S], pt [S,3], pixel_val [S,2] with S = b*V*R*P.  A level's projected map must stay below 4 GiB per call. */
 size_t car_fused_blob_floats(void);
 size_t car_fused_bias_floats(void);
-size_t car_fused_scratch_ints(int b, int V, int R, int P);
 int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
                       const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt,
                       const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                      float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* scratch, void* stream);
-int car_fused_samples_direct(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                             const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt,
-                             const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                             float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream);
-int car_fused_samples_texfirst(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                               const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt,
-                               const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                               float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* scratch, void* stream);
-int car_fused_samples_tex(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                          const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt,
-                          const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                          float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, int* redo, void* stream);
+                      float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream);
 
 /* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
  *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).
@@ -216,7 +190,6 @@ typedef struct car_dims {
     int n_levels;                  /* pyramid levels (3)                                                                      */
     int level_h[CAR_MAX_LEVELS], level_w[CAR_MAX_LEVELS], level_c[CAR_MAX_LEVELS];   /* e.g. 64x64x256, 128x128x256, 256x256x64 */
     int repeat_attention;          /* second attention round (models.py:547), the reference's default: 1                          */
-    int fused_direct;              /* fused stage: 0 car_fused_samples (product), 1 car_fused_samples_direct, 2 car_fused_samples_texfirst */
 } car_dims;
 
 /* Parameters in the reference's state_dict layout: row-major [out][in] fp32, 1x1 convolutions flattened (models.py:96-144). */
@@ -274,8 +247,7 @@ size_t car_workspace_bytes(const car_dims* dims);
 int car_render_forward(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
                        void* workspace, size_t workspace_bytes, void* stream);
 /* Where a named intermediate lives inside the workspace after car_render_forward (tests, debugging, profiling): one of
- * "rays" "e" "qry" "g" "logit" "logit2" "pt" "at_wt2" "ebar" "z1" "uh" "zrep" "out3" "redo" (ints: the fused stage's hand-back
- * list).  Returns 0 and the offset / count in 4-byte words. */
+ * "rays" "e" "qry" "g" "logit" "logit2" "pt" "at_wt2" "ebar" "z1" "uh" "zrep" "out3".  Returns 0 and the float offset / count. */
 int car_workspace_find(const car_dims* dims, const char* name, size_t* offset_floats, size_t* n_floats);
 
 /* ---- stage timing (the reference's only hooks are record_function labels, resnet_block_fc.py:54, 139, and one time.time() pair,

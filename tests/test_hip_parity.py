@@ -572,72 +572,3 @@ def test_forward_without_z_runs_get_z_on_the_device():
         e = err_stats(out[k].cpu(), ora[k])
         assert e["max"] <= TOL, (k, e)
     assert torch.equal(out["valid_mask"].cpu(), ora["valid_mask"])
-
-
-@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c3", "t2_c4", "t2_c5"])
-def test_texel_cache_kernel_is_bit_identical_to_the_direct_kernel(name):
-    """csrc/car_fused_tex.hip (taps served from an LDS texel cache filled by LDS-DMA, sample groups that do not fit handed back to
-    csrc/car_fused.hip) against csrc/car_fused.hip alone (every tap from global memory): same arithmetic in the same order per
-    sample, so every tensor the stage writes and every output must agree bit for bit."""
-    c, fx, ora, tex = run_case(name, engine_setup=lambda e: setattr(e, "fused_direct", 2))
-    _, _, _, direct = run_case(name, engine_setup=lambda e: setattr(e, "fused_direct", 1))
-    _, _, _, product = run_case(name)
-    assert direct["stages"]["handed_back"] is None and tex["stages"]["handed_back"] >= 0
-    for k in ("interp_val", "qry", "logit", "g", "pt"):
-        assert torch.equal(product["stages"][k], direct["stages"][k]), ("geometry pre-pass", k)
-    for k in ("rgb", "depth_ray", "at_wt", "at_wt_max", "valid_mask", "pixel_val"):
-        assert torch.equal(product[k], direct[k]), ("geometry pre-pass", k)
-    for k in ("interp_val", "qry", "logit", "g", "pt"):
-        assert torch.equal(tex["stages"][k], direct["stages"][k]), (k, (tex["stages"][k].double() - direct["stages"][k].double()).abs().max().item())
-    for k in ("rgb", "depth_ray", "at_wt", "at_wt_max", "valid_mask", "pixel_val"):
-        assert torch.equal(tex[k], direct[k]), k
-    n_groups = c["b"] * 2 * -(-c["rays"] // 32) * -(-c["P"] // 4)
-    print(f"{name}: {tex['stages']['handed_back']} of {n_groups} sample groups handed back")
-
-
-@pytest.mark.parametrize("H,P,R,b,alpha", [(256, 64, 4096, 1, 0.5), (256, 64, 2000, 2, 0.1), (64, 32, 1500, 1, 0.8), (384, 24, 777, 1, 0.5)])
-def test_texel_cache_kernel_on_dense_rays(H, P, R, b, alpha):
-    """Consecutive pixels (what a render loop sends): neighbouring rays share their texels, the bundles' footprints fit the cache and
-    the texel-cache kernel itself does the work (the sparse fixture rays above mostly exercise the hand-back).  Bit-identical to the
-    direct kernel; 48 of the rays against the oracle."""
-    from cross_attention_renderer_amd import synthetic as S
-    from cross_attention_renderer_amd.engine import RenderEngine
-    from cross_attention_renderer_amd.models import CrossAttentionRenderer
-    dev = torch.device("cuda:0")
-    torch.manual_seed(0)
-    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).eval()
-    S.perturb_parameters(m, seed=2)
-    m.H = m.W = H
-    uv = S.pixel_grid(H, H)[(H // 3) * H + 5:(H // 3) * H + 5 + R].contiguous()
-    inp = S.stereo_scene(H, b=b, uv=uv, seed=5, alpha=alpha)
-    z = S.feature_maps(b, 2, H, seed=1)
-    sd = {k: v.clone() for k, v in m.state_dict().items()}
-    m = m.to(dev)
-    dinp, dz = to_device(inp, dev, cameras_on_host=True), [t.to(dev) for t in z]
-    outs = {}
-    for variant in (0, 1, 2):
-        m._engine = RenderEngine(m)
-        m._engine.fused_direct = variant
-        with torch.no_grad():
-            o = m(dinp, z=dz, debug=True)
-        torch.cuda.synchronize()
-        outs[variant] = o
-    tex, ref = outs[2], outs[1]
-    for k in ("interp_val", "qry", "logit", "g", "pt"):
-        assert torch.equal(outs[0]["stages"][k], ref["stages"][k]), ("geometry pre-pass", k)
-    for k in ("rgb", "depth_ray", "at_wt", "at_wt_max", "valid_mask"):
-        assert torch.equal(outs[0][k], ref[k]), ("geometry pre-pass", k)
-    n_groups = b * 2 * -(-R // 32) * -(-P // 4)
-    print(f"H={H} P={P} R={R} b={b} alpha={alpha}: {tex['stages']['handed_back']} of {n_groups} sample groups handed back")
-    assert tex["stages"]["handed_back"] <= n_groups // 2, "the texel-cache kernel did not do the work"
-    for k in ("interp_val", "qry", "logit", "g", "pt"):
-        assert torch.equal(tex["stages"][k], ref["stages"][k]), k
-    for k in ("rgb", "depth_ray", "at_wt", "at_wt_max", "valid_mask"):
-        assert torch.equal(tex[k], ref[k]), k
-    idx = torch.linspace(0, R - 1, 48).long()
-    sub = {"context": inp["context"], "query": dict(inp["query"], uv=inp["query"]["uv"][:, :, idx].contiguous())}
-    with torch.no_grad():
-        ora = O.render_forward(sd, sub, z, O.RenderConfig(n_view=2, npoints=P, H=H, W=H))
-    for k, got in (("rgb", tex["rgb"][:, :, idx]), ("depth_ray", tex["depth_ray"][:, idx]), ("at_wt", tex["at_wt"][:, idx])):
-        e = err_stats(got.cpu(), ora[k])
-        assert e["max"] <= TOL, (k, e)

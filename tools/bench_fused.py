@@ -26,7 +26,7 @@ def main():
     dev_lib = ctypes.CDLL(build_dev())
     fn = dev_lib.car_fused_samples_ablate
     fn.restype = ctypes.c_int
-    fn.argtypes = [ctypes.c_int] + _lib.SIGNATURES["car_fused_samples_direct"][1]
+    fn.argtypes = [ctypes.c_int] + _lib.SIGNATURES["car_fused_samples"][1]
     lib = _lib.load()
     dev = torch.device("cuda:0")
     model = bench.build_model(dev)
@@ -76,44 +76,7 @@ def main():
     pixel_val = torch.empty(2 * R * bench.P * 2, device=dev)
     S = 2 * R * bench.P
     flop = 2.0 * S * bench.FUSED_MACS
-    # the product: texel-cache kernel (csrc/car_fused_tex.hip) + the direct kernel over what it hands back
-    scratch = torch.zeros(lib.car_fused_scratch_ints(1, 2, R, bench.P), dtype=torch.int32, device=dev)
-    for name, fn2 in (("geometry pre-pass + fused kernel (product)", lib.car_fused_samples), ("texel cache + hand-back", lib.car_fused_samples_texfirst),
-                      ("texel cache alone", lib.car_fused_samples_tex)):
-        lat = []
-        for it in range(7):
-            scratch[:1].zero_()
-            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            rc = fn2(eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), gm, hs, wss, 3, 576, gmeta, wpt.data_ptr(), blob.data_ptr(),
-                     bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
-                     pixel_val.data_ptr(), scratch.data_ptr(), st)
-            b_.record()
-            _lib.check(rc, name)
-            lat.append((a, b_))
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b_) for a, b_ in lat[2:])
-        print(f"{name}: median {ms[len(ms) // 2]:.3f} ms  min {ms[0]:.3f} ms  -> {flop / ms[len(ms) // 2] / 1e9:.1f} TFLOP/s; "
-              f"{int(scratch[0])} of {scratch.numel() - 1} groups handed back", flush=True)
-    tfn = dev_lib.car_fused_samples_tex_ablate
-    tfn.restype = ctypes.c_int
-    tfn.argtypes = [ctypes.c_int] + _lib.SIGNATURES["car_fused_samples_tex"][1]
-    for v in (0, 1, 2, 3, 4, 5, 6):
-        lat = []
-        for it in range(6):
-            scratch[:1].zero_()
-            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            rc = tfn(v, eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), gm, hs, wss, 3, 576, gmeta, wpt.data_ptr(), blob.data_ptr(),
-                     bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
-                     pixel_val.data_ptr(), scratch.data_ptr(), st)
-            b_.record()
-            assert rc == 0
-            lat.append((a, b_))
-        torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b_) for a, b_ in lat[2:])
-        print(f"TEX ABL={v}: median {ms[len(ms) // 2]:.3f} ms  min {ms[0]:.3f} ms", flush=True)
-    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 5]
+    variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 5, 6, 7, 8, 9, 10]
     for v in variants:
         lat = []
         for it in range(7):

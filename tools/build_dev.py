@@ -15,17 +15,13 @@ def build_dev() -> str:
     import __graft_entry__ as ge
     ge.build()
     os.makedirs(DEV_DIR, exist_ok=True)
-    dev_units = ("car_fused.hip", "car_fused_tex.hip")
-    hdrs = [os.path.join(ge.CSRC, f) for f in os.listdir(ge.CSRC) if f.endswith(".h")]
-    dev_objs = []
-    for unit in dev_units:
-        obj = os.path.join(DEV_DIR, unit.replace(".hip", "_dev.o"))
-        src = os.path.join(ge.CSRC, unit)
-        if ge._stale(obj, [src] + hdrs):
-            subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCAR_ABLATION", "-c", src, "-o", obj,
-                                   "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS[unit]])
-        dev_objs.append(obj)
-    objs = [os.path.join(ge.CSRC, "_obj", u.replace(".hip", ".o")) for u in ge.UNITS if u not in dev_units] + dev_objs
+    obj = os.path.join(DEV_DIR, "car_fused_dev.o")
+    src = os.path.join(ge.CSRC, "car_fused.hip")
+    deps = [src] + [os.path.join(ge.CSRC, f) for f in os.listdir(ge.CSRC) if f.endswith(".h")]
+    if ge._stale(obj, deps):
+        subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCAR_ABLATION", "-c", src, "-o", obj,
+                               "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS["car_fused.hip"]])
+    objs = [os.path.join(ge.CSRC, "_obj", u.replace(".hip", ".o")) for u in ge.UNITS if u != "car_fused.hip"] + [obj]
     if ge._stale(DEV_LIB, objs):
         subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", DEV_LIB, *objs])
     return DEV_LIB
