@@ -79,7 +79,8 @@ __device__ __forceinline__ int chunk_tiles(int g) {
 // ABL > 0: timing-only ablations (wrong results), instantiated only in the -DCAR_ABLATION development build (tools/):
 // 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers, 5 the gather alone (no e-path MFMAs, no weight DMA, no
 // barriers); probes of the texture-address path on top of 5: 6 odd rows masked off (whole quads of lanes inactive), 7 odd channel
-// quads masked off (half of every quad of lanes inactive), 9 no level-0 taps, 10 level-2 taps only in the first two chunks
+// quads masked off (half of every quad of lanes inactive), 9 no level-0 taps, 10 level-2 taps only in the first two chunks;
+// 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val)
 template <int ABL>
 __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -100,6 +101,10 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     const bool live = ray_i < a.R && pp < a.P;
     const long i = ((long)nn * a.R + (ray_i < a.R ? ray_i : a.R - 1)) * a.P + (pp < a.P ? pp : a.P - 1);
 
+    // ABL 4 (development build): the full kernel, plus shader-clock stamps of wave 0 at the phase boundaries, written over pixel_val
+    long long stamp[12];
+    auto mark = [&](int k) { if constexpr (ABL == 4) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); };
+    mark(0);
     for (int k = tid; k < kC; k += 768) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
     for (int k = tid; k < kBiasFloats; k += 768) lds[kLdsBias + k] = a.bias[k];
     int g = 0;
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
             *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f), tanhf(py / 5.0f), tanhf(pz / 5.0f), 0.0f);
         }
         if (g_live) {
-            a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1];
+            if constexpr (ABL != 4) { a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1]; }
             a.pt[3 * gi + 0] = smp.pt[0]; a.pt[3 * gi + 1] = smp.pt[1]; a.pt[3 * gi + 2] = smp.pt[2];
         }
         float* gl = lds + kLdsG + sg * 16;
@@ -157,6 +162,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
         }
     }
     __syncthreads();                                                   // tables and tap records visible
+    mark(1);
 
     // ---- gather machinery: lane owns rows rr = (lane>>3) + 8*it (it = 0, 1) and channel quad qd = lane & 7 of a chunk.
     //      A batch = the 4 tap loads of one row group `it` at one level; two batches (bufA: it 0, bufB: it 1) are in flight. ----
@@ -246,6 +252,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
         finish_row(it);
     }
     stream_sync();                                                     // weight chunk 0 landed
+    mark(2);
     constexpr bool kTapsLive = (ABL == 0 || ABL >= 5);
     issue_row(bufA, 0, 1, 2, 0);                                       // pipeline prologue: level 2 of chunk (0, 1), both row groups
     issue_row(bufB, 0, 1, 2, 1);
@@ -293,6 +300,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
             ++g;
         }
         scale_acc<kTE>(acc, e_down);
+        mark(3 + sv);
         if (sv == 0) {
             m0 = sample_max<kTE, false>(acc);
             if (live) store_rows<kTE>(acc, a.e + i * (2 * kE), q4);
@@ -305,11 +313,24 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     pow2_scale(fmaxf(fmaxf(m0, sample_max<kTE, false>(acc)), 1e-30f), p, pinv);
     f32x4 k1[kTD];
     init_bias<kTD>(k1, lds + kLdsBias + kBiasK1, q4, p / lsc[kLayerK1]);
-    chained_layer<kTE, false, ABL>(k1, acc, p, a.blob, lds, g, lane, wave);
-    if (live) store_rows<kTE>(acc, a.e + i * (2 * kE) + kE, q4);
+    // As soon as a K step has taken its two tiles of e_1 they are stored and e_0's tiles are fetched into the same registers: the
+    // 221 KB of e traffic per workgroup trickle through the texture-address path under the layer's MFMAs instead of standing
+    // between the two halves of the layer (and in front of the weight stream of the second half).
+    float* erow = a.e + i * (2 * kE) + 4 * q4;
+    auto swap_tiles = [&](int m) {
 #pragma unroll
-    for (int t = 0; t < kTE; ++t) acc[t] = *reinterpret_cast<const f32x4*>(a.e + i * (2 * kE) + 16 * t + 4 * q4);
+        for (int t = 2 * m; t < 2 * m + 2; ++t) {
+            // unconditional: a lane past the end of the rays / steps works on a clamped duplicate of a live sample and writes that
+            // sample's own values again — and the chunk barrier counts on exactly four memory instructions per call
+            *reinterpret_cast<float4*>(erow + kE + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+            acc[t] = *reinterpret_cast<const f32x4*>(erow + 16 * t);
+        }
+    };
+    chained_layer<kTE, false, ABL, 4>(k1, acc, p, a.blob, lds, g, lane, wave, swap_tiles);
+    mark(7);
+    if constexpr (ABL == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mark(9); }
     chained_layer<kTE, false, ABL>(k1, acc, p, a.blob, lds, g, lane, wave);
+    mark(8);
     scale_acc<kTD>(k1, lsc[kLayerK1] * pinv);
     f32x4 key[kTD];
     pow2_scale(fmaxf(sample_max<kTD, true>(k1), 1e-30f), p, pinv);
@@ -317,6 +338,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     chained_layer<kTD, true, ABL>(key, k1, p, a.blob, lds, g, lane, wave);
     scale_acc<kTD>(key, lsc[kLayerK2] * pinv);
 
+    mark(5);
     // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ---------------------------------------------------
     half8 ghi, glo;                                                    // B operand of the layer fed by g (k = 16: folded bias)
     {
@@ -355,6 +377,13 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
         store_rows<kTD>(qv, a.qry + i * kD, q4);
         if (q4 == 0) a.logit[i] = dot / 16.0f;
     }
+    mark(6);
+    if constexpr (ABL == 4) {
+        if (tid == 0) {
+            long long* out = reinterpret_cast<long long*>(a.pixel_val) + (long)blk * 16;
+            for (int k = 0; k < 10; ++k) out[k] = stamp[k];
+        }
+    }
 }
 
 
@@ -384,6 +413,7 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 5: kern = fused_kernel<5>; break;   case 6: kern = fused_kernel<6>; break;   case 7: kern = fused_kernel<7>; break;
         case 8: kern = fused_kernel<8>; break;   case 9: kern = fused_kernel<9>; break;   case 10: kern = fused_kernel<10>; break;
+        case 4: kern = fused_kernel<4>; break;
         default: break;
     }
 #else

@@ -66,6 +66,7 @@ __device__ __forceinline__ void stream_sync() {
     if constexpr (ABL == 3 || ABL >= 5) return;
     if constexpr (KEEP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
@@ -140,10 +141,13 @@ __device__ __forceinline__ void store_rows(const f32x4 (&acc)[NT], float* row, i
 }
 
 // one chained layer with 128 outputs over NSRC source tiles (two per K step), weight chunks of two K steps; the source values
-// are multiplied by the power of two p on their way into the fp16 split
-template <int NSRC, bool RELU, int ABL>
+// are multiplied by the power of two p on their way into the fp16 split.  `after(m)` runs once K step m has been issued (its two
+// source tiles are consumed by then); HOOK_OPS = the number of vector memory instructions it issues per call (they are younger
+// than the chunk's DMA pieces and may stay in flight across the chunk barrier).
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <int NSRC, bool RELU, int ABL, int HOOK_OPS = 0, class Hook = NoHook>
 __device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&src)[NSRC], float p, const float* __restrict__ blob,
-                                              float* lds, int& g, int lane, int wave) {
+                                              float* lds, int& g, int lane, int wave, Hook after = Hook()) {
     constexpr int kSteps = NSRC / 2;
 #pragma unroll
     for (int m0 = 0; m0 < kSteps; m0 += 2) {
@@ -169,12 +173,15 @@ __device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&s
                     if (kl * 4 + q < kPieces) stream_issue_piece<ABL>(nx, kl * 4 + q, lane, wave);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // a single-step chunk has only 4 slots: issue the remaining pieces of its successor before the hook's memory operations
+                if (kl + 1 == nks) {
+#pragma unroll
+                    for (int p_ = nks * 4; p_ < kPieces; ++p_) stream_issue_piece<ABL>(nx, p_, lane, wave);
+                }
+                after(m);
             }
         }
-        // a single-step chunk has only 4 slots: issue the remaining pieces of its successor here
-#pragma unroll
-        for (int p_ = nks * 4; p_ < kPieces; ++p_) stream_issue_piece<ABL>(nx, p_, lane, wave);
-        stream_sync<ABL>();
+        if (nks == 2) stream_sync<ABL, 2 * HOOK_OPS>(); else stream_sync<ABL, HOOK_OPS>();
         ++g;
     }
 }
