@@ -14,6 +14,13 @@ extern "C" size_t car_fused_blob_floats(void);
 extern "C" size_t car_fused_bias_floats(void);
 extern "C" size_t car_round2_packed_floats(void);
 extern "C" size_t car_round2_bias_floats(void);
+extern "C" size_t car_chain_packed_floats(int K, int N);
+extern "C" int car_chain_pack(const float* W, int ldw, const float* W2, int K, int N, float* packed, void* stream);
+extern "C" int car_ray_mid(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* ebar, int ld_ebar,
+                           float* z1, float* uh, long M, void* stream);
+extern "C" int car_ray_tail(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* ebar, int ld_ebar,
+                            const float* phi_x, int ld_phi, const float* z1, const float* rays, int b, int V, int R, float* rgb, float* valid,
+                            void* stream);
 
 namespace {
 
@@ -124,26 +131,12 @@ __global__ void absmax_kernel(const float* __restrict__ x, long n4, unsigned* __
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
-// dst[r, 0:D) = scale * src[r, 0:D)   (z_local term of models.py:561-565 before the value projection is accumulated onto it)
-__global__ void scale_rows_kernel(const float* __restrict__ src, int D, float scale, float* __restrict__ dst, int ld, long rows) {
-    const long total = rows * D;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
-        dst[(idx / D) * ld + idx % D] = src[idx] * scale;
-}
-// z[r, v*D : (v+1)*D) = z[r, 0:D) for v = 1..V-1   (per-view replication, models.py:541, 565, 605-606)
-__global__ void replicate_views_kernel(float* __restrict__ z, int D, int V, long rows) {
-    const long total = rows * D * (V - 1);
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long r = idx / (D * (V - 1));
-        const int c = (int)(idx % (D * (V - 1)));
-        z[r * D * V + D + c] = z[r * D * V + c % D];
-    }
-}
-
 // ---- plan layout ---------------------------------------------------------------------------------------------------
 struct Plan {
-    size_t steps, blob, fbias, wpt, r2w, r2b, proj[CAR_MAX_LEVELS], latent_value, encode_latent, qre_h, lin_in, lin_out,
-        lin_z[kBlocks], fc0[kBlocks], fc1[kBlocks], total;         // offsets in floats
+    // offsets in floats.  latent_value, lin_in: car_linear_pack layout (inputs read from memory, bias folded); the *_c entries:
+    // car_chain_pack layout (inputs are the previous layer's accumulators, car_raychain.hip); mid_bias / tail_bias: their biases
+    size_t steps, blob, fbias, wpt, r2w, r2b, proj[CAR_MAX_LEVELS], latent_value, lin_in, enc_c, qreh_c, lz_c[kBlocks], fc0_c[kBlocks],
+        fc1_c[kBlocks], lout_c, mid_bias, tail_bias, total;
 };
 Plan plan_layout(const car_dims& d) {
     Plan p;
@@ -157,15 +150,17 @@ Plan plan_layout(const car_dims& d) {
     p.r2b = take(car_round2_bias_floats());
     for (int l = 0; l < CAR_MAX_LEVELS; ++l) p.proj[l] = l < d.n_levels ? take(car_linear_packed_floats(d.level_c[l], kC)) : 0;
     p.latent_value = take(car_linear_packed_floats(kC, kE));
-    p.encode_latent = take(car_linear_packed_floats(kE, kD));
-    p.qre_h = take(car_linear_packed_floats(kD, kD));
     p.lin_in = take(car_linear_packed_floats(kPhiIn, kD));
-    p.lin_out = take(car_linear_packed_floats(kD, 3));
+    p.enc_c = take(car_chain_packed_floats(kE, kD));
+    p.qreh_c = take(car_chain_packed_floats(kD, kD));
     for (int i = 0; i < kBlocks; ++i) {
-        p.lin_z[i] = take(car_linear_packed_floats(2 * kE, kD));
-        p.fc0[i] = take(car_linear_packed_floats(kD, kD));
-        p.fc1[i] = take(car_linear_packed_floats(kD, kD));
+        p.lz_c[i] = take(car_chain_packed_floats(kE, kD));
+        p.fc0_c[i] = take(car_chain_packed_floats(kD, kD));
+        p.fc1_c[i] = take(car_chain_packed_floats(kD, kD));
     }
+    p.lout_c = take(car_chain_packed_floats(kD, 3));
+    p.mid_bias = take(kD);
+    p.tail_bias = take(3 * kBlocks * kD + 32);
     p.total = o;
     return p;
 }
@@ -187,8 +182,7 @@ int check_dims(const car_dims* d, const char* who) {
 
 // ---- workspace layout ----------------------------------------------------------------------------------------------
 struct Work {
-    size_t rays, phi_x, e, q, g, logit, logit2, pt, pixel_val, coords, at_wt, at_wt2, amax, depth, ebar, z1, hb, uh, zrep, x, net,
-        out3, valid, total;                                        // offsets in floats
+    size_t rays, phi_x, e, q, g, logit, logit2, pt, pixel_val, coords, at_wt, at_wt2, amax, depth, ebar, z1, uh, valid, total;                                        // offsets in floats
 };
 Work work_layout(const car_dims& d) {
     Work w;
@@ -211,12 +205,7 @@ Work work_layout(const car_dims& d) {
     w.depth = take(BR);
     w.ebar = take(BR * kC);
     w.z1 = take(BR * kE);
-    w.hb = take(BR * kD);
     w.uh = take(BR * kD);
-    w.zrep = take(BR * 2 * kE);
-    w.x = take(BR * kD);
-    w.net = take(BR * kD);
-    w.out3 = take(BR * 4);
     w.valid = take(BR);
     w.total = o;
     return w;
@@ -311,7 +300,7 @@ extern "C" int car_workspace_find(const car_dims* dims, const char* name, size_t
     const struct { const char* name; size_t off, cnt; } tab[] = {
         {"rays", w.rays, n * dims->R * CAR_RAY_FLOATS}, {"e", w.e, S * kC}, {"qry", w.q, S * kD}, {"g", w.g, S * CAR_G_DIM},
         {"logit", w.logit, S}, {"logit2", w.logit2, S}, {"pt", w.pt, S * 3}, {"at_wt2", w.at_wt2, S}, {"ebar", w.ebar, BR * kC},
-        {"z1", w.z1, BR * kE}, {"uh", w.uh, BR * kD}, {"zrep", w.zrep, BR * 2 * kE}, {"out3", w.out3, BR * 4}};
+        {"z1", w.z1, BR * kE}, {"uh", w.uh, BR * kD}};
     for (const auto& t : tab)
         if (strcmp(t.name, name) == 0) { *offset_floats = t.off; *n_floats = t.cnt; return CAR_OK; }
     car_set_error("car_workspace_find: unknown tensor '%s'", name);
@@ -416,15 +405,24 @@ extern "C" int car_plan_build(const car_dims* dims, const car_weights* w, void* 
         coff += dims->level_c[l];
     }
     CAR_TRY(car_linear_pack(w->latent_value_w, kC, w->latent_value_b, kC, kE, base + p.latent_value, stream));
-    CAR_TRY(car_linear_pack(w->encode_latent_w, kE, w->encode_latent_b, kE, kD, base + p.encode_latent, stream));
-    CAR_TRY(car_linear_pack(w->query_repeat_embed_w, kD + 16, nullptr, kD, kD, base + p.qre_h, stream));
     CAR_TRY(car_linear_pack(w->phi_lin_in_w, kPhiIn, w->phi_lin_in_b, kPhiIn, kD, base + p.lin_in, stream));
-    CAR_TRY(car_linear_pack(w->phi_lin_out_w, kD, w->phi_lin_out_b, kD, 3, base + p.lin_out, stream));
+    // the per-ray chains (car_raychain.hip): layers fed from the previous layer's accumulators
+    CAR_TRY(car_chain_pack(w->encode_latent_w, kE, nullptr, kE, kD, base + p.enc_c, stream));
+    CAR_TRY(car_chain_pack(w->query_repeat_embed_w, kD + 16, nullptr, kD, kD, base + p.qreh_c, stream));
     for (int i = 0; i < kBlocks; ++i) {
-        CAR_TRY(car_linear_pack(w->phi_lin_z_w[i], 2 * kE, w->phi_lin_z_b[i], 2 * kE, kD, base + p.lin_z[i], stream));
-        CAR_TRY(car_linear_pack(w->phi_fc_0_w[i], kD, w->phi_fc_0_b[i], kD, kD, base + p.fc0[i], stream));
-        CAR_TRY(car_linear_pack(w->phi_fc_1_w[i], kD, w->phi_fc_1_b[i], kD, kD, base + p.fc1[i], stream));
+        CAR_TRY(car_chain_pack(w->phi_lin_z_w[i], 2 * kE, w->phi_lin_z_w[i] + kE, kE, kD, base + p.lz_c[i], stream));      // [z, z]: halves added
+        CAR_TRY(car_chain_pack(w->phi_fc_0_w[i], kD, nullptr, kD, kD, base + p.fc0_c[i], stream));
+        CAR_TRY(car_chain_pack(w->phi_fc_1_w[i], kD, nullptr, kD, kD, base + p.fc1_c[i], stream));
     }
+    CAR_TRY(car_chain_pack(w->phi_lin_out_w, kD, nullptr, kD, 3, base + p.lout_c, stream));
+    if (hipMemsetAsync(base + p.tail_bias, 0, sizeof(float) * (3 * kBlocks * kD + 32), st) != hipSuccess) { car_set_error("car_plan_build: memset failed"); return CAR_E_LAUNCH; }
+    auto d2d = [&](float* dst, const float* src, int n) { return hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, st) == hipSuccess; };
+    bool ok = d2d(base + p.mid_bias, w->encode_latent_b, kD);
+    for (int i = 0; i < kBlocks; ++i)
+        ok = ok && d2d(base + p.tail_bias + (3 * i + 0) * kD, w->phi_lin_z_b[i], kD) && d2d(base + p.tail_bias + (3 * i + 1) * kD, w->phi_fc_0_b[i], kD) &&
+             d2d(base + p.tail_bias + (3 * i + 2) * kD, w->phi_fc_1_b[i], kD);
+    ok = ok && d2d(base + p.tail_bias + 3 * kBlocks * kD, w->phi_lin_out_b, 3);
+    if (!ok) { car_set_error("car_plan_build: bias copy failed"); return CAR_E_LAUNCH; }
     return CAR_OK;
 }
 
@@ -488,13 +486,19 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
         CAR_TRY(car_attend(ws + w.logit, nullptr, kD, ws + w.e, kC, b, V, R, P, nullptr, 0.0f, at_wt, ws + w.ebar, kC, 1, ws + w.pt, in->poses,
                            depth, amax, stream));
     }
-    float* zrep = ws + w.zrep;
+    // weight-chunk tables of the two per-ray chains (car_raychain.hip): float offset inside the plan and tile count of every K = 32
+    // chunk, in the order the kernels consume them
+    unsigned offs[96];
+    int nts[96];
+    int nch = 0;
+    auto chunks = [&](size_t at, int n, int nt) { for (int c = 0; c < n; ++c) { offs[nch] = (unsigned)(at + (size_t)c * nt * 1024); nts[nch++] = nt; } };
+    CAR_REQUIRE(p.total < (1ull << 32), "car_render_forward: plan too large");
     if (d.repeat_attention) {
         {   // a15, per ray: z1 = Wv ebar + bv; uh = Wr1[:, :128] encode_latent(z1)
             Stage stage("ray_layers_1", st);
-            CAR_TRY(car_linear(ws + w.ebar, kC, pl + p.latent_value, kC, kE, ws + w.z1, kE, BR, 0, stream));
-            CAR_TRY(car_linear(ws + w.z1, kE, pl + p.encode_latent, kE, kD, ws + w.hb, kD, BR, 0, stream));
-            CAR_TRY(car_linear(ws + w.hb, kD, pl + p.qre_h, kD, kD, ws + w.uh, kD, BR, 0, stream));
+            nch = 0;
+            chunks(p.latent_value, 19, 9); chunks(p.enc_c, 9, 4); chunks(p.qreh_c, 4, 4);
+            CAR_TRY(car_ray_mid(pl, offs, nts, nch, pl + p.mid_bias, ws + w.ebar, kC, ws + w.z1, ws + w.uh, BR, stream));
         }
         {   // a15, per sample: second-round query and logits
             Stage stage("round2_logits", st);
@@ -505,28 +509,18 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
             CAR_TRY(car_attend(ws + w.logit2, nullptr, kD, ws + w.e, kC, b, V, R, P, nullptr, 0.0f, ws + w.at_wt2, ws + w.ebar, kC, 1, nullptr,
                                nullptr, nullptr, nullptr, stream));
         }
+    } else if (hipMemsetAsync(ws + w.z1, 0, sizeof(float) * BR * kE, st) != hipSuccess) {       // no second round: z = Wv ebar1 + bv
+        car_set_error("car_render_forward: memset failed");
+        return CAR_E_LAUNCH;
     }
-    {   // z = (Wv ebar2 + bv) + V z1 (models.py:561-565), per-view replication, light-field decoder (resnet_block_fc.py:132-168), a18
+    {   // z = (Wv ebar + bv) + V z1 (models.py:561-565), light-field decoder (resnet_block_fc.py:132-168), valid mask / white background
         Stage stage("ray_layers_2", st);
-        if (d.repeat_attention) {
-            (void)hipGetLastError();
-            hipLaunchKernelGGL(scale_rows_kernel, dim3(1024), dim3(256), 0, st, ws + w.z1, kE, (float)V, zrep, V * kE, BR);
-            CAR_CHECK_LAUNCH("car_render_forward (scale)");
-            CAR_TRY(car_linear(ws + w.ebar, kC, pl + p.latent_value, kC, kE, zrep, V * kE, BR, CAR_LIN_ACCUM, stream));
-        } else {
-            CAR_TRY(car_linear(ws + w.ebar, kC, pl + p.latent_value, kC, kE, zrep, V * kE, BR, 0, stream));
-        }
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(replicate_views_kernel, dim3(1024), dim3(256), 0, st, zrep, kE, V, BR);
-        CAR_CHECK_LAUNCH("car_render_forward (replicate)");
-        CAR_TRY(car_linear(ws + w.phi_x, kPhiLd, pl + p.lin_in, kPhiIn, kD, ws + w.x, kD, BR, 0, stream));
-        for (int i = 0; i < kBlocks; ++i) {
-            CAR_TRY(car_linear(zrep, V * kE, pl + p.lin_z[i], V * kE, kD, ws + w.x, kD, BR, CAR_LIN_ACCUM, stream));
-            CAR_TRY(car_linear(ws + w.x, kD, pl + p.fc0[i], kD, kD, ws + w.net, kD, BR, CAR_LIN_RELU_IN, stream));
-            CAR_TRY(car_linear(ws + w.net, kD, pl + p.fc1[i], kD, kD, ws + w.x, kD, BR, CAR_LIN_RELU_IN | CAR_LIN_ACCUM, stream));
-        }
-        CAR_TRY(car_linear(ws + w.x, kD, pl + p.lin_out, kD, 3, ws + w.out3, 4, BR, CAR_LIN_RELU_IN, stream));
-        CAR_TRY(car_finalize(ws + w.rays, ws + w.out3, 4, b, V, R, out->rgb, valid, stream));
+        nch = 0;
+        chunks(p.latent_value, 19, 9); chunks(p.lin_in, 1, 4);
+        for (int i = 0; i < kBlocks; ++i) { chunks(p.lz_c[i], 9, 4); chunks(p.fc0_c[i], 4, 4); chunks(p.fc1_c[i], 4, 4); }
+        chunks(p.lout_c, 4, 1);
+        CAR_TRY(car_ray_tail(pl, offs, nts, nch, pl + p.tail_bias, ws + w.ebar, kC, ws + w.phi_x, kPhiLd, ws + w.z1, ws + w.rays, b, V, R, out->rgb, valid,
+                             stream));
     }
     return CAR_OK;
 }

@@ -384,7 +384,7 @@ class RenderEngine:
                 return work[off.value:off.value + cnt.value].view(*shape).clone()
             res["stages"] = {"rays": ws("rays", n, R, 12), "pt": ws("pt", n, R, P, 3), "local_coords": None,
                              "g": ws("g", n, R, P, 16), "interp_val": ws("e", n, R, P, 576),
-                             "z_final": ws("zrep", b * R, 576)[:, :288].reshape(b, R, 288),
+                             "z1": ws("z1", b, R, 288),
                              "at_wt2": ws("at_wt2", n, R, P) if m.repeat_attention else None, "poses": poses}
         return res
 

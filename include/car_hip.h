@@ -168,6 +168,26 @@ int car_round2_logits(const float* g, const float* uh, const float* qry, const f
  * the z_embed half of query_repeat_embed is constant along the samples of a ray). r [b*V,R,P,C], u [b,R,C]. */
 int car_add_ray_bias_relu(float* r, const float* u, int b, int V, int R, int P, int C, void* stream);
 
+/* ---- the per-ray layers as two kernels (csrc/car_raychain.hip): a layer's outputs stay in the MFMA accumulators of the wave that owns
+ * the 32 rays and are the next layer's B operands (exact fp32, v_mfma_f32_32x32x2_f32).
+ *   car_chain_pack : weights of a layer fed that way, K order of the accumulator layout, no bias column; W2 (optional, same shape and
+ *                    row stride) is added element-wise.  car_chain_packed_floats(K, N) floats.
+ *   car_ray_mid    : z1 = latent_value(ebar) [M,288];  uh = query_repeat_embed[:, :128] encode_latent(z1) [M,128]   (models.py:487, 548, 552)
+ *   car_ray_tail   : z = latent_value(ebar) + V z1;  rgb = phi([z, z], coords) valid + (1 - valid), valid [b R]   (models.py:561-565, 597-617;
+ *                    resnet_block_fc.py:132-168)
+ * `arena` + host arrays offs / nts (n_chunks entries): where every K = 32 weight chunk lives (float offset from `arena`) and how many
+ * 32-output tiles it has, in consumption order — mid: latent_value (car_linear_pack layout, 19 x 9), encode_latent (9 x 4),
+ * query_repeat_embed[:, :128] (4 x 4); tail: latent_value, lin_in (1 x 4), 3 x {lin_z halves added (9 x 4), fc_0 (4 x 4), fc_1 (4 x 4)},
+ * lin_out (4 x 1).  bias — mid: encode_latent.bias; tail: 3 x {lin_z, fc_0, fc_1 biases}, lin_out.bias padded to 32.
+ * car_plan_build / car_render_forward set all of this up. */
+size_t car_chain_packed_floats(int K, int N);
+int car_chain_pack(const float* W, int ldw, const float* W2, int K, int N, float* packed, void* stream);
+int car_ray_mid(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* ebar, int ld_ebar,
+                float* z1, float* uh, long M, void* stream);
+int car_ray_tail(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* ebar, int ld_ebar,
+                 const float* phi_x, int ld_phi, const float* z1, const float* rays, int b, int V, int R, float* rgb, float* valid,
+                 void* stream);
+
 /* ---- a18: valid mask and white background (models.py:614-617).
  * rays [b*V,R,CAR_RAY_FLOATS]; rgb_in [b,R,ld_in] (first 3 columns used) -> rgb [b,R,3], valid [b,R]. */
 int car_finalize(const float* rays, const float* rgb_in, int ld_in, int b, int V, int R, float* rgb, float* valid,
@@ -247,7 +267,7 @@ size_t car_workspace_bytes(const car_dims* dims);
 int car_render_forward(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
                        void* workspace, size_t workspace_bytes, void* stream);
 /* Where a named intermediate lives inside the workspace after car_render_forward (tests, debugging, profiling): one of
- * "rays" "e" "qry" "g" "logit" "logit2" "pt" "at_wt2" "ebar" "z1" "uh" "zrep" "out3".  Returns 0 and the float offset / count. */
+ * "rays" "e" "qry" "g" "logit" "logit2" "pt" "at_wt2" "ebar" "z1" "uh".  Returns 0 and the float offset / count. */
 int car_workspace_find(const car_dims* dims, const char* name, size_t* offset_floats, size_t* n_floats);
 
 /* ---- stage timing (the reference's only hooks are record_function labels, resnet_block_fc.py:54, 139, and one time.time() pair,

@@ -550,9 +550,12 @@ def test_forward_without_z_runs_get_z_on_the_device():
     P, R = 32, 96
     m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P).eval()
     sd = EC.seeded_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=11)
-    # the untrained encoder's pyramid has magnitudes of ~1e2; bring the first point-MLP layer's view of it back to O(1) so that the
-    # render is as well conditioned as with a trained model
+    # the untrained encoder's pyramid has magnitudes of ~1e2 and the seeded value path gives colours of ~1e2 (fp32 summation noise
+    # of 1e-4 x |rgb| on both sides); bring the first point-MLP layer's view of the pyramid and the value layer back to O(1) so that
+    # the render is as well conditioned as with a trained model
     sd["query_encode_latent.weight"][:, :576] /= 100.0
+    sd["latent_value.weight"] /= 30.0
+    sd["latent_value.bias"] /= 30.0
     m.load_state_dict(sd, strict=True)
     inp = EC.context_pair()
     inp["query"]["uv"] = C.select_rays(EC.H, R)[None, None].contiguous()

@@ -39,7 +39,7 @@ def main():
             rows.append(("at_wt2", hs["at_wt2"], st["at_wt2"]))
         b, V = c["b"], c["n_view"]
         zf = st["z_final"]
-        rows += [("z_final", hs["z_final"], zf.reshape(b, V, *zf.shape[1:])[:, 0]),
+        rows += [("z_final", hs.get("z_final"), zf.reshape(b, V, *zf.shape[1:])[:, 0]),
                  ("depth_ray", out["depth_ray"], ora["depth_ray"]), ("rgb", out["rgb"], ora["rgb"]),
                  ("rgb vs REF", out["rgb"], fx["out_rgb"]), ("depth vs REF", out["depth_ray"], fx["out_depth_ray"]),
                  ("at_wt vs REF", out["at_wt"], fx["out_at_wt"])]
