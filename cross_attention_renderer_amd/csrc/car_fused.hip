@@ -1,6 +1,8 @@
 // car_fused.hip — the fused per-sample kernel (SURVEY.md §8a rows a6-a13 + the logits of a14; reference models.py:261-344,
 // 487-532).  Per sample, without touching HBM in between: geometry (car_geom.h, fp64 Pluecker intersection) -> per 32-channel
-// chunk a 12-tap gather of the per-texel projected maps (the first point-MLP layer applied once per texel) ->
+// chunk an 8-tap gather of the per-texel projected maps (the first point-MLP layer applied once per texel): four taps
+// of the finest pyramid level and four taps of the merged lattice, on which the coarser levels are summed once per stereo pair
+// (car_geom.h car_lattice_taps) ->
 // e_s = W2 relu(h_s) + b2 for both source views -> k1 = Wk1 [e_0 ; e_1] -> key -> qry -> logit = <key, qry>/16.  Every layer
 // runs on the f16 matrix pipe as three v_mfma_f32_16x16x32_f16 products of fp16 hi/lo operand halves (car_fused_mma.h); a
 // layer's accumulators are the next layer's B operands.
@@ -8,7 +10,7 @@
 // Three waves per SIMD (<= 168 registers per wave), which needs
 //   * the key layer's accumulators (k1, 32 registers) out of the e path: k1 = Wk1 [e_0 ; e_1] is computed after both
 //     sources, chained from the accumulators for e_1 and from e_0 read back from the output tensor it was just stored to (L2);
-//   * half-size tap batches (one level of one row group: 4 float4) in two alternating buffers;
+//   * half-size tap batches (one map of one row group: 4 float4) in two alternating buffers;
 //   * no read-ahead of the weight operands (the third wave hides the LDS latency instead).
 // One workgroup = 12 waves = 192 samples = 48 consecutive rays x 4 consecutive steps (wave = (16-ray bundle, step)); the weight
 // stream is shared by 192 samples.  The tap tables are stored compactly (base offset + two flags, four weights).
@@ -27,9 +29,9 @@ constexpr int kPieces = 3;                         // LDS-DMA pieces per chunk: 
 #include "car_fused_mma.h"
 
 constexpr int kLdsStage = kLdsW + 2 * kChunkTiles * kTile;      // [12][16][36]           h tiles, wave private     27 KB
-constexpr int kLdsTapB = kLdsStage + kGroup * kStageLd;         // [192][2][3] uint       byte offset of the nw texel | 1: x1 != x0 | 2: y1 != y0   4.5 KB
-constexpr int kLdsTapW = kLdsTapB + kGroup * 6;                 // [192][2][3][4]         tap weights (nw, ne, sw, se)   18 KB
-constexpr int kLdsPe = kLdsTapW + kGroup * 24;                  // [192][2][4]            tanh(pt_s/5)                6 KB
+constexpr int kLdsTapB = kLdsStage + kGroup * kStageLd;         // [192][2][2] uint       byte offset of the nw node / texel | 1: x1 != x0 | 2: y1 != y0   3 KB
+constexpr int kLdsTapW = kLdsTapB + kGroup * 4;                 // [192][2][2][4]         tap weights (nw, ne, sw, se)   12 KB
+constexpr int kLdsPe = kLdsTapW + kGroup * 16;                  // [192][2][4]            tanh(pt_s/5)                6 KB
 constexpr int kLdsWpt = kLdsPe + kGroup * 8;                    // [576][4]               (W1[:,C:C+3], b1)           9 KB
 constexpr int kLdsBias = kLdsWpt + kC * 4;                      // [672]
 constexpr int kLdsG = kLdsBias + kBiasFloats;                   // [192][16]              geometric query g per sample 12 KB
@@ -41,9 +43,12 @@ struct FusedArgs {
     const CarPose* poses;
     const CarRay* rays;
     const float* steps;
-    const float* gmap[3];
-    int gh[3], gw[3];
-    const float* gmeta;        // [3] max |G_l| per level (car_project_maps)
+    const float* gmap[2];      // 0: merged lattice of the coarser levels [b*V][2 padding modes][lh][lw][kC]; 1: the finest level, projected,
+                               // [b*V][fh][fw][kC] (car_project_maps)
+    int lh, lw, pad;
+    float sx, sy;              // lattice coordinate u = (x + 1) * sx - 1: width / height of the finest of the merged levels
+    int fh, fw;
+    const float* gmeta;        // [2] max |lattice|, max |finest level| (car_project_maps)
     const float* wpt;
     const float* blob;
     const float* bias;
@@ -79,7 +84,7 @@ __device__ __forceinline__ int chunk_tiles(int g) {
 // ABL > 0: timing-only ablations (wrong results), instantiated only in the -DCAR_ABLATION development build (tools/):
 // 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers, 5 the gather alone (no e-path MFMAs, no weight DMA, no
 // barriers); probes of the texture-address path on top of 5: 6 odd rows masked off (whole quads of lanes inactive), 7 odd channel
-// quads masked off (half of every quad of lanes inactive), 9 no level-0 taps, 10 level-2 taps only in the first two chunks;
+// quads masked off (half of every quad of lanes inactive);
 // 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val)
 template <int ABL>
 __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
@@ -133,17 +138,22 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
             int mode, m;
             if (sv == v) { gx = smp.grid[0]; gy = smp.grid[1]; mode = 0; m = n; }
             else { gx = sv == 0 ? smp.grid_in[0][0] : smp.grid_in[1][0]; gy = sv == 0 ? smp.grid_in[0][1] : smp.grid_in[1][1]; mode = 1; m = sc * V + sv; }
-            unsigned* tb = reinterpret_cast<unsigned*>(lds + kLdsTapB) + (sg * 2 + sv) * 3;
-            float* tw = lds + kLdsTapW + (sg * 2 + sv) * 12;
-#pragma unroll
-            for (int l = 0; l < 3; ++l) {
+            unsigned* tb = reinterpret_cast<unsigned*>(lds + kLdsTapB) + (sg * 2 + sv) * 2;
+            float* tw = lds + kLdsTapW + (sg * 2 + sv) * 8;
+            {   // the four taps are nw + {0, 1 node} + {0, 1 row}; a node's row is kC*4 = 2304 B, a multiple of 256, so the two flags ride
+                // in the low bits of the nw node's byte offset
+                int node, flags;
+                float w[4];
+                car_lattice_taps(gx, gy, a.lw, a.lh, a.pad, a.sx, a.sy, &node, &flags, w);
+                tb[0] = (unsigned)((m * 2 + mode) * a.lh * a.lw + node) * (unsigned)(kC * 4) | (unsigned)flags;
+                *reinterpret_cast<float4*>(tw) = make_float4(w[0], w[1], w[2], w[3]);
+            }
+            {   // the finest level: (x0|x1, y0|y1) after clamping, weight 0 for a tap outside the map
                 int idx[4];
                 float w[4];
-                car_bilinear_taps(gx, gy, a.gw[l], a.gh[l], mode, idx, w);
-                // the four taps are (x0|x1, y0|y1) after clamping: nw + {0, 1 texel} + {0, 1 row}; a texel row is kC*4 = 2304 B, a multiple
-                // of 256, so the two flags ride in the low bits of the nw texel's byte offset
-                tb[l] = (unsigned)(m * a.gh[l] * a.gw[l] + idx[0]) * (unsigned)(kC * 4) | (idx[1] != idx[0] ? 1u : 0u) | (idx[2] != idx[0] ? 2u : 0u);
-                *reinterpret_cast<float4*>(tw + 4 * l) = make_float4(w[0], w[1], w[2], w[3]);
+                car_bilinear_taps(gx, gy, a.fw, a.fh, mode, idx, w);
+                tb[1] = (unsigned)(m * a.fh * a.fw + idx[0]) * (unsigned)(kC * 4) | (idx[1] != idx[0] ? 1u : 0u) | (idx[2] != idx[0] ? 2u : 0u);
+                *reinterpret_cast<float4*>(tw + 4) = make_float4(w[0], w[1], w[2], w[3]);
             }
             const float px = sv == 0 ? smp.pt_in[0][0] : smp.pt_in[1][0], py = sv == 0 ? smp.pt_in[0][1] : smp.pt_in[1][1],
                         pz = sv == 0 ? smp.pt_in[0][2] : smp.pt_in[1][2];
@@ -165,25 +175,24 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     mark(1);
 
     // ---- gather machinery: lane owns rows rr = (lane>>3) + 8*it (it = 0, 1) and channel quad qd = lane & 7 of a chunk.
-    //      A batch = the 4 tap loads of one row group `it` at one level; two batches (bufA: it 0, bufB: it 1) are in flight. ----
+    //      A batch = the 4 tap loads of one row group `it` from one map (l = 1 the finest level, 0 the lattice); two batches (bufA: it 0,
+    //      bufB: it 1) are in flight. ----
     const int qd = lane & 7, r0 = lane >> 3;
     float* stage = lds + kLdsStage + wave * kRows * kStageLd;
     float4 hacc[2];
     f32x4 bufA[4], bufB[4];
     const unsigned qd16 = 16u * qd;
-    const unsigned row_step[3] = {(unsigned)a.gw[0] * (kC * 4), (unsigned)a.gw[1] * (kC * 4), (unsigned)a.gw[2] * (kC * 4)};
+    const unsigned row_step[2] = {(unsigned)a.lw * (kC * 4), (unsigned)a.fw * (kC * 4)};
 
     auto issue_row = [&](f32x4 (&tap)[4], int sv, int c, int l, int it) {
         if constexpr (ABL == 1 || ABL == 2 || ABL == 3) return;
-        if constexpr (ABL == 9) { if (l == 0) return; }
-        if constexpr (ABL == 10) { if (l == 2 && c >= 2) return; }
         if constexpr (ABL == 6) { if (r0 & 1) return; }
         if constexpr (ABL == 7) { if (qd & 1) return; }
         const char* base = reinterpret_cast<const char*>(a.gmap[l] + 32 * c);
         // ABL 8: lane = (sample s, k group q4) as the MFMA's B operand wants it, the two row groups become the two 16-byte pieces
         const int row = ABL == 8 ? s : r0 + 8 * it;
         const unsigned col = ABL == 8 ? 16u * q4 + 64u * it : qd16;
-        const unsigned tbv = reinterpret_cast<const unsigned*>(lds + kLdsTapB)[((wave * kRows + row) * 2 + sv) * 3 + l];
+        const unsigned tbv = reinterpret_cast<const unsigned*>(lds + kLdsTapB)[((wave * kRows + row) * 2 + sv) * 2 + l];
         const unsigned o00 = (tbv & ~3u) + col, dx = (tbv & 1u) ? (unsigned)(kC * 4) : 0u, dy = (tbv & 2u) ? row_step[l] : 0u;
         tap[0] = *reinterpret_cast<const f32x4*>(base + o00);
         tap[1] = *reinterpret_cast<const f32x4*>(base + (o00 + dx));
@@ -192,7 +201,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     };
     auto blend_row = [&](const f32x4 (&tap)[4], int sv, int l, int it) {
         if constexpr (ABL == 2 || ABL == 3) return;
-        const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 12 + 4 * l);
+        const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 8 + 4 * l);
         const float ww[4] = {w.x, w.y, w.z, w.w};
         f32x2 lo2 = {hacc[it].x, hacc[it].y}, hi2 = {hacc[it].z, hacc[it].w};          // v_pk_fma_f32: two FMAs per instruction
 #pragma unroll
@@ -222,14 +231,14 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
             make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
     };
     // Scales of the split-fp16 arithmetic (car_fused_mma.h).  Packed weights carry 2^shift per layer (dW.. = 2^-shift, from the
-    // bias table).  h is bounded by the per-level maxima of the projected maps plus the point / bias term, because the tap
-    // weights of a level are non-negative and sum to at most one and |tanh| <= 1: one power of two hp for the whole launch.
+    // bias table).  h is bounded by the largest lattice value plus the largest value of the finest level plus the point / bias
+    // term, because a map's tap weights are non-negative and sum to at most one and |tanh| <= 1: one power of two hp per launch.
     const float* lsc = lds + kLdsBias + kBiasScale;
     auto uniform = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };   // keep it in an SGPR
     float hp, e_up, e_down;
     {
         float hinv;
-        pow2_scale(fmaxf(((a.gmeta[0] + a.gmeta[1]) + a.gmeta[2]) + lsc[5], 1e-30f), hp, hinv);
+        pow2_scale(fmaxf((a.gmeta[0] + a.gmeta[1]) + lsc[5], 1e-30f), hp, hinv);
         const float dW2 = lsc[kLayerW2];
         e_up = uniform(hp / dW2); e_down = uniform(dW2 * hinv); hp = uniform(hp);
     }
@@ -245,7 +254,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     for (int it = 0; it < 2; ++it) {
         affine_row(0, 0, it);
 #pragma unroll
-        for (int l = 2; l >= 0; --l) {
+        for (int l = 1; l >= 0; --l) {
             issue_row(bufA, 0, 0, l, it);
             blend_row(bufA, 0, l, it);
         }
@@ -254,8 +263,8 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     stream_sync();                                                     // weight chunk 0 landed
     mark(2);
     constexpr bool kTapsLive = (ABL == 0 || ABL >= 5);
-    issue_row(bufA, 0, 1, 2, 0);                                       // pipeline prologue: level 2 of chunk (0, 1), both row groups
-    issue_row(bufB, 0, 1, 2, 1);
+    issue_row(bufA, 0, 1, 1, 0);                                       // pipeline prologue: the finest level of chunk (0, 1), both row groups
+    issue_row(bufB, 0, 1, 1, 1);
 
     f32x4 acc[kTE];
     float m0 = 0.0f;                                                   // largest |e_0| of this lane's sample
@@ -266,26 +275,24 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
         init_bias<kTE>(acc, lds + kLdsBias + kBiasE, q4, e_up);
 #pragma unroll 1
         for (int c = 0; c < kKS; ++c) {
-            // chunk being gathered: m+1 = (nsv, nc); level 2 of chunk m+2 = (n2sv, n2c) is issued at the end.  Branch-free on purpose:
-            // past the last chunk the gather harmlessly re-reads chunks of source 1.
+            // chunk being gathered: m+1 = (nsv, nc); the finest level of chunk m+2 = (n2sv, n2c) is issued at the end.  Branch-free on
+            // purpose: past the last chunk the gather harmlessly re-reads chunks of source 1.
             const int nsv = (c + 1 < kKS) ? sv : 1;
             const int nc = (c + 1 < kKS) ? c + 1 : 0;
             const int n2sv = (c + 2 < kKS) ? sv : 1;
             const int n2c = (c + 2 < kKS) ? c + 2 : c + 2 - kKS;
             const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
             const NextChunk nx = next_chunk(a.blob, lds, g + 1);
-            // 9 slots of (4 ds_read_b128 + 6 MFMAs of 16 cycles); between them one piece of the gather / DMA issue.  Batches (level, row
-            // group) in the order (2,0) (2,1) (1,0) (1,1) (0,0) (0,1); batch k is blended in slot {1,2,4,5,7,8}[k] and batch k+2 issued
-            // into the buffer it frees; slots 0-2 also carry the DMA pieces, slot 0 the affine start values.
+            // 9 slots of (4 ds_read_b128 + 6 MFMAs of 16 cycles); between them one piece of the gather / DMA issue.  Batches (map, row
+            // group) in the order (1,0) (1,1) (0,0) (0,1); batch k is blended in slot {2,3,6,7}[k] and batch k+2 issued into the buffer
+            // it frees; slots 0-2 also carry the DMA pieces, slot 0 the affine start values.
             auto piece = [&](int qs) {
                 if (qs < kPieces) stream_issue_piece<ABL>(nx, qs, lane, wave);
                 if (qs == 0) { affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); }
-                else if (qs == 1) { blend_row(bufA, nsv, 2, 0); issue_row(bufA, nsv, nc, 1, 0); }
-                else if (qs == 2) { blend_row(bufB, nsv, 2, 1); issue_row(bufB, nsv, nc, 1, 1); }
-                else if (qs == 4) { blend_row(bufA, nsv, 1, 0); issue_row(bufA, nsv, nc, 0, 0); }
-                else if (qs == 5) { blend_row(bufB, nsv, 1, 1); issue_row(bufB, nsv, nc, 0, 1); }
-                else if (qs == 7) { blend_row(bufA, nsv, 0, 0); finish_row(0); issue_row(bufA, n2sv, n2c, 2, 0); }
-                else if (qs == 8) { blend_row(bufB, nsv, 0, 1); finish_row(1); issue_row(bufB, n2sv, n2c, 2, 1); }
+                else if (qs == 2) { blend_row(bufA, nsv, 1, 0); issue_row(bufA, nsv, nc, 0, 0); }
+                else if (qs == 3) { blend_row(bufB, nsv, 1, 1); issue_row(bufB, nsv, nc, 0, 1); }
+                else if (qs == 6) { blend_row(bufA, nsv, 0, 0); finish_row(0); issue_row(bufA, n2sv, n2c, 1, 0); }
+                else if (qs == 7) { blend_row(bufB, nsv, 0, 1); finish_row(1); issue_row(bufB, n2sv, n2c, 1, 1); }
             };
 #pragma unroll
             for (int qs = 0; qs < kTE / 2; ++qs) {
@@ -295,7 +302,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             read_b(bhi, blo);                                          // next chunk's B operand (own LDS tile, in-order LDS)
-            // the 8 tap loads issued in slots 7 and 8 (after the last DMA piece) stay in flight over the barrier
+            // the 8 tap loads issued in slots 6 and 7 stay in flight over the barrier
             stream_sync<ABL, kTapsLive ? 8 : 0>();
             ++g;
         }
@@ -387,21 +394,23 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
 }
 
 
-int launch_fused(int abl, const float* poses, const float* rays, const float* steps, const float* const* gmaps, const int* level_h,
-                 const int* level_w, int n_levels, int C, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,
+int launch_fused(int abl, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w, int lat_pad,
+                 const float* fine, int fine_h, int fine_w, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,
                  int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
-    CAR_REQUIRE(poses && rays && steps && gmaps && level_h && level_w && gmeta && wpt && blob && bias, "car_fused_samples: null input");
+    CAR_REQUIRE(poses && rays && steps && lattice && fine && gmeta && wpt && blob && bias, "car_fused_samples: null input");
     CAR_REQUIRE(e && qry && g && logit && pt && pixel_val, "car_fused_samples: null output");
-    CAR_REQUIRE(n_levels == 3 && C == kC && V == 2, "car_fused_samples: built for 3 pyramid levels, C = %d, V = 2 (got %d, %d, %d)", kC, n_levels, C, V);
+    CAR_REQUIRE(V == 2, "car_fused_samples: built for V = 2 (got %d)", V);
     CAR_REQUIRE(b > 0 && R > 0 && P > 0 && H > 1 && W > 1, "car_fused_samples: bad sizes");
+    CAR_REQUIRE(lat_pad >= 2 && lat_h > 2 * lat_pad + 1 && lat_w > 2 * lat_pad + 1 && ((lat_h - 2 * lat_pad) & 1) && ((lat_w - 2 * lat_pad) & 1),
+                "car_fused_samples: bad lattice %d x %d, pad %d (car_lattice_shape)", lat_h, lat_w, lat_pad);
+    // nodes and texels are addressed by 32-bit byte offsets inside their map; hosts with more scenes render them in groups (engine.py)
+    CAR_REQUIRE(fine_h > 0 && fine_w > 0 && (long)b * V * 2 * lat_h * lat_w * (kC * 4) < 4294967296L && (long)b * V * fine_h * fine_w * (kC * 4) < 4294967296L,
+                "car_fused_samples: the lattice and the finest level of one call must each stay below 4 GiB (render fewer scenes per call)");
     FusedArgs a;
     a.poses = (const CarPose*)poses; a.rays = (const CarRay*)rays; a.steps = steps;
-    for (int l = 0; l < 3; ++l) {
-        a.gmap[l] = gmaps[l]; a.gh[l] = level_h[l]; a.gw[l] = level_w[l];
-        // texel rows are addressed by 32-bit byte offsets inside a level; hosts with more scenes render them in groups (engine.py)
-        CAR_REQUIRE(a.gmap[l] && a.gh[l] > 0 && a.gw[l] > 0 && (long)b * V * a.gh[l] * a.gw[l] * (kC * 4) < 4294967296L,
-                    "car_fused_samples: bad level %d (a level's projected map must stay below 4 GiB per call: render fewer scenes per call)", l);
-    }
+    a.gmap[0] = lattice; a.lh = lat_h; a.lw = lat_w; a.pad = lat_pad;
+    a.gmap[1] = fine; a.fh = fine_h; a.fw = fine_w;
+    a.sx = (float)((lat_w - 2 * lat_pad + 1) / 2); a.sy = (float)((lat_h - 2 * lat_pad + 1) / 2);
     a.gmeta = gmeta; a.wpt = wpt; a.blob = blob; a.bias = bias;
     a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
     a.S = (long)b * V * R * P;
@@ -412,7 +421,7 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     switch (abl) {
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 5: kern = fused_kernel<5>; break;   case 6: kern = fused_kernel<6>; break;   case 7: kern = fused_kernel<7>; break;
-        case 8: kern = fused_kernel<8>; break;   case 9: kern = fused_kernel<9>; break;   case 10: kern = fused_kernel<10>; break;
+        case 8: kern = fused_kernel<8>; break;
         case 4: kern = fused_kernel<4>; break;
         default: break;
     }
@@ -432,21 +441,21 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
 extern "C" size_t car_fused_blob_floats(void) { return (size_t)kBlobTiles * kTile; }
 extern "C" size_t car_fused_bias_floats(void) { return (size_t)kBiasFloats; }
 
-extern "C" int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                                 const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
-                                 const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                                 float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
-    return launch_fused(0, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
-                        logit, pt, pixel_val, stream);
+extern "C" int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
+                                 int lat_pad, const float* fine, int fine_h, int fine_w, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V,
+                                 int R, int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val,
+                                 void* stream) {
+    return launch_fused(0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, fine, fine_h, fine_w, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt,
+                        pixel_val, stream);
 }
 
 #ifdef CAR_ABLATION
 // development build only (tools/build_dev.py): timing-only variants of the kernel, results are wrong by construction
-extern "C" int car_fused_samples_ablate(int abl, const float* poses, const float* rays, const float* steps, const float* const* gmaps,
-                                        const int* level_h, const int* level_w, int n_levels, int C, const float* gmeta,
-                                        const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W,
-                                        float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
-    return launch_fused(abl, poses, rays, steps, gmaps, level_h, level_w, n_levels, C, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
-                        logit, pt, pixel_val, stream);
+extern "C" int car_fused_samples_ablate(int abl, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h,
+                                        int lat_w, int lat_pad, const float* fine, int fine_h, int fine_w, const float* gmeta, const float* wpt, const float* blob, const float* bias,
+                                        int b, int V, int R, int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt,
+                                        float* pixel_val, void* stream) {
+    return launch_fused(abl, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, fine, fine_h, fine_w, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit,
+                        pt, pixel_val, stream);
 }
 #endif

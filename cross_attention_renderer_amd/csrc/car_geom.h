@@ -319,9 +319,8 @@ CAR_HD void car_sample_setup(const CarPose& P, const CarPose* poses_of_scene, co
 // outside the map has weight 0.  Coordinates may be ~1e10 (geometry.project scrubbing): the float->int
 // conversion is guarded.
 // ----------------------------------------------------------------------------------------------------
-CAR_HD void car_bilinear_taps(float gx, float gy, int W, int H, int mode, int* idx, float* w) {
-    float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
-    float iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+// ... from texel coordinates (ix, iy): texel i has its centre at i
+CAR_HD void car_bilinear_taps_px(float ix, float iy, int W, int H, int mode, int* idx, float* w) {
     if (mode == 0) {
         ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));
         iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
@@ -342,4 +341,32 @@ CAR_HD void car_bilinear_taps(float gx, float gy, int W, int H, int mode, int* i
     idx[1] = cy0 * W + cx1; w[1] = (vx1 && vy0) ? wx1 * wy0 : 0.0f;    // ne
     idx[2] = cy1 * W + cx0; w[2] = (vx0 && vy1) ? wx0 * wy1 : 0.0f;    // sw
     idx[3] = cy1 * W + cx1; w[3] = (vx1 && vy1) ? wx1 * wy1 : 0.0f;    // se
+}
+CAR_HD void car_bilinear_taps(float gx, float gy, int W, int H, int mode, int* idx, float* w) {
+    car_bilinear_taps_px(((gx + 1.0f) * (float)W - 1.0f) / 2.0f, ((gy + 1.0f) * (float)H - 1.0f) / 2.0f, W, H, mode, idx, w);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// The merged lattice (car_project_maps).  grid_sample of a level is a tensor product of hat functions on
+// that level's texel centres; with u = (x + 1) W_max - 1 (twice the finest level's texel coordinate) the centres of a
+// level r times coarser sit at u = 2 r i + r - 1, all integers, and so do the kinks the two padding modes add (zeros: one
+// texel beyond the edge; border: the clamp at the outer centres).  The SUM over the levels is therefore bilinear inside
+// every cell of the integer lattice u in [-pad, 2 W_max - 1 + pad], pad = r_max + 1, and four taps of one map — built once
+// per stereo pair and padding mode — give what twelve taps of three levels give.  Outside the lattice both sums are constant
+// (zero / the border value), so the lookup clamps.  Returns the node index y0 * lw + x0 of the north-west tap, flags
+// (1: the east taps are one node over, 2: the south taps one row down) and the weights (nw, ne, sw, se).
+// ----------------------------------------------------------------------------------------------------
+CAR_HD void car_lattice_taps(float gx, float gy, int lw, int lh, int pad, float sx, float sy, int* node, int* flags, float* w) {
+    float ux = (gx + 1.0f) * sx - 1.0f, uy = (gy + 1.0f) * sy - 1.0f;
+    const float lox = -(float)pad, hix = (float)(lw - 1 - pad), loy = -(float)pad, hiy = (float)(lh - 1 - pad);
+    if (!(ux > lox)) ux = lox;                                         // also NaN
+    if (!(uy > loy)) uy = loy;
+    if (ux > hix) ux = hix;
+    if (uy > hiy) uy = hiy;
+    const float x0f = floorf(ux), y0f = floorf(uy);
+    const float wx0 = (x0f + 1.0f) - ux, wx1 = ux - x0f, wy0 = (y0f + 1.0f) - uy, wy1 = uy - y0f;
+    const int x0 = (int)x0f + pad, y0 = (int)y0f + pad;
+    *node = y0 * lw + x0;
+    *flags = (x0 < lw - 1 ? 1 : 0) | (y0 < lh - 1 ? 2 : 0);            // on the last node the far weight is exactly 0
+    w[0] = wx0 * wy0; w[1] = wx1 * wy0; w[2] = wx0 * wy1; w[3] = wx1 * wy1;
 }

@@ -6,6 +6,7 @@
 // path: cross_attention_renderer_amd/engine.py calls it for that configuration (its own stage-by-stage sequence covers the
 // constructor variants and serves as the A/B partner in tests/test_hip_parity.py).
 #include "car_common.h"
+#include "car_geom.h"
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -131,6 +132,65 @@ __global__ void absmax_kernel(const float* __restrict__ x, long n4, unsigned* __
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
+// The merged lattice (car_geom.h car_lattice_taps): node (jy, jx) of map (m, mode) = sum over the levels of the bilinear
+// interpolation of the projected level G_l[m] at lattice coordinate u = j - pad, i.e. at texel coordinate (u + 1 - r_l) / (2 r_l) of
+// a level r_l times coarser than the finest, with the level's own padding rule (mode 0 border, 1 zeros).  One thread = four channels
+// of one node.
+struct MergeArgs {
+    const float* g[CAR_MAX_LEVELS];
+    int h[CAR_MAX_LEVELS], w[CAR_MAX_LEVELS], r[CAR_MAX_LEVELS];
+    int n_levels, lh, lw, pad;
+    long total;                   // n_maps * 2 * lh * lw * (kC / 4)
+    float* lat;
+};
+__global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.total) return;
+    const int q = (int)(idx % (kC / 4));
+    long node = idx / (kC / 4);
+    const int jx = (int)(node % a.lw); node /= a.lw;
+    const int jy = (int)(node % a.lh); node /= a.lh;
+    const int mode = (int)(node & 1), m = (int)(node >> 1);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = a.n_levels - 1; l >= 0; --l) {
+        const float r2 = (float)(2 * a.r[l]);
+        const float ix = (float)(jx - a.pad + 1 - a.r[l]) / r2, iy = (float)(jy - a.pad + 1 - a.r[l]) / r2;
+        int t4[4];
+        float w4[4];
+        car_bilinear_taps_px(ix, iy, a.w[l], a.h[l], mode, t4, w4);
+        const float* base = a.g[l] + (long)m * a.h[l] * a.w[l] * kC + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (long)t4[t] * kC);
+            acc.x = fmaf(w4[t], v.x, acc.x); acc.y = fmaf(w4[t], v.y, acc.y); acc.z = fmaf(w4[t], v.z, acc.z); acc.w = fmaf(w4[t], v.w, acc.w);
+        }
+    }
+    reinterpret_cast<float4*>(a.lat)[idx] = acc;
+}
+// The level with the most texels ("fine") is gathered directly — merged, it would double the lattice in both directions — and the
+// other levels are summed on their common lattice.
+struct Lattice { int h, w, pad, r[CAR_MAX_LEVELS], fine; bool ok; };
+Lattice lattice_of(const car_dims& d) {
+    Lattice L{};
+    int hm = 0, wm = 0, rmax = 1;
+    L.fine = 0;
+    for (int l = 1; l < d.n_levels; ++l)
+        if ((long)d.level_h[l] * d.level_w[l] >= (long)d.level_h[L.fine] * d.level_w[L.fine]) L.fine = l;
+    for (int l = 0; l < d.n_levels; ++l) {
+        if (l == L.fine) continue;
+        hm = d.level_h[l] > hm ? d.level_h[l] : hm; wm = d.level_w[l] > wm ? d.level_w[l] : wm;
+    }
+    L.ok = d.n_levels > 1;
+    for (int l = 0; l < d.n_levels && L.ok; ++l) {
+        if (l == L.fine) continue;
+        const int h = d.level_h[l], w = d.level_w[l];
+        L.ok = h > 0 && w > 0 && hm % h == 0 && wm % w == 0 && hm / h == wm / w;
+        if (L.ok) { L.r[l] = hm / h; rmax = L.r[l] > rmax ? L.r[l] : rmax; }
+    }
+    L.pad = rmax + 1;
+    L.h = 2 * hm + 2 * rmax + 1; L.w = 2 * wm + 2 * rmax + 1;
+    return L;
+}
 // ---- plan layout ---------------------------------------------------------------------------------------------------
 struct Plan {
     // offsets in floats.  latent_value, lin_in: car_linear_pack layout (inputs read from memory, bias folded); the *_c entries:
@@ -177,6 +237,9 @@ int check_dims(const car_dims* d, const char* who) {
     }
     CAR_REQUIRE(csum == kC, "%s: the levels' channels must add up to %d (got %d)", who, kC, csum);
     CAR_REQUIRE(2 * d->P <= 128 * 3, "%s: too many samples per ray", who);
+    CAR_REQUIRE(lattice_of(*d).ok, "%s: below the finest pyramid level every level must be an integer factor coarser than the next, the same "
+                "factor in both directions (the fused kernel gathers them from their common lattice); other pyramids run through the stage "
+                "entries", who);
     return CAR_OK;
 }
 
@@ -281,16 +344,37 @@ extern "C" size_t car_workspace_bytes(const car_dims* dims) {
     if (check_dims(dims, "car_workspace_bytes") != CAR_OK) return 0;
     return work_layout(*dims).total * sizeof(float);
 }
-extern "C" size_t car_gmaps_level_offset(const car_dims* dims, int level) {
-    if (check_dims(dims, "car_gmaps_level_offset") != CAR_OK || level < 0 || level > dims->n_levels) return 0;
-    size_t n = 0;
-    for (int l = 0; l < level; ++l) n += (size_t)dims->b * dims->V * dims->level_h[l] * dims->level_w[l] * kC;
+namespace {
+size_t lattice_floats(const car_dims& d) { const Lattice L = lattice_of(d); return (size_t)d.b * d.V * 2 * L.h * L.w * kC; }
+size_t level_floats(const car_dims& d, int l) { return (size_t)d.b * d.V * d.level_h[l] * d.level_w[l] * kC; }
+// projected levels behind the lattice and gmeta: the finest first (an input of the fused kernel), then the merged ones (scratch)
+size_t level_offset(const car_dims& d, int level) {
+    const int fine = lattice_of(d).fine;
+    size_t n = up64(lattice_floats(d)) + 64;
+    if (level == fine) return n;
+    n += up64(level_floats(d, fine));
+    for (int l = 0; l < level && l < d.n_levels; ++l) if (l != fine) n += up64(level_floats(d, l));
     return n;
 }
-extern "C" size_t car_gmeta_offset(const car_dims* dims) { return dims ? car_gmaps_level_offset(dims, dims->n_levels) : 0; }
+}  // namespace
+extern "C" size_t car_gmeta_offset(const car_dims* dims) {
+    if (check_dims(dims, "car_gmeta_offset") != CAR_OK) return 0;
+    return up64(lattice_floats(*dims));
+}
+extern "C" size_t car_fine_offset(const car_dims* dims) {
+    if (check_dims(dims, "car_fine_offset") != CAR_OK) return 0;
+    return level_offset(*dims, lattice_of(*dims).fine);
+}
 extern "C" size_t car_gmaps_floats(const car_dims* dims) {
     if (check_dims(dims, "car_gmaps_floats") != CAR_OK) return 0;
-    return car_gmeta_offset(dims) + CAR_MAX_LEVELS;
+    return level_offset(*dims, CAR_MAX_LEVELS + 1);
+}
+extern "C" int car_lattice_shape(const car_dims* dims, int* lat_h, int* lat_w, int* lat_pad, int* fine_level) {
+    CAR_TRY(check_dims(dims, "car_lattice_shape"));
+    CAR_REQUIRE(lat_h && lat_w && lat_pad && fine_level, "car_lattice_shape: null pointer");
+    const Lattice L = lattice_of(*dims);
+    *lat_h = L.h; *lat_w = L.w; *lat_pad = L.pad; *fine_level = L.fine;
+    return CAR_OK;
 }
 extern "C" int car_workspace_find(const car_dims* dims, const char* name, size_t* offset_floats, size_t* n_floats) {
     CAR_TRY(check_dims(dims, "car_workspace_find"));
@@ -434,16 +518,32 @@ extern "C" int car_project_maps(const car_dims* dims, const void* plan, const fl
     hipStream_t st = (hipStream_t)stream;
     float* gmeta = gmaps + car_gmeta_offset(dims);
     if (hipMemsetAsync(gmeta, 0, sizeof(float) * CAR_MAX_LEVELS, st) != hipSuccess) { car_set_error("car_project_maps: memset failed"); return CAR_E_LAUNCH; }
+    const Lattice L = lattice_of(*dims);
+    MergeArgs a{};
+    int nm = 0;
     for (int l = 0; l < dims->n_levels; ++l) {
         CAR_REQUIRE(maps[l], "car_project_maps: level %d is null", l);
         const long M = (long)dims->b * dims->V * dims->level_h[l] * dims->level_w[l];
-        float* gl = gmaps + car_gmaps_level_offset(dims, l);
+        float* gl = gmaps + level_offset(*dims, l);
         CAR_TRY(car_linear(maps[l], dims->level_c[l], base + p.proj[l], dims->level_c[l], kC, gl, kC, M, 0, stream));
-        // largest |G_l|: bounds the level's contribution to h (the fused kernel scales its fp16 operands by it)
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, gl, M * kC / 4, reinterpret_cast<unsigned*>(gmeta + l));
-        CAR_CHECK_LAUNCH("car_project_maps (absmax)");
+        if (l == L.fine) {
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, gl, M * kC / 4, reinterpret_cast<unsigned*>(gmeta + 1));
+            CAR_CHECK_LAUNCH("car_project_maps (absmax)");
+            continue;
+        }
+        a.g[nm] = gl; a.h[nm] = dims->level_h[l]; a.w[nm] = dims->level_w[l]; a.r[nm] = L.r[l];
+        ++nm;
     }
+    a.n_levels = nm; a.lh = L.h; a.lw = L.w; a.pad = L.pad;
+    a.total = (long)lattice_floats(*dims) / 4;
+    a.lat = gmaps;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)car_div_up(a.total, 256)), dim3(256), 0, st, a);
+    CAR_CHECK_LAUNCH("car_project_maps (merge)");
+    // largest |lattice value|: bounds h (the fused kernel scales its fp16 operands by it)
+    hipLaunchKernelGGL(absmax_kernel, dim3(4096), dim3(256), 0, st, gmaps, a.total, reinterpret_cast<unsigned*>(gmeta));
+    CAR_CHECK_LAUNCH("car_project_maps (absmax)");
     return CAR_OK;
 }
 
@@ -451,8 +551,8 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
                                   void* workspace, size_t workspace_bytes, void* stream) {
     CAR_TRY(check_dims(dims, "car_render_forward"));
     CAR_REQUIRE(plan && in && out && workspace, "car_render_forward: null pointer");
-    CAR_REQUIRE(in->poses && in->uv && in->gmaps[0] && in->gmaps[1] && in->gmaps[2] && in->gmeta && out->rgb,
-                "car_render_forward: poses, uv, gmaps, gmeta and rgb are required");
+    CAR_REQUIRE(in->poses && in->uv && in->lattice && in->fine && in->gmeta && out->rgb,
+                "car_render_forward: poses, uv, lattice, fine, gmeta and rgb are required");
     const car_dims& d = *dims;
     const Plan p = plan_layout(d);
     const Work w = work_layout(d);
@@ -478,7 +578,9 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
     }
     {   // a6-a13 + round-1 logits: the fused per-sample kernel
         Stage stage("fused_samples", st);
-        CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->gmaps, d.level_h, d.level_w, 3, kC, in->gmeta, pl + p.wpt, pl + p.blob,
+        const Lattice L = lattice_of(d);
+        CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->fine, d.level_h[L.fine], d.level_w[L.fine],
+                                  in->gmeta, pl + p.wpt, pl + p.blob,
                                   pl + p.fbias, b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
     }
     {   // a14 + a16: attention round 1, depth read-out, argmax

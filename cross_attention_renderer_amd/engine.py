@@ -85,7 +85,7 @@ class RenderEngine:
         self.fuse_round2 = True        # staged route: round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
         # sizing of the one-call route (tests shrink them to force several calls)
         self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
-        self.max_level_bytes = (1 << 32) - 1               # a projected level of one call: the fused kernel's 32-bit texel offsets
+        self.max_level_bytes = (1 << 32) - 1               # lattice / finest level of one call: the fused kernel's 32-bit node offsets
         self.last_calls = 0            # number of car_render_forward calls the last forward was split into
         self._round2_key = None
         self._round2 = None
@@ -302,13 +302,18 @@ class RenderEngine:
         d_all = self._dims(b, R, z)
         plan = self._plan_for(d_all, dev)
         pair = self._pair_for(d_all, plan, z, dev)
-        level_off = [lib.car_gmaps_level_offset(ctypes.byref(d_all), l) for l in range(3)]
-        level_scene = [V * z[l].shape[2] * z[l].shape[3] * 576 for l in range(3)]                # floats per scene
+        lh, lw, lpad, fine = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.car_lattice_shape(ctypes.byref(d_all), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(lpad), ctypes.byref(fine)),
+                   "car_lattice_shape")
+        lattice_scene = V * 2 * lh.value * lw.value * 576                                        # floats per scene
+        fine_scene = V * z[fine.value].shape[2] * z[fine.value].shape[3] * 576
+        fine_ptr = pair.data_ptr() + 4 * lib.car_fine_offset(ctypes.byref(d_all))
         gmeta_ptr = pair.data_ptr() + 4 * lib.car_gmeta_offset(ctypes.byref(d_all))
 
-        # scenes per call: a projected level must stay below 4 GiB (32-bit texel offsets in the fused kernel); rays per call: the
-        # workspace (~0.44 MB per ray at 64 samples) must fit the free memory.  Rays are independent, so the split is exact.
-        gs = max(1, min(b, min(self.max_level_bytes // (4 * ls) for ls in level_scene)))
+        # scenes per call: the merged lattice and the finest projected level must each stay below 4 GiB (32-bit node offsets in the
+        # fused kernel); rays per call: the workspace (~0.44 MB per ray at 64 samples) must fit the free memory.  Rays are
+        # independent, so the split is exact.
+        gs = max(1, min(b, self.max_level_bytes // (4 * max(lattice_scene, fine_scene))))
         budget = self._workspace_budget(dev)
 
         def ws_bytes(nb, nr):
@@ -353,8 +358,8 @@ class RenderEngine:
                 ci = _lib.CarInputs()
                 ci.poses = poses.data_ptr() + 4 * 96 * s0 * V
                 ci.uv = uv_c.data_ptr()
-                for l in range(3):
-                    ci.gmaps[l] = pair.data_ptr() + 4 * (level_off[l] + s0 * level_scene[l])
+                ci.lattice = pair.data_ptr() + 4 * s0 * lattice_scene
+                ci.fine = fine_ptr + 4 * s0 * fine_scene
                 ci.gmeta = gmeta_ptr
                 ci.steps = steps.data_ptr()
                 co = _lib.CarOutputs(*[tgt[k].data_ptr() for k in order])

@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
     car_inputs in;
     memset(&in, 0, sizeof in);
     in.poses = poses; in.uv = uv;
-    for (int l = 0; l < d.n_levels; ++l) in.gmaps[l] = gmaps + car_gmaps_level_offset(&d, l);
+    in.lattice = gmaps; in.fine = gmaps + car_fine_offset(&d);
     in.gmeta = gmaps + car_gmeta_offset(&d);
     car_outputs out;
     memset(&out, 0, sizeof out);

@@ -118,3 +118,40 @@ def test_bilinear_taps_match_grid_sample(shim):
         want = torch.nn.functional.grid_sample(feat, grid, mode="bilinear", padding_mode=name,
                                                align_corners=False)[0, :, 0].T
         assert (got - want).abs().max() < 1e-5, name
+
+
+@pytest.mark.parametrize("sizes", [((8, 8), (16, 16)), ((4, 6), (16, 24), (8, 12)), ((16, 16),)])
+def test_merged_lattice_equals_the_sum_of_the_levels(shim, sizes):
+    """car_lattice_taps / the merge kernel's arithmetic: four taps of the lattice on which the levels are summed (built with the
+    levels' own padding rule) equal the sum of the levels' grid_sample, for border and zeros padding, inside, on and far outside
+    the maps (the identity behind the fused kernel's gather)."""
+    g = torch.Generator().manual_seed(1)
+    Cc = 5
+    feats = [torch.randn(1, Cc, h, w, generator=g) for h, w in sizes]
+    hm, wm = max(h for h, _ in sizes), max(w for _, w in sizes)
+    r = [hm // h for h, _ in sizes]
+    assert all(hm % h == 0 and wm // w == hm // h for h, w in sizes)
+    pad = max(r) + 1
+    lh, lw = 2 * hm + 2 * max(r) + 1, 2 * wm + 2 * max(r) + 1
+    lat = np.zeros((2, lh, lw, Cc), np.float32)
+    cl = [np.ascontiguousarray(f[0].permute(1, 2, 0).numpy()) for f in feats]
+    ptrs = (ctypes.c_void_p * len(cl))(*[a.ctypes.data for a in cl])
+    ia = lambda v: (ctypes.c_int * len(v))(*v)
+    shim.host_lattice_build(ptrs, ia([h for h, _ in sizes]), ia([w for _, w in sizes]), ia(r), len(sizes), Cc, lh, lw, pad, _ptr(lat))
+    n = 2000
+    grid = torch.rand(1, 1, n, 2, generator=g) * 2.6 - 1.3
+    grid[0, 0, 0] = torch.tensor([1e10, -1e10]); grid[0, 0, 1] = torch.tensor([-1.0, 1.0]); grid[0, 0, 2] = torch.tensor([7.8e7, 0.1])
+    grid[0, 0, 3] = torch.tensor([1.0, -1.0]); grid[0, 0, 4] = torch.tensor([-1.0 + 1.0 / wm, 1.0 - 1.0 / hm])     # outermost texel centres
+    gnp = np.ascontiguousarray(grid.reshape(-1, 2).numpy())
+    node = np.zeros(n, np.int32); flags = np.zeros(n, np.int32); w = np.zeros((n, 4), np.float32)
+    shim.host_lattice_taps.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    shim.host_lattice_taps(_ptr(gnp), n, lw, lh, pad, float(wm), float(hm), _ptr(node), _ptr(flags), _ptr(w))
+    assert node.min() >= 0 and (node + (flags & 1) + (flags >> 1) * lw).max() < lh * lw
+    assert np.all(np.abs(w.sum(1) - 1.0) < 1e-6) and w.min() >= 0.0
+    idx = np.stack([node, node + (flags & 1), node + (flags >> 1) * lw, node + (flags & 1) + (flags >> 1) * lw], 1)
+    for mode, name in ((0, "border"), (1, "zeros")):
+        flat = torch.as_tensor(lat[mode].reshape(lh * lw, Cc))
+        got = (flat[torch.as_tensor(idx).long()] * torch.as_tensor(w)[..., None]).sum(1)
+        want = sum(torch.nn.functional.grid_sample(f, grid, mode="bilinear", padding_mode=name, align_corners=False) for f in feats)[0, :, 0].T
+        assert (got - want).abs().max() < 2e-5, (name, (got - want).abs().max())

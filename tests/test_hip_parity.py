@@ -504,8 +504,9 @@ def test_forward_on_device_made_poses(name):
 # ----------------------------------------------------------------------------------------------------------
 def test_c3_twelve_scenes_at_full_size():
     """BASELINE config 3 (batch_size 12 at 256x256, 64 samples): one forward over 12 scenes x 8192 rays — the per-GPU share when
-    the frame's rays are banded over 8 ranks — through the one-call route (12.6 M samples, 36 GB of workspace, level maps of
-    3.6 GB: just below the 4 GiB a call may address), 64 rays of every scene against the oracle."""
+    the frame's rays are banded over 8 ranks — through the one-call route (12.6 M samples; the merged lattices of 12 scenes are
+    7.5 GB, a call addresses 4 GiB of them: two calls of six scenes, 18 GB of workspace each), 64 rays of every scene against the
+    oracle."""
     from cross_attention_renderer_amd import synthetic as S
     from cross_attention_renderer_amd.models import CrossAttentionRenderer
     dev = torch.device("cuda:0")
@@ -522,7 +523,7 @@ def test_c3_twelve_scenes_at_full_size():
     with torch.no_grad():
         out = m(to_device(inp, dev, cameras_on_host=True), z=[t.to(dev) for t in z])
     torch.cuda.synchronize()
-    assert m._engine.last_calls == 1
+    assert m._engine.last_calls == 2
     assert torch.isfinite(out["rgb"]).all()
     idx = torch.linspace(0, R - 1, 64).long()
     sub = {"context": inp["context"], "query": dict(inp["query"], uv=inp["query"]["uv"][:, :, idx].contiguous())}
@@ -534,9 +535,10 @@ def test_c3_twelve_scenes_at_full_size():
     assert torch.equal(out["valid_mask"][:, idx].cpu(), ora["valid_mask"])
     decided, wrong = argmax_exact_where_decided(out["at_wt_max"][:, idx].cpu(), ora["at_wt"])
     assert wrong == 0
-    # 15 scenes would put the finest projected level at 4.5 GB: the engine renders them in two groups
+    # 7 scenes of 256 x 256 images would put the merged lattice (2 views x 2 padding modes x 261 x 261 nodes) at 4.4 GB: the engine
+    # renders them in two groups
     eng = m._engine
-    assert min(eng.max_level_bytes // (4 * 2 * 256 * 256 * 576), 15) == 14
+    assert min(eng.max_level_bytes // (4 * 2 * 2 * 261 * 261 * 576), 7) == 6
 
 
 def test_forward_without_z_runs_get_z_on_the_device():
