@@ -98,6 +98,22 @@ SIGNATURES = {
 _lib: Optional[ctypes.CDLL] = None
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources and the public header: build() stores it next to the library, load() refuses a library built
+    from anything else (a pushed .so can not silently lag behind the tree)."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(os.path.dirname(here), "include", "car_hip.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def load() -> ctypes.CDLL:
     """Loads the HIP library (once) and sets the prototypes.  Raises if it is missing."""
     global _lib
@@ -110,6 +126,10 @@ def load() -> ctypes.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
             "The render path has no CPU/PyTorch fallback.")
+    stamp = LIB_PATH + ".srchash"
+    if os.path.exists(stamp) and open(stamp).read().strip() != source_hash():
+        raise RuntimeError(f"{LIB_PATH} was built from other sources than the ones in this tree (csrc/, include/car_hip.h): rebuild it "
+                           "with `python __graft_entry__.py`")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
