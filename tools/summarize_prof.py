@@ -47,6 +47,7 @@ def main():
              "group by kernel_name, grid_size_x")
         for name, gx, n, val in c.execute(q, (counter,)):
             traffic.setdefault((short(name), gx), {})[key] = val * 1024.0 * scale
+            traffic[(short(name), gx)]["n_" + key] = n
     if traffic:
         print("## HBM-side traffic per dispatch (PMC; FETCH_SIZE x2, WRITE_SIZE raw; KiB -> GB)\n\n| kernel | grid | read GB | write GB |\n|---|---|---|---|")
         for (name, gx), t in sorted(traffic.items(), key=lambda kv: -(kv[1].get("read", 0) + kv[1].get("write", 0))):
@@ -62,6 +63,20 @@ def main():
                                      "write_bytes": t.get("write", 0), "kernel": name, "grid_threads": gx,
                                      "source": f"profiles/{os.path.basename(root.rstrip('/')).replace('prof_', '')}_*_rocprof.md "
                                                "(rocprofv3 --pmc FETCH_SIZE x2, --pmc WRITE_SIZE, per dispatch)"}}
+            # one frame = every kernel that runs once (or more) per bench step; the passes ran `frames` steps (warm-up + timed)
+            frames = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 2
+            rd = sum(t.get("read", 0) * (t.get("n_read", 0) // frames) for t in traffic.values())
+            wr = sum(t.get("write", 0) * (t.get("n_write", 0) // frames) for t in traffic.values())
+            rec["frame"] = {"read_bytes": rd, "write_bytes": wr, "bytes_per_frame": rd + wr,
+                            "source": rec["fused_samples"]["source"].replace("per dispatch", "every dispatch of one 65536-ray frame")}
+            try:
+                with open(out) as f:
+                    old = json.load(f)
+                for k in ("bound", "ta_busy", "mfma_busy", "l1_bytes_per_launch", "l1_note"):
+                    if k in old.get("fused_samples", {}):
+                        rec["fused_samples"][k] = old["fused_samples"][k]
+            except (OSError, ValueError):
+                pass
             with open(out, "w") as f:
                 json.dump(rec, f, indent=1)
 
