@@ -261,7 +261,7 @@ def main():
             samples = V * R * P * (min(args.chunk_rays, R) / R)
             flop = 2.0 * samples * FUSED_MACS
             pmc = prof.get("fused_samples", {})
-            roof = {"bound": pmc.get("bound", "ta/l1"), "kernel": f"fused_kernel on {int(samples)} samples (geometry, 12-tap gather of the projected maps, e, key, qry, logits; "
+            roof = {"bound": pmc.get("bound", "ta/l1"), "kernel": f"fused_kernel on {int(samples)} samples (geometry, 8-tap gather of the projected maps (finest level + merged lattice), e, key, qry, logits; "
                                                                   "f16 matrix pipe, fp16 hi/lo split x3)",
                     "achieved": flop / mean / 1e12, "peak": F16_MFMA_PEAK / 3 / 1e12, "unit": "TFLOP/s", "frac": flop / mean / (F16_MFMA_PEAK / 3),
                     "peak_note": "dense f16 MFMA peak 2500 / 3 products per fp32 term; the kernel is bound by the texture-address / L1 path "

@@ -84,7 +84,8 @@ __device__ __forceinline__ int chunk_tiles(int g) {
 // ABL > 0: timing-only ablations (wrong results), instantiated only in the -DCAR_ABLATION development build (tools/):
 // 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers, 5 the gather alone (no e-path MFMAs, no weight DMA, no
 // barriers); probes of the texture-address path on top of 5: 6 odd rows masked off (whole quads of lanes inactive), 7 odd channel
-// quads masked off (half of every quad of lanes inactive);
+// quads masked off (half of every quad of lanes inactive); 11 the full kernel without the barrier of the weight stream (racy);
+// 12 = 3 + no A-operand reads from LDS (matrix pipe + VALU only);
 // 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val)
 template <int ABL>
 __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     const unsigned row_step[2] = {(unsigned)a.lw * (kC * 4), (unsigned)a.fw * (kC * 4)};
 
     auto issue_row = [&](f32x4 (&tap)[4], int sv, int c, int l, int it) {
-        if constexpr (ABL == 1 || ABL == 2 || ABL == 3) return;
+        if constexpr (ABL == 1 || ABL == 2 || ABL == 3 || ABL == 12) return;
         if constexpr (ABL == 6) { if (r0 & 1) return; }
         if constexpr (ABL == 7) { if (qd & 1) return; }
         const char* base = reinterpret_cast<const char*>(a.gmap[l] + 32 * c);
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
         tap[3] = *reinterpret_cast<const f32x4*>(base + (o00 + dx + dy));
     };
     auto blend_row = [&](const f32x4 (&tap)[4], int sv, int l, int it) {
-        if constexpr (ABL == 2 || ABL == 3) return;
+        if constexpr (ABL == 2 || ABL == 3 || ABL == 12) return;
         const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 8 + 4 * l);
         const float ww[4] = {w.x, w.y, w.z, w.w};
         f32x2 lo2 = {hacc[it].x, hacc[it].y}, hi2 = {hacc[it].z, hacc[it].w};          // v_pk_fma_f32: two FMAs per instruction
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
         hacc[it] = make_float4(lo2[0], lo2[1], hi2[0], hi2[1]);
     };
     auto affine_row = [&](int sv, int c, int it) {
-        if constexpr (ABL == 2 || ABL == 3) return;
+        if constexpr (ABL == 2 || ABL == 3 || ABL == 12) return;
         const int rr = r0 + 8 * it;
         const float4 pe = *reinterpret_cast<const float4*>(lds + kLdsPe + ((wave * kRows + rr) * 2 + sv) * 4);
         const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 4 * (32 * c + 4 * qd));
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
                                fmaf(w3.z, pe.z, fmaf(w3.y, pe.y, w3.x * pe.x)) + w3.w);
     };
     auto finish_row = [&](int it) {
-        if constexpr (ABL == 2 || ABL == 3) return;
+        if constexpr (ABL == 2 || ABL == 3 || ABL == 12) return;
         const float4 o = hacc[it];
         *reinterpret_cast<float4*>(stage + (r0 + 8 * it) * kStageLd + 4 * qd) =
             make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
@@ -297,7 +298,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
 #pragma unroll
             for (int qs = 0; qs < kTE / 2; ++qs) {
                 const float* w0 = wl + (2 * qs * 2) * 256;
-                if constexpr (ABL < 5) mfma_pair(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
+                if constexpr (ABL < 5 || ABL >= 11) mfma_pair<ABL>(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
                 piece(qs);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -421,7 +422,7 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     switch (abl) {
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 5: kern = fused_kernel<5>; break;   case 6: kern = fused_kernel<6>; break;   case 7: kern = fused_kernel<7>; break;
-        case 8: kern = fused_kernel<8>; break;
+        case 8: kern = fused_kernel<8>; break;   case 11: kern = fused_kernel<11>; break;   case 12: kern = fused_kernel<12>; break;
         case 4: kern = fused_kernel<4>; break;
         default: break;
     }

@@ -41,7 +41,7 @@ __device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, 
 // LDS-DMA in inline asm, see car_linear.hip.  Must only run after the barrier that retired the buffer's previous chunk.
 template <int ABL = 0>
 __device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, int lane, int wave) {
-    if constexpr (ABL == 3 || ABL >= 5) return;
+    if constexpr (ABL == 3 || (ABL >= 5 && ABL != 11 && ABL != 13)) return;
     int kb = kWaves * p + wave;
     kb = kb < n.nkb ? kb : kb - n.nkb;
     kb = kb < n.nkb ? kb : kb - n.nkb;
@@ -63,12 +63,12 @@ __device__ __forceinline__ void stream_issue_all(const float* __restrict__ blob,
 // order, so "at most KEEP outstanding" still means every DMA piece has landed).
 template <int ABL = 0, int KEEP = 0>
 __device__ __forceinline__ void stream_sync() {
-    if constexpr (ABL == 3 || ABL >= 5) return;
+    if constexpr (ABL == 3 || (ABL >= 5 && ABL != 11 && ABL != 13)) return;
     if constexpr (KEEP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (ABL != 11) __syncthreads();                          // 11 (development build): the weight stream without its barrier
 }
 
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
@@ -106,11 +106,16 @@ __device__ __forceinline__ float sample_max(const f32x4 (&v)[NT]) {
 }
 
 // two output tiles x three split products, interleaved so consecutive MFMAs never share an accumulator
+template <int ABL = 0>
 __device__ __forceinline__ void mfma_pair(f32x4& c0, f32x4& c1, const float* w0, const float* w1, const half8& bhi, const half8& blo) {
-    const half8 ah0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0));
-    const half8 ah1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1));
-    const half8 al0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0 + 256));
-    const half8 al1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1 + 256));
+    half8 ah0, ah1, al0, al1;
+    if constexpr (ABL == 12) { ah0 = bhi; ah1 = blo; al0 = blo; al1 = bhi; }        // development build: no A-operand reads from LDS
+    else {
+        ah0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0));
+        ah1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1));
+        al0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0 + 256));
+        al1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1 + 256));
+    }
     c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhi, c0, 0, 0, 0);
     c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhi, c1, 0, 0, 0);
     c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blo, c0, 0, 0, 0);
@@ -169,7 +174,7 @@ __device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&s
 #pragma unroll
                 for (int q = 0; q < kTD / 2; ++q) {
                     const float* w0 = wl + ((kl * kTD + 2 * q) * 2) * 256;
-                    mfma_pair(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, bhi, blo);
+                    mfma_pair<ABL>(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, bhi, blo);
                     if (kl * 4 + q < kPieces) stream_issue_piece<ABL>(nx, kl * 4 + q, lane, wave);
                     __builtin_amdgcn_sched_barrier(0);
                 }

@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-bash tools/profile_bench.sh round2 > gpurun_out/profile_round2.log 2>&1; echo "profile rc=$?"
-cat gpurun_out/profile_round2.log | tail -8
-bash tools/pmc_fused.sh 0 > gpurun_out/pmc_fused_round2.log 2>&1; echo "pmc rc=$?"
-tail -40 gpurun_out/pmc_fused_round2.log
-head -40 gpurun_out/prof_round2_summary.md
+timeout 600 python tools/bench_fused.py 3 12 > gpurun_out/r2_bench_fused11.log 2>&1; echo "bench_fused rc=$?"
+grep -v amdgpu gpurun_out/r2_bench_fused11.log | tail -6
