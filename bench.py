@@ -4,7 +4,7 @@
 
 A *step* renders one full 256x256 query frame (65 536 rays, 64 samples per view, 2 context views = config
 "RealEstate10K pair 256x256, 64 samples") of a camera trajectory between the two context views: EVERY step has its own query
-pose, so the per-frame pose algebra (camera matrices to the host, torch.inverse like the reference, 768 bytes back) is
+pose, so the per-frame pose algebra (car_pose_setup on the device: the cameras are resident there, nothing crosses the bus) is
 inside the timed region, as in the reference's render loop (render_realestate10k_traj.py:118-137).  Inputs are synthetic
 (seeded stereo pair, N(0,1) feature pyramid, perturbed default-init weights), resident in HBM before the timed region;
 ``get_z`` (the image encoder) is excluded on both sides, as in BASELINE.md.

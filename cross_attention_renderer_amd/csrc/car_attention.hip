@@ -144,7 +144,8 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
                 const int oi = __shfl_xor(bi, o, 64);
                 if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
             }
-            if (lane == 0) w_argmax[(long)(sc * V + v) * R + r] = bi;
+            // all-NaN weights leave the sentinel: torch.argmax returns the first NaN's index then
+            if (lane == 0) w_argmax[(long)(sc * V + v) * R + r] = bi == 0x7fffffff ? 0 : bi;
         }
     }
 }

@@ -223,11 +223,14 @@ def test_register_staged_weights_agree_with_lds_dma():
 # ----------------------------------------------------------------------------------------------------------
 # size-independent properties at the full bench shape (256x256, 64 samples, one 8192-ray chunk)
 # ----------------------------------------------------------------------------------------------------------
-def test_full_size_properties():
+@pytest.mark.parametrize("H,P", [(256, 64), (256, 128), (384, 64)])
+def test_full_size_properties(H, P):
+    """One 8192-ray chunk at the sizes of BASELINE.json's configs 2 (256 x 256, 64 samples), 4 (128 samples) and 5 (384 x 384):
+    size-independent properties of the whole chunk, and 64 of its rays against the oracle."""
     from cross_attention_renderer_amd import synthetic as S
     from cross_attention_renderer_amd.models import CrossAttentionRenderer
     dev = torch.device("cuda:0")
-    H, P, R = 256, 64, 8192
+    R = 8192
     torch.manual_seed(0)
     m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).eval()
     S.perturb_parameters(m, seed=0)

@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python tools/bench_fused.py 3 12 > gpurun_out/r2_bench_fused11.log 2>&1; echo "bench_fused rc=$?"
-grep -v amdgpu gpurun_out/r2_bench_fused11.log | tail -6
+timeout 1500 python -m pytest tests -m gpu -q --maxfail=10 --timeout 600 > gpurun_out/r2_pytest10.log 2>&1; echo "pytest rc=$?"
+grep -E "passed|failed|Error|assert" gpurun_out/r2_pytest10.log | head -20
+timeout 600 python bench.py > gpurun_out/r2_bench10.log 2>&1; echo "bench rc=$?"
+grep -v amdgpu gpurun_out/r2_bench10.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms'], d['roofline']['frac'], d['hbm'])"
