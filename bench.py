@@ -177,6 +177,8 @@ def main():
     ap.add_argument("--chunk-rays", type=int, default=65536,
                     help="rays per forward call: the whole frame (or band) by default (a 288 GB GPU does not need the reference render script's 8192-ray chunks; --chunk-rays 8192 reproduces them)")
     ap.add_argument("--no-extras", action="store_true", help="skip the gather-stage and frame-per-rank measurements")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the multi-rank code path)")
+    ap.add_argument("--device", type=int, default=None, help="device index for every rank (smoke tests of the multi-rank path on one GPU; default LOCAL_RANK)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,13 +186,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a ROCm device: the render path has no CPU fallback")
+    if args.device is not None:
+        local_rank = args.device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # nccl == RCCL on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world)      # nccl == RCCL on ROCm
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -260,7 +264,13 @@ def main():
             mean = sum(lat) / len(lat) * 1e-3
             samples = V * R * P * (min(args.chunk_rays, R) / R)
             flop = 2.0 * samples * FUSED_MACS
-            pmc = prof.get("fused_samples", {})
+            pmc = dict(prof.get("fused_samples", {}))
+            part = samples / float(V * H * H * P)              # the PMC passes profiled a whole-frame launch: scale to this launch
+            for k in ("l1_bytes_per_launch", "bytes_per_launch"):
+                if pmc.get(k) is not None:
+                    pmc[k] = pmc[k] * part
+            if part != 1.0 and pmc.get("source"):
+                pmc["source"] += f", scaled by {part:g} to this launch's share of the frame"
             roof = {"bound": pmc.get("bound", "ta/l1"), "kernel": f"fused_kernel on {int(samples)} samples (geometry, 8-tap gather of the projected maps (finest level + merged lattice), e, key, qry, logits; "
                                                                   "f16 matrix pipe, fp16 hi/lo split x3)",
                     "achieved": flop / mean / 1e12, "peak": F16_MFMA_PEAK / 3 / 1e12, "unit": "TFLOP/s", "frac": flop / mean / (F16_MFMA_PEAK / 3),

@@ -82,8 +82,11 @@ class TileGather:
                 self.stage.copy_(tile)
                 self.copied = torch.cuda.Event()
                 self.copied.record(self.stream)
-                # one RCCL all-gather straight into the (world, rows, channels) buffer: no per-rank output copies
-                self.work = dist.all_gather_into_tensor(self.out, self.stage, group=self.group, async_op=True)
+                if dist.get_backend(self.group) == "nccl":
+                    # one RCCL all-gather straight into the (world, rows, channels) buffer: no per-rank output copies
+                    self.work = dist.all_gather_into_tensor(self.out, self.stage, group=self.group, async_op=True)
+                else:
+                    self.work = dist.all_gather(parts, self.stage, group=self.group, async_op=True)
             # the caller may overwrite `tile` as soon as the snapshot is taken
             torch.cuda.current_stream().wait_event(self.copied)
         else:
