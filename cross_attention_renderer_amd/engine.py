@@ -286,6 +286,16 @@ class RenderEngine:
             self._pair, self._pair_key = pair, key
         return self._pair
 
+    @staticmethod
+    def _common_lattice(z: List[Tensor]) -> bool:
+        """The fused kernel gathers the levels below the finest one from their merged lattice (car_lattice_shape): each must be an
+        integer factor coarser than the widest of them, the same factor in both directions.  Other pyramids take the stage route."""
+        sizes = [(t.shape[2], t.shape[3]) for t in z]
+        fine = max(range(len(sizes)), key=lambda l: (sizes[l][0] * sizes[l][1], l))
+        rest = [s for l, s in enumerate(sizes) if l != fine]
+        hm, wm = max(h for h, _ in rest), max(w for _, w in rest)
+        return all(hm % h == 0 and wm % w == 0 and hm // h == wm // w for h, w in rest)
+
     def _workspace_budget(self, device) -> int:
         if self.max_workspace_bytes is not None:
             return int(self.max_workspace_bytes)
@@ -457,7 +467,8 @@ class RenderEngine:
 
         concat2 = (V == 2 and not m.no_latent_concat)
         if (self.fuse_samples and self.project_maps and concat2 and not m.no_sample and len(z) == 3
-                and sum(t.shape[1] for t in z) == 576 and m.hidden_dim == 128 and m.phi.n_blocks == 3 and m.phi.d_hidden == 128):
+                and sum(t.shape[1] for t in z) == 576 and m.hidden_dim == 128 and m.phi.n_blocks == 3 and m.phi.d_hidden == 128
+                and self._common_lattice(z)):
             return self._render_one_call(inp, z, poses, uv, steps, b, V, R, P, H, W, debug)
 
         pk = self._weights(dev)

@@ -502,6 +502,40 @@ def test_forward_on_device_made_poses(name):
     assert (np.asarray(out["valid_mask"]) == fx["out_valid_mask"]).all()
 
 
+def test_pyramid_without_a_common_lattice_takes_the_stage_route():
+    """A pyramid whose coarser levels are no integer refinements of each other (20 x 20 under 32 x 32) has no merged lattice: the
+    engine renders it through the stage kernels (per-level gathers), same contract against the oracle."""
+    from cross_attention_renderer_amd import synthetic as S
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    dev = torch.device("cuda:0")
+    H, P, R = 64, 16, 96
+    torch.manual_seed(0)
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).eval()
+    S.perturb_parameters(m, seed=3)
+    m.H = m.W = H
+    uv = S.pixel_grid(H, H)[20 * H:20 * H + R].contiguous()
+    inp = S.stereo_scene(H, b=1, uv=uv, seed=9, alpha=0.3)
+    g = torch.Generator().manual_seed(4)
+    z = [torch.randn(2, 256, 20, 20, generator=g), torch.randn(2, 256, 32, 32, generator=g), torch.randn(2, 64, H, H, generator=g)]
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to(dev)
+    calls = []
+    with torch.no_grad():
+        m(to_device(inp, dev, cameras_on_host=True), z=[t.to(dev) for t in S.feature_maps(1, 2, H, seed=8)])     # builds the engine
+        eng = m._engine
+        one_call = eng._render_one_call
+        eng._render_one_call = lambda *a, **k: (calls.append(1), one_call(*a, **k))[1]
+        out = m(to_device(inp, dev, cameras_on_host=True), z=[t.to(dev) for t in z])
+    torch.cuda.synchronize()
+    assert not calls, "this pyramid must not reach the one-call route"
+    with torch.no_grad():
+        ora = O.render_forward(sd, inp, z, O.RenderConfig(n_view=2, npoints=P, H=H, W=H))
+    for k in ("rgb", "depth_ray", "at_wt"):
+        e = err_stats(out[k].cpu(), ora[k])
+        assert e["max"] <= TOL, (k, e)
+    assert torch.equal(out["valid_mask"].cpu(), ora["valid_mask"])
+
+
 # ----------------------------------------------------------------------------------------------------------
 # config C3 at its size: 12 scenes per call
 # ----------------------------------------------------------------------------------------------------------
