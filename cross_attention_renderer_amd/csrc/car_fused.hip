@@ -85,7 +85,7 @@ __device__ __forceinline__ int chunk_tiles(int g) {
 // 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers, 5 the gather alone (no e-path MFMAs, no weight DMA, no
 // barriers); probes of the texture-address path on top of 5: 6 odd rows masked off (whole quads of lanes inactive), 7 odd channel
 // quads masked off (half of every quad of lanes inactive); 11 the full kernel without the barrier of the weight stream (racy);
-// 12 = 3 + no A-operand reads from LDS (matrix pipe + VALU only);
+// 12 = 3 + no A-operand reads from LDS (matrix pipe + VALU only); 13 the full kernel without the A-operand reads;
 // 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val)
 template <int ABL>
 __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
@@ -429,7 +429,7 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     switch (abl) {
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 5: kern = fused_kernel<5>; break;   case 6: kern = fused_kernel<6>; break;   case 7: kern = fused_kernel<7>; break;
-        case 8: kern = fused_kernel<8>; break;   case 11: kern = fused_kernel<11>; break;   case 12: kern = fused_kernel<12>; break;
+        case 8: kern = fused_kernel<8>; break;   case 11: kern = fused_kernel<11>; break;   case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;
         case 14: kern = fused_kernel<14>; break;   case 15: kern = fused_kernel<15>; break;
         case 4: kern = fused_kernel<4>; break;
         default: break;

@@ -109,7 +109,7 @@ __device__ __forceinline__ float sample_max(const f32x4 (&v)[NT]) {
 template <int ABL = 0>
 __device__ __forceinline__ void mfma_pair(f32x4& c0, f32x4& c1, const float* w0, const float* w1, const half8& bhi, const half8& blo) {
     half8 ah0, ah1, al0, al1;
-    if constexpr (ABL == 12) { ah0 = bhi; ah1 = blo; al0 = blo; al1 = bhi; }        // development build: no A-operand reads from LDS
+    if constexpr (ABL == 12 || ABL == 13) { ah0 = bhi; ah1 = blo; al0 = blo; al1 = bhi; }        // development build: no A-operand reads from LDS
     else {
         ah0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0));
         ah1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1));

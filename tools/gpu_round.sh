@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q --timeout 600 -k "common_lattice or one_call_route" > gpurun_out/r2_pytest12.log 2>&1; echo "pytest rc=$?"
-grep -E "passed|failed|Error|assert" gpurun_out/r2_pytest12.log | head -20
+timeout 600 python tools/bench_fused.py 0 13 > gpurun_out/r2_bench_fused13.log 2>&1; echo "bench_fused rc=$?"
+grep -v amdgpu gpurun_out/r2_bench_fused13.log | tail -3
