@@ -138,8 +138,8 @@ def gather_stage(model, inp, z, rays: int = CHUNK):
     for _ in range(7):
         a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        eng.gather(maps, grid, rays * P, 0, 0, V, out, C, 0)          # a7: border
-        eng.gather(maps, grid, rays * P, 1, 0, V, out, C, 0)          # a10: zeros
+        eng.gather(maps, grid, rays * P, 0, 0, V, out, C, 0, run=P)   # a7: border
+        eng.gather(maps, grid, rays * P, 1, 0, V, out, C, 0, run=P)   # a10: zeros
         b_.record()
         ev.append((a, b_))
     torch.cuda.synchronize()

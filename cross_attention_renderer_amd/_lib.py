@@ -54,7 +54,7 @@ SIGNATURES = {
     "car_sample_setup": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P,
                                  c_int, c_int, _P, _P]),
     "car_project_points": (c_int, [_P, _P, c_int, c_long, c_int, c_int, c_int, c_int, _P, _P]),
-    "car_gather_bilinear": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_long, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "car_gather_bilinear": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_long, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "car_gather_encode": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_long, _P, c_int, _P]),
     "car_fused_blob_floats": (c_size_t, []),
     "car_fused_bias_floats": (c_size_t, []),

@@ -24,7 +24,7 @@ constexpr int kGRows = 16;          // output rows per workgroup
 // level) into LDS, then every thread moves float4s: 4 tap reads (L2 / Infinity Cache resident maps), one 16-byte store.
 // The stage is bound by the HBM write of the gathered rows.
 __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps, const float* __restrict__ grid,
-                                                     long pts, int mode, int place, int V, float* __restrict__ out,
+                                                     long pts, int run, int mode, int place, int V, float* __restrict__ out,
                                                      int ld_out, int col_out) {
     __shared__ int s_idx[kGRows][CAR_MAX_LEVELS][4];
     __shared__ float s_w[kGRows][CAR_MAX_LEVELS][4];
@@ -32,11 +32,28 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps,
     const int qpr = L.q0[L.n_levels];
     const long total_rows = (long)n_maps * pts;
     const int tid = threadIdx.x;
-    for (long row0 = (long)blockIdx.x * kGRows; row0 < total_rows; row0 += (long)gridDim.x * kGRows) {
+    // A work group's 16 rows: 16 consecutive points (run == 1), or the same step of 16 neighbouring rays when the points of a map
+    // are rays x `run` steps — neighbouring rays sample neighbouring texels, so their taps share cache lines.
+    const long rays = pts / run, rblocks = (rays + kGRows - 1) / kGRows;
+    const long groups = run > 1 ? (long)n_maps * rblocks * run : (total_rows + kGRows - 1) / kGRows;
+    __shared__ bool s_live[kGRows];
+    for (long gidx = blockIdx.x; gidx < groups; gidx += gridDim.x) {
         if (tid < kGRows * L.n_levels) {
             const int rl = tid / L.n_levels, l = tid % L.n_levels;
-            long mp = row0 + rl;
-            if (mp >= total_rows) mp = total_rows - 1;
+            long mp;
+            bool live_row;
+            if (run > 1) {
+                const long p = gidx % run, rb = (gidx / run) % rblocks, mm = gidx / (run * rblocks);
+                long ray = rb * kGRows + rl;
+                live_row = ray < rays;
+                if (!live_row) ray = rays - 1;
+                mp = mm * pts + ray * run + p;
+            } else {
+                mp = gidx * kGRows + rl;
+                live_row = mp < total_rows;
+                if (!live_row) mp = total_rows - 1;
+            }
+            if (l == 0) s_live[rl] = live_row;
             const int m = (int)(mp / pts);
             int tidx[4];
             float tw[4];
@@ -65,7 +82,7 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps,
                 const int item = it0 + u * 256;
                 const int ci = item < n_items ? item : tid;             // clamp: harmless duplicate read, store masked
                 const int rl = ci / qpr, q = ci % qpr;
-                ok[u] = item < n_items && row0 + rl < total_rows;
+                ok[u] = item < n_items && s_live[rl];
                 int l = 0;
                 while (l + 1 < L.n_levels && q >= L.q0[l + 1]) ++l;
                 const float* base = L.map[l] + 4 * (q - L.q0[l]);
@@ -99,7 +116,7 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps,
 }  // namespace
 
 extern "C" int car_gather_bilinear(const float* const* maps, const int* level_c, const int* level_h,
-                                   const int* level_w, int n_levels, int n_maps, const float* grid, long pts, int mode,
+                                   const int* level_w, int n_levels, int n_maps, const float* grid, long pts, int run, int mode,
                                    int place, int V, float* out, int ld_out, int col_out, void* stream) {
     CAR_REQUIRE(maps && level_c && level_h && level_w && grid && out, "car_gather_bilinear: null pointer");
     CAR_REQUIRE(n_levels > 0 && n_levels <= CAR_MAX_LEVELS && n_maps > 0 && pts > 0, "car_gather_bilinear: bad sizes");
@@ -121,10 +138,11 @@ extern "C" int car_gather_bilinear(const float* const* maps, const int* level_c,
     CAR_REQUIRE(ld_out % 4 == 0 && col_out % 4 == 0 && col_out >= 0 && col_out + 4 * q <= ld_out,
                 "car_gather_bilinear: output window [%d,%d) must be float4-aligned inside a row of %d", col_out, col_out + 4 * q, ld_out);
     CAR_REQUIRE((long)n_maps * level_h[0] * level_w[0] < 2147483647L, "car_gather_bilinear: map too large for 32-bit texel indices");
-    const long groups = ((long)n_maps * pts + kGRows - 1) / kGRows;
+    if (run < 1 || pts % run != 0) run = 1;
+    const long groups = run > 1 ? (long)n_maps * ((pts / run + kGRows - 1) / kGRows) * run : ((long)n_maps * pts + kGRows - 1) / kGRows;
     const unsigned blocks = (unsigned)(groups < 65536 ? groups : 65536);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L, n_maps, grid, pts, mode,
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L, n_maps, grid, pts, run, mode,
                        place, V, out, ld_out, col_out);
     CAR_CHECK_LAUNCH("car_gather_bilinear");
     return CAR_OK;

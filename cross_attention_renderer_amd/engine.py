@@ -425,13 +425,13 @@ class RenderEngine:
                                        flags | self.linear_flags, _stream()), "car_linear")
 
     def gather(self, maps: List[Tensor], grid: Tensor, pts: int, mode: int, place: int, V: int, out: Tensor,
-               ld_out: int, col_out: int):
+               ld_out: int, col_out: int, run: int = 1):
         L = len(maps)
         ptrs = (ctypes.c_void_p * L)(*[m.data_ptr() for m in maps])
         cs = (ctypes.c_int * L)(*[m.shape[3] for m in maps])
         hs = (ctypes.c_int * L)(*[m.shape[1] for m in maps])
         ws = (ctypes.c_int * L)(*[m.shape[2] for m in maps])
-        _lib.check(self.lib.car_gather_bilinear(ptrs, cs, hs, ws, L, maps[0].shape[0], _ptr(grid), pts, mode, place, V,
+        _lib.check(self.lib.car_gather_bilinear(ptrs, cs, hs, ws, L, maps[0].shape[0], _ptr(grid), pts, run, mode, place, V,
                                                 _ptr(out), ld_out, col_out, _stream()), "car_gather_bilinear")
 
     # ------------------------------------------------------------------ the forward pass
@@ -521,11 +521,11 @@ class RenderEngine:
             del h1
             Ce = V * (C // 2)
         elif concat2:
-            self.gather(maps, pixel_val, R * P, 0, PLACE_OWN, V, x1, ld1, 0)
+            self.gather(maps, pixel_val, R * P, 0, PLACE_OWN, V, x1, ld1, 0, run=P)
             gi = grid_in.view(b, V, R, P, V, 2)
             # pixel_val_stack (models.py:316): map (b, s) is sampled where the *other* line's points land in view s
             grid_other = torch.stack([gi[:, 1, :, :, 0], gi[:, 0, :, :, 1]], dim=1).contiguous()
-            self.gather(maps, grid_other, R * P, 1, PLACE_OTHER2, V, x1, ld1, 0)
+            self.gather(maps, grid_other, R * P, 1, PLACE_OTHER2, V, x1, ld1, 0, run=P)
             h1 = torch.empty(S * V, C, **f32)
             self.linear(x1, ld1, pk["query_encode_latent"], h1, C, S * V, RELU_OUT)
             e = torch.empty(S, V * (C // 2), **f32)
@@ -536,13 +536,13 @@ class RenderEngine:
             e = self._encode_three_views(maps, poses, pixel_val, x1, pt_in, b, R, P, H, W, C, pk)
             Ce = 3 * (C // 2)
         elif single:
-            self.gather(maps, pixel_val, R * P, 0, PLACE_PLAIN, V, x1, ld1, 0)
+            self.gather(maps, pixel_val, R * P, 0, PLACE_PLAIN, V, x1, ld1, 0, run=P)
             e = torch.empty(S, C, **f32)
             self.linear(x1, ld1, pk["update_val_merge"], e, C, S)
             Ce = C
         else:
             e = torch.empty(S, C, **f32)
-            self.gather(maps, pixel_val, R * P, 0, PLACE_PLAIN, V, e, C, 0)
+            self.gather(maps, pixel_val, R * P, 0, PLACE_PLAIN, V, e, C, 0, run=P)
             Ce = C
         del x1
 
@@ -575,7 +575,7 @@ class RenderEngine:
         pe = ptenc.view(b, V, pts, V, 4)                    # tanh(nan_to_num(T_s pt)/5): [scene, context, point, frame s]
         pin = pt_in.view(b, V, pts, V, 3)
         tmp = torch.empty(S, C, **f32)
-        self.gather(maps, pixel_val, pts, 0, PLACE_PLAIN, V, tmp, C, 0)
+        self.gather(maps, pixel_val, pts, 0, PLACE_PLAIN, V, tmp, C, 0, run=P)
         x3v[:, :, :, 0, :C] = tmp.view(b, V, pts, C)
         per_view = [[t.view(b, V, *t.shape[1:])[:, o].contiguous() for t in maps] for o in range(V)]
         tmp2 = torch.empty(b * pts, C, **f32)
@@ -589,7 +589,7 @@ class RenderEngine:
                 q = pin[:, o, :, c, :].contiguous()         # context o's points expressed in frame c
                 _lib.check(self.lib.car_project_points(_ptr(poses), _ptr(q), b, pts, V, o, H, W, _ptr(grid), _stream()),
                            "car_project_points")
-                self.gather(per_view[o], grid, pts, 1, PLACE_PLAIN, 1, tmp2, C, 0)
+                self.gather(per_view[o], grid, pts, 1, PLACE_PLAIN, 1, tmp2, C, 0, run=P)
                 x3v[:, c, :, k, :C] = tmp2.view(b, pts, C)
                 x3v[:, c, :, k, C:C + 3] = pe[:, o, :, c, :3]
                 k += 1

@@ -99,9 +99,12 @@ int car_project_points(const float* poses, const float* pts, int n_scenes, long 
  *   PLAIN : m*pts + i
  *   OWN   : (m*pts + i)*V + (m % V)                              (own-view features, source slot = own view)
  *   OTHER2: ((b*2 + (1-s))*pts + i)*2 + s  with m = b*2+s         (V == 2: features of view s for the other line)
- * of `out` (row stride ld_out floats) starting at column col_out. */
+ * of `out` (row stride ld_out floats) starting at column col_out.
+ * run: when the points of a map are rays x `run` samples (point = ray*run + sample), a work group gathers the same sample of 16
+ * neighbouring rays — their taps share cache lines; 1 = no such structure (any other value that does not divide pts is treated as 1).
+ * The result does not depend on it. */
 int car_gather_bilinear(const float* const* maps, const int* level_c, const int* level_h, const int* level_w,
-                        int n_levels, int n_maps, const float* grid, long pts, int mode, int place, int V,
+                        int n_levels, int n_maps, const float* grid, long pts, int run, int mode, int place, int V,
                         float* out, int ld_out, int col_out, void* stream);
 
 /* ---- a7 + a10 + first layer of a11, fused through linearity (models.py:278, 317, 330-341).

@@ -104,6 +104,12 @@ def test_gather_matches_grid_sample():
         got = out.cpu().view(n, pts, 32)
         assert (got[..., 4:4 + Ct] - want).abs().max() < 1e-5, name
         assert (got[..., :4] == -7).all() and (got[..., 4 + Ct:] == -7).all()
+        # the same points declared as rays x samples (a work group takes one sample of 16 neighbouring rays; 700 = 35 rays x 20,
+        # 28 x 25: ragged last ray block): another order of the same rows, bit-identical; a run that does not divide pts is ignored
+        for run in (20, 25, 700, 13):
+            out2 = torch.full((n * pts, 32), -7.0, device=dev)
+            eng.gather(maps, grid.to(dev), pts, mode, 0, 1, out2, 32, 4, run=run)
+            assert torch.equal(out2, out), (name, run)
 
 
 @pytest.mark.parametrize("name", ["t0_default", "t0_query_at_ctx0", "t0_diverging", "t1_c1", "t2_c5", "t0_no_sample", "t0_nview1"])

@@ -28,10 +28,10 @@ def main():
     out = torch.empty(V * R * P, C, device=dev)
     for mode, name in ((0, "border"), (1, "zeros")):
         for _ in range(2):
-            eng.gather(maps, grid, R * P, mode, 0, V, out, C, 0)
+            eng.gather(maps, grid, R * P, mode, 0, V, out, C, 0, run=P)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
         for s, e in ev:
-            s.record(); eng.gather(maps, grid, R * P, mode, 0, V, out, C, 0); e.record()
+            s.record(); eng.gather(maps, grid, R * P, mode, 0, V, out, C, 0, run=P); e.record()
         torch.cuda.synchronize()
         ms = sorted(s.elapsed_time(e) for s, e in ev)[5]
         nbytes = out.numel() * 4 + sum(m.numel() * 4 for m in maps)

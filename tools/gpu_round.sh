@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 600 python tools/bench_fused.py 0 13 > gpurun_out/r2_bench_fused13.log 2>&1; echo "bench_fused rc=$?"
-grep -v amdgpu gpurun_out/r2_bench_fused13.log | tail -3
+python tools/bw_probe.py 2>&1 | grep -v amdgpu | tail -4
