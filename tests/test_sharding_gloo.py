@@ -70,3 +70,32 @@ def test_ray_bands_partition_exactly():
             assert all(bands[i][1] == bands[i + 1][0] for i in range(w - 1))
             sizes = [e - s for s, e in bands]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.gpu
+def test_tile_gather_over_rccl_single_rank():
+    """The RCCL branch of TileGather (all_gather_into_tensor on a side stream, the path bench.py --gpus N takes) with a one-rank
+    "nccl" group on the one GPU of the test box: API shapes, stream hand-over and buffer reuse; plus shard_query / gather_rays."""
+    if dist.is_initialized():
+        pytest.skip("a process group is already up in this process")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda:0")
+        tg = Sh.TileGather(1, 4096, 5, dev)
+        for it in range(3):
+            t = torch.full((4096, 5), float(it + 1), device=dev)
+            tg(t)
+            t.zero_()                                   # the caller may overwrite its tile right away
+            out = tg.wait()
+            torch.cuda.synchronize()
+            assert out.shape == (1, 4096, 5) and (out == it + 1).all()
+        uv = torch.rand(2, 1, 65, 2, device=dev) * 100
+        inp = {"context": {"rgb": torch.zeros(2, 2, 4, 4, 3, device=dev)}, "query": {"uv": uv}}
+        shard, (s, e) = Sh.shard_query(inp, 0, 1)
+        assert (s, e) == (0, 65)
+        tile = Sh.pack_tile(_fake_render(shard["query"]["uv"]))
+        assert torch.equal(Sh.gather_rays(tile, 65), tile)
+    finally:
+        dist.destroy_process_group()
