@@ -102,14 +102,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     // 192 samples = 48 consecutive rays x 4 consecutive steps: wave = (bundle of 16 rays, step), lane & 15 = ray of the bundle, so the
     // 16 rows a wave gathers together are the same step of neighbouring rays (shared texel rows)
     const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + kBundles * kRows - 1) / (kBundles * kRows);
-    int pg = blk % pgs, bun = (blk / pgs) % bundles;
-    const int nn = blk / (pgs * bundles);
-    if constexpr (ABL == 14) { bun = blk % bundles; pg = (blk / bundles) % pgs; }      // development build: neighbouring bundles first
-    if constexpr (ABL == 15) {                                                       // ... in runs of 16 bundles (3 image rows of 256)
-        const int local = blk % (pgs * bundles), run = local / (16 * pgs), in = local % (16 * pgs);
-        bun = run * 16 + in % 16; pg = in / 16;
-        if (bun >= bundles) { bun = bundles - 1; }
-    }
+    const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
     const int ray_i = bun * (kBundles * kRows) + (wave / kStepsPerGroup) * kRows + s, pp = pg * kStepsPerGroup + wave % kStepsPerGroup;
     const bool live = ray_i < a.R && pp < a.P;
     const long i = ((long)nn * a.R + (ray_i < a.R ? ray_i : a.R - 1)) * a.P + (pp < a.P ? pp : a.P - 1);
@@ -430,7 +423,6 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 5: kern = fused_kernel<5>; break;   case 6: kern = fused_kernel<6>; break;   case 7: kern = fused_kernel<7>; break;
         case 8: kern = fused_kernel<8>; break;   case 11: kern = fused_kernel<11>; break;   case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;
-        case 14: kern = fused_kernel<14>; break;   case 15: kern = fused_kernel<15>; break;
         case 4: kern = fused_kernel<4>; break;
         default: break;
     }

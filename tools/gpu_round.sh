@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_sharding_gloo.py -m gpu -q --timeout 600 > gpurun_out/r2_pytest14.log 2>&1; echo "pytest rc=$?"
-grep -E "passed|failed|Error|assert" gpurun_out/r2_pytest14.log | head -20
+timeout 600 python tools/bench_fused.py 0 16 17 0 > gpurun_out/r2_bench_fused14.log 2>&1; echo "bench_fused rc=$?"
+grep -v amdgpu gpurun_out/r2_bench_fused14.log | tail -4
