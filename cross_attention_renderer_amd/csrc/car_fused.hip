@@ -25,6 +25,8 @@ constexpr int kWaves = 12, kRows = 16, kGroup = kWaves * kRows;      // 192 samp
 constexpr int kStepsPerGroup = 4, kBundles = kWaves / kStepsPerGroup;  // 3 bundles of 16 rays x 4 steps
 
 constexpr int kPieces = 3;                         // LDS-DMA pieces per chunk: 12 waves x 1 KB each
+constexpr unsigned kDeadTap = 0xfffffe00u;         // tap-table entry of a sample that reads exact zeros: beyond any map, no wrap with the column offset
+constexpr long kMaxMapBytes = 0xfffff000L;         // a map of one call stays below it
 
 #include "car_fused_mma.h"
 
@@ -48,6 +50,7 @@ struct FusedArgs {
     int lh, lw, pad;
     float sx, sy;              // lattice coordinate u = (x + 1) * sx - 1: width / height of the finest of the merged levels
     int fh, fw;
+    unsigned gbytes[2];        // sizes of the two maps of this call: the range of the gather's buffer loads
     const float* gmeta;        // [2] max |lattice|, max |finest level| (car_project_maps)
     const float* wpt;
     const float* blob;
@@ -146,14 +149,20 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
                 int node, flags;
                 float w[4];
                 car_lattice_taps(gx, gy, a.lw, a.lh, a.pad, a.sx, a.sy, &node, &flags, w);
-                tb[0] = (unsigned)((m * 2 + mode) * a.lh * a.lw + node) * (unsigned)(kC * 4) | (unsigned)flags;
-                *reinterpret_cast<float4*>(tw) = make_float4(w[0], w[1], w[2], w[3]);
+                // zeros padding, point on or beyond the outer ring: the four nodes are exactly zero.  Such a sample (its projection
+                // misses the other view: a third of them on a wide-baseline pair) gets the out-of-range offset kDeadTap: the buffer
+                // loads of its lanes return zeros without touching memory, and weight zero makes the contribution exactly +-0
+                const bool dead = mode == 1 && (flags & 4);
+                tb[0] = dead ? kDeadTap : (unsigned)((m * 2 + mode) * a.lh * a.lw + node) * (unsigned)(kC * 4) | (unsigned)(flags & 3);
+                *reinterpret_cast<float4*>(tw) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w[0], w[1], w[2], w[3]);
             }
             {   // the finest level: (x0|x1, y0|y1) after clamping, weight 0 for a tap outside the map
                 int idx[4];
                 float w[4];
                 car_bilinear_taps(gx, gy, a.fw, a.fh, mode, idx, w);
-                tb[1] = (unsigned)(m * a.fh * a.fw + idx[0]) * (unsigned)(kC * 4) | (idx[1] != idx[0] ? 1u : 0u) | (idx[2] != idx[0] ? 2u : 0u);
+                const bool dead = w[0] == 0.0f && w[1] == 0.0f && w[2] == 0.0f && w[3] == 0.0f;      // every tap outside the map: nothing to fetch
+                tb[1] = dead ? kDeadTap
+                             : (unsigned)(m * a.fh * a.fw + idx[0]) * (unsigned)(kC * 4) | (idx[1] != idx[0] ? 1u : 0u) | (idx[2] != idx[0] ? 2u : 0u);
                 *reinterpret_cast<float4*>(tw + 4) = make_float4(w[0], w[1], w[2], w[3]);
             }
             const float px = sv == 0 ? smp.pt_in[0][0] : smp.pt_in[1][0], py = sv == 0 ? smp.pt_in[0][1] : smp.pt_in[1][1],
@@ -185,20 +194,25 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     const unsigned qd16 = 16u * qd;
     const unsigned row_step[2] = {(unsigned)a.lw * (kC * 4), (unsigned)a.fw * (kC * 4)};
 
+    // Buffer loads (range-checked against the map's size): a lane whose offset is kDeadTap gets zeros and costs no memory access.
+    const __amdgpu_buffer_rsrc_t rsrc[2] = {
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gmap[0]), 0, (int)a.gbytes[0], 0x00027000),
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gmap[1]), 0, (int)a.gbytes[1], 0x00027000)};
     auto issue_row = [&](f32x4 (&tap)[4], int sv, int c, int l, int it) {
         if constexpr (ABL == 1 || ABL == 2 || ABL == 3 || ABL == 12) return;
         if constexpr (ABL == 6) { if (r0 & 1) return; }
         if constexpr (ABL == 7) { if (qd & 1) return; }
-        const char* base = reinterpret_cast<const char*>(a.gmap[l] + 32 * c);
+        const int chunk_off = 128 * c;                                 // the chunk's 32 channels: scalar offset, not range-checked
         // ABL 8: lane = (sample s, k group q4) as the MFMA's B operand wants it, the two row groups become the two 16-byte pieces
         const int row = ABL == 8 ? s : r0 + 8 * it;
         const unsigned col = ABL == 8 ? 16u * q4 + 64u * it : qd16;
         const unsigned tbv = reinterpret_cast<const unsigned*>(lds + kLdsTapB)[((wave * kRows + row) * 2 + sv) * 2 + l];
         const unsigned o00 = (tbv & ~3u) + col, dx = (tbv & 1u) ? (unsigned)(kC * 4) : 0u, dy = (tbv & 2u) ? row_step[l] : 0u;
-        tap[0] = *reinterpret_cast<const f32x4*>(base + o00);
-        tap[1] = *reinterpret_cast<const f32x4*>(base + (o00 + dx));
-        tap[2] = *reinterpret_cast<const f32x4*>(base + (o00 + dy));
-        tap[3] = *reinterpret_cast<const f32x4*>(base + (o00 + dx + dy));
+        auto ld = [&](unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc[l], (int)off, chunk_off, 0)); };
+        tap[0] = ld(o00);
+        tap[1] = ld(o00 + dx);
+        tap[2] = ld(o00 + dy);
+        tap[3] = ld(o00 + dx + dy);
     };
     auto blend_row = [&](const f32x4 (&tap)[4], int sv, int l, int it) {
         if constexpr (ABL == 2 || ABL == 3 || ABL == 12) return;
@@ -405,12 +419,13 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     CAR_REQUIRE(lat_pad >= 2 && lat_h > 2 * lat_pad + 1 && lat_w > 2 * lat_pad + 1 && ((lat_h - 2 * lat_pad) & 1) && ((lat_w - 2 * lat_pad) & 1),
                 "car_fused_samples: bad lattice %d x %d, pad %d (car_lattice_shape)", lat_h, lat_w, lat_pad);
     // nodes and texels are addressed by 32-bit byte offsets inside their map; hosts with more scenes render them in groups (engine.py)
-    CAR_REQUIRE(fine_h > 0 && fine_w > 0 && (long)b * V * 2 * lat_h * lat_w * (kC * 4) < 4294967296L && (long)b * V * fine_h * fine_w * (kC * 4) < 4294967296L,
+    CAR_REQUIRE(fine_h > 0 && fine_w > 0 && (long)b * V * 2 * lat_h * lat_w * (kC * 4) < kMaxMapBytes && (long)b * V * fine_h * fine_w * (kC * 4) < kMaxMapBytes,
                 "car_fused_samples: the lattice and the finest level of one call must each stay below 4 GiB (render fewer scenes per call)");
     FusedArgs a;
     a.poses = (const CarPose*)poses; a.rays = (const CarRay*)rays; a.steps = steps;
     a.gmap[0] = lattice; a.lh = lat_h; a.lw = lat_w; a.pad = lat_pad;
     a.gmap[1] = fine; a.fh = fine_h; a.fw = fine_w;
+    a.gbytes[0] = (unsigned)((long)b * V * 2 * lat_h * lat_w * (kC * 4)); a.gbytes[1] = (unsigned)((long)b * V * fine_h * fine_w * (kC * 4));
     a.sx = (float)((lat_w - 2 * lat_pad + 1) / 2); a.sy = (float)((lat_h - 2 * lat_pad + 1) / 2);
     a.gmeta = gmeta; a.wpt = wpt; a.blob = blob; a.bias = bias;
     a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;

@@ -85,7 +85,7 @@ class RenderEngine:
         self.fuse_round2 = True        # staged route: round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
         # sizing of the one-call route (tests shrink them to force several calls)
         self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
-        self.max_level_bytes = (1 << 32) - 1               # lattice / finest level of one call: the fused kernel's 32-bit node offsets
+        self.max_level_bytes = 0xfffff000 - 1              # lattice / finest level of one call: the fused kernel's 32-bit node offsets
         self.last_calls = 0            # number of car_render_forward calls the last forward was split into
         self._round2_key = None
         self._round2 = None

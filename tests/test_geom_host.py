@@ -147,9 +147,14 @@ def test_merged_lattice_equals_the_sum_of_the_levels(shim, sizes):
     shim.host_lattice_taps.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     shim.host_lattice_taps(_ptr(gnp), n, lw, lh, pad, float(wm), float(hm), _ptr(node), _ptr(flags), _ptr(w))
-    assert node.min() >= 0 and (node + (flags & 1) + (flags >> 1) * lw).max() < lh * lw
+    east, south, ring = flags & 1, (flags >> 1) & 1, (flags >> 2) & 1
+    assert node.min() >= 0 and (node + east + south * lw).max() < lh * lw
     assert np.all(np.abs(w.sum(1) - 1.0) < 1e-6) and w.min() >= 0.0
-    idx = np.stack([node, node + (flags & 1), node + (flags >> 1) * lw, node + (flags & 1) + (flags >> 1) * lw], 1)
+    idx = np.stack([node, node + east, node + south * lw, node + east + south * lw], 1)
+    # bit 2: on or beyond the outer ring, where the zeros-padding lattice is exactly zero (the fused kernel does not fetch those taps)
+    assert ring[0] == 1 and ring[2] == 1 and 0 < ring.mean() < 0.5
+    # (a tap with a non-zero value there is the far one of a point clamped onto the ring: its weight is exactly zero)
+    assert (lat[1].reshape(lh * lw, Cc)[idx[ring == 1]] * w[ring == 1][..., None] == 0).all()
     for mode, name in ((0, "border"), (1, "zeros")):
         flat = torch.as_tensor(lat[mode].reshape(lh * lw, Cc))
         got = (flat[torch.as_tensor(idx).long()] * torch.as_tensor(w)[..., None]).sum(1)
