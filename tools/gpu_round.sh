@@ -1,4 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python tools/bench_fused.py 5 6 7 > gpurun_out/r2_bench_fused16.log 2>&1; echo "bench_fused rc=$?"
-grep -v amdgpu gpurun_out/r2_bench_fused16.log | tail -3
+bash tools/profile_bench.sh round2 > gpurun_out/profile_round2.log 2>&1; echo "profile rc=$?"
+tail -6 gpurun_out/profile_round2.log
+bash tools/pmc_fused.sh 0 > gpurun_out/pmc_fused_round2.log 2>&1; echo "pmc rc=$?"
+timeout 600 python bench.py > gpurun_out/r2_bench_final.log 2>&1; echo "bench rc=$?"
+grep -v amdgpu gpurun_out/r2_bench_final.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms'], d['gather_stage']['frac'])"
+head -30 gpurun_out/prof_round2_summary.md
