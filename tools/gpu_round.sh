@@ -1,8 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-bash tools/profile_bench.sh round2 > gpurun_out/profile_round2.log 2>&1; echo "profile rc=$?"
-tail -6 gpurun_out/profile_round2.log
-bash tools/pmc_fused.sh 0 > gpurun_out/pmc_fused_round2.log 2>&1; echo "pmc rc=$?"
-timeout 600 python bench.py > gpurun_out/r2_bench_final.log 2>&1; echo "bench rc=$?"
-grep -v amdgpu gpurun_out/r2_bench_final.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['stage_ms'], d['gather_stage']['frac'])"
-head -30 gpurun_out/prof_round2_summary.md
+timeout 1500 python tools/validate_frame.py 0.5 0.1 2>/dev/null | grep -v amdgpu > gpurun_out/round2_whole_frame_parity.md; echo "validate rc=$?"
+cat gpurun_out/round2_whole_frame_parity.md
