@@ -4,8 +4,10 @@
 
 A *step* renders one full 256x256 query frame (65 536 rays, 64 samples per view, 2 context views = config
 "RealEstate10K pair 256x256, 64 samples") of a camera trajectory between the two context views: EVERY step has its own query
-pose, so the per-frame pose algebra (car_pose_setup on the device: the cameras are resident there, nothing crosses the bus) is
-inside the timed region, as in the reference's render loop (render_realestate10k_traj.py:118-137).  Inputs are synthetic
+pose, so the per-frame pose algebra is inside the timed region, as in the reference's render loop
+(render_realestate10k_traj.py:118-137): by default the reference's own torch.inverse calls on the host CPU and a 768-byte pinned
+upload queued behind the previous frame (the path whose results the parity tests pin at 1e-4 against the oracle);
+``--cameras device`` keeps the cameras on the GPU and runs car_pose_setup there instead (same frame time).  Inputs are synthetic
 (seeded stereo pair, N(0,1) feature pyramid, perturbed default-init weights), resident in HBM before the timed region;
 ``get_z`` (the image encoder) is excluded on both sides, as in BASELINE.md.
 
@@ -65,7 +67,7 @@ def make_frame(alpha: float, device):
     return inp, z
 
 
-def trajectory(n_frames: int, device, band=None):
+def trajectory(n_frames: int, device, band=None, cameras_on_host: bool = False):
     """``n_frames`` input dicts of the same stereo pair, query pose moving from one context camera towards the other;
     ``band`` = (start, end) restricts the rays (this rank's share of the frame)."""
     base, _ = make_frame(0.5, None)
@@ -73,8 +75,9 @@ def trajectory(n_frames: int, device, band=None):
     for i in range(n_frames):
         inp, _ = make_frame((i + 0.5) / n_frames, None)
         uv = base["query"]["uv"] if band is None else base["query"]["uv"][:, :, band[0]:band[1]].contiguous()
-        frames.append({"context": {k: v.to(device) for k, v in base["context"].items()},
-                       "query": {"cam2world": inp["query"]["cam2world"].to(device), "intrinsics": inp["query"]["intrinsics"].to(device),
+        cam = (lambda t: t) if cameras_on_host else (lambda t: t.to(device))
+        frames.append({"context": {k: (cam(v) if k in ("cam2world", "intrinsics") else v.to(device)) for k, v in base["context"].items()},
+                       "query": {"cam2world": cam(inp["query"]["cam2world"]), "intrinsics": cam(inp["query"]["intrinsics"]),
                                  "uv": uv.to(device)}})
     return frames
 
@@ -177,6 +180,9 @@ def main():
     ap.add_argument("--chunk-rays", type=int, default=65536,
                     help="rays per forward call: the whole frame (or band) by default (a 288 GB GPU does not need the reference render script's 8192-ray chunks; --chunk-rays 8192 reproduces them)")
     ap.add_argument("--no-extras", action="store_true", help="skip the gather-stage and frame-per-rank measurements")
+    ap.add_argument("--cameras", choices=("host", "device"), default="host",
+                    help="where the camera matrices live: host = the reference's own torch.inverse on the CPU per frame + a 768-byte "
+                         "upload (the arithmetic the parity tests pin; default); device = car_pose_setup per frame (no host work)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the multi-rank code path)")
     ap.add_argument("--device", type=int, default=None, help="device index for every rank (smoke tests of the multi-rank path on one GPU; default LOCAL_RANK)")
     args = ap.parse_args()
@@ -211,7 +217,7 @@ def main():
     band = ray_band(R_frame, rank, world)
     R = band[1] - band[0]
     n_frames = args.steps + args.warmup
-    frames = trajectory(n_frames, dev, band if world > 1 else None)
+    frames = trajectory(n_frames, dev, band if world > 1 else None, args.cameras == "host")
     tile = torch.empty(R, 5, device=dev)
     gather = TileGather(world, -(-R_frame // world), 5, dev) if world > 1 else None
     if gather is not None and R != -(-R_frame // world):
@@ -233,7 +239,7 @@ def main():
         per_rank = None
         if world > 1 and not args.no_extras:
             k2 = max(2, args.steps // 2)
-            full = trajectory(k2, dev, None)
+            full = trajectory(k2, dev, None, args.cameras == "host")
             tile2 = torch.empty(R_frame, 5, device=dev)
             g2 = TileGather(world, R_frame, 5, dev)
             render_frame(model, full[0], z, tile2, args.chunk_rays)
@@ -297,7 +303,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32 (split-f16 x3 MFMA)", "data": "synthetic",
-            "config": {"workload": f"256x256 query frame, 64 samples/view, 2 context views (config 2), a new query pose every step, "
+            "config": {"workload": f"256x256 query frame, 64 samples/view, 2 context views (config 2), a new query pose every step (cameras on the {args.cameras}), "
                                    f"{-(-R // args.chunk_rays)} forward call(s) x {min(args.chunk_rays, R)} rays per rank",
                        "rays_per_step": R_frame, "rays_per_step_per_gpu": R,
                        "parallelism": "one GPU" if world == 1 else f"one frame's rays banded over {world} ranks, RCCL all-gather of tiles"},

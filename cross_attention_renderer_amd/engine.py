@@ -202,7 +202,8 @@ class RenderEngine:
             return poses
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts) + (H, str(dev))
         if key != self._pose_key:
-            self._pose_dev = pack_poses(inp, H).to(dev, non_blocking=True)
+            # pinned staging: the 768-byte upload is queued behind the previous frame's kernels instead of waiting for them
+            self._pose_dev = pack_poses(inp, H).pin_memory().to(dev, non_blocking=True)
             self._pose_key = key
             self._pose_src = ts                      # keep the tensors alive so data_ptr cannot be recycled
         return self._pose_dev

@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python tools/validate_frame.py 0.5 0.1 2>/dev/null | grep -v amdgpu > gpurun_out/round2_whole_frame_parity.md; echo "validate rc=$?"
-cat gpurun_out/round2_whole_frame_parity.md
+for cam in host device host device; do
+timeout 600 python bench.py --cpu-rays 0 --no-extras --cameras $cam > gpurun_out/r2_bench_cam_$cam.log 2>&1; echo "bench rc=$?"
+grep -v amdgpu gpurun_out/r2_bench_cam_$cam.log | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$cam', d['value'], d['ms_per_step'], sum(d['stage_ms'].values()))"
+done
