@@ -73,9 +73,9 @@ SIGNATURES = {
     "car_add_ray_bias_relu": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "car_finalize": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "car_chain_packed_floats": (c_size_t, [c_int, c_int]),
-    "car_chain_pack": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
-    "car_ray_mid": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, _P, c_long, _P]),
-    "car_ray_tail": (c_int, [_P, _P, _P, c_int, _P, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
+    "car_chain_pack": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    "car_ray_mid": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, c_long, _P]),
+    "car_ray_tail": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "car_plan_bytes": (c_size_t, [ctypes.POINTER(CarDims)]),
     "car_plan_build": (c_int, [ctypes.POINTER(CarDims), ctypes.POINTER(CarWeights), _P, _P]),
     "car_gmaps_floats": (c_size_t, [ctypes.POINTER(CarDims)]),

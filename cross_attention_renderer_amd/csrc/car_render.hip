@@ -16,12 +16,13 @@ extern "C" size_t car_fused_bias_floats(void);
 extern "C" size_t car_round2_packed_floats(void);
 extern "C" size_t car_round2_bias_floats(void);
 extern "C" size_t car_chain_packed_floats(int K, int N);
-extern "C" int car_chain_pack(const float* W, int ldw, const float* W2, int K, int N, float* packed, void* stream);
-extern "C" int car_ray_mid(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* ebar, int ld_ebar,
-                           float* z1, float* uh, long M, void* stream);
-extern "C" int car_ray_tail(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* ebar, int ld_ebar,
-                            const float* phi_x, int ld_phi, const float* z1, const float* rays, int b, int V, int R, float* rgb, float* valid,
-                            void* stream);
+extern "C" int car_chain_pack(const float* W, int ldw, const float* W2, int K, int N, int chained, float* packed, float* scale, int slot,
+                              void* stream);
+extern "C" int car_ray_mid(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* scale,
+                           const int* layers, int n_layers, const float* ebar, int ld_ebar, float* z1, float* uh, long M, void* stream);
+extern "C" int car_ray_tail(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* scale,
+                            const int* layers, int n_layers, const float* ebar, int ld_ebar, const float* phi_x, int ld_phi, const float* z1,
+                            const float* rays, int b, int V, int R, float* rgb, float* valid, void* stream);
 
 namespace {
 
@@ -193,10 +194,11 @@ Lattice lattice_of(const car_dims& d) {
 }
 // ---- plan layout ---------------------------------------------------------------------------------------------------
 struct Plan {
-    // offsets in floats.  latent_value, lin_in: car_linear_pack layout (inputs read from memory, bias folded); the *_c entries:
-    // car_chain_pack layout (inputs are the previous layer's accumulators, car_raychain.hip); mid_bias / tail_bias: their biases
+    // offsets in floats.  latent_value ... lout_c: car_chain_pack tiles of the per-ray chains (car_raychain.hip; latent_value and lin_in
+    // read their input rows from memory, the *_c layers the previous layer's accumulators); chain_scale: their powers of two;
+    // mid_bias / tail_bias: their biases in consumption order
     size_t steps, blob, fbias, wpt, r2w, r2b, proj[CAR_MAX_LEVELS], latent_value, lin_in, enc_c, qreh_c, lz_c[kBlocks], fc0_c[kBlocks],
-        fc1_c[kBlocks], lout_c, mid_bias, tail_bias, total;
+        fc1_c[kBlocks], lout_c, chain_scale, mid_bias, tail_bias, total;
 };
 Plan plan_layout(const car_dims& d) {
     Plan p;
@@ -209,8 +211,8 @@ Plan plan_layout(const car_dims& d) {
     p.r2w = take(car_round2_packed_floats());
     p.r2b = take(car_round2_bias_floats());
     for (int l = 0; l < CAR_MAX_LEVELS; ++l) p.proj[l] = l < d.n_levels ? take(car_linear_packed_floats(d.level_c[l], kC)) : 0;
-    p.latent_value = take(car_linear_packed_floats(kC, kE));
-    p.lin_in = take(car_linear_packed_floats(kPhiIn, kD));
+    p.latent_value = take(car_chain_packed_floats(kC, kE));
+    p.lin_in = take(car_chain_packed_floats(kPhiIn, kD));
     p.enc_c = take(car_chain_packed_floats(kE, kD));
     p.qreh_c = take(car_chain_packed_floats(kD, kD));
     for (int i = 0; i < kBlocks; ++i) {
@@ -219,8 +221,9 @@ Plan plan_layout(const car_dims& d) {
         p.fc1_c[i] = take(car_chain_packed_floats(kD, kD));
     }
     p.lout_c = take(car_chain_packed_floats(kD, 3));
-    p.mid_bias = take(kD);
-    p.tail_bias = take(3 * kBlocks * kD + 32);
+    p.chain_scale = take(32);
+    p.mid_bias = take(kE + kD);
+    p.tail_bias = take(kE + kD + 3 * kBlocks * kD + 32);
     p.total = o;
     return p;
 }
@@ -488,24 +491,30 @@ extern "C" int car_plan_build(const car_dims* dims, const car_weights* w, void* 
         CAR_TRY(car_linear_pack(w->query_encode_latent_w + coff, kC + 3, nullptr, dims->level_c[l], kC, base + p.proj[l], stream));
         coff += dims->level_c[l];
     }
-    CAR_TRY(car_linear_pack(w->latent_value_w, kC, w->latent_value_b, kC, kE, base + p.latent_value, stream));
-    CAR_TRY(car_linear_pack(w->phi_lin_in_w, kPhiIn, w->phi_lin_in_b, kPhiIn, kD, base + p.lin_in, stream));
-    // the per-ray chains (car_raychain.hip): layers fed from the previous layer's accumulators
-    CAR_TRY(car_chain_pack(w->encode_latent_w, kE, nullptr, kE, kD, base + p.enc_c, stream));
-    CAR_TRY(car_chain_pack(w->query_repeat_embed_w, kD + 16, nullptr, kD, kD, base + p.qreh_c, stream));
+    // the per-ray chains (car_raychain.hip), split-fp16 tiles; scale slots: 0 latent_value, 1 encode_latent, 2 query_repeat_embed[:, :128],
+    // 3 lin_in, 4 + 3 i lin_z_i, 5 + 3 i fc_0_i, 6 + 3 i fc_1_i, 13 lin_out
+    float* cs = base + p.chain_scale;
+    CAR_TRY(car_chain_pack(w->latent_value_w, kC, nullptr, kC, kE, 0, base + p.latent_value, cs, 0, stream));
+    CAR_TRY(car_chain_pack(w->encode_latent_w, kE, nullptr, kE, kD, 1, base + p.enc_c, cs, 1, stream));
+    CAR_TRY(car_chain_pack(w->query_repeat_embed_w, kD + 16, nullptr, kD, kD, 1, base + p.qreh_c, cs, 2, stream));
+    CAR_TRY(car_chain_pack(w->phi_lin_in_w, kPhiIn, nullptr, kPhiIn, kD, 0, base + p.lin_in, cs, 3, stream));
     for (int i = 0; i < kBlocks; ++i) {
-        CAR_TRY(car_chain_pack(w->phi_lin_z_w[i], 2 * kE, w->phi_lin_z_w[i] + kE, kE, kD, base + p.lz_c[i], stream));      // [z, z]: halves added
-        CAR_TRY(car_chain_pack(w->phi_fc_0_w[i], kD, nullptr, kD, kD, base + p.fc0_c[i], stream));
-        CAR_TRY(car_chain_pack(w->phi_fc_1_w[i], kD, nullptr, kD, kD, base + p.fc1_c[i], stream));
+        CAR_TRY(car_chain_pack(w->phi_lin_z_w[i], 2 * kE, w->phi_lin_z_w[i] + kE, kE, kD, 1, base + p.lz_c[i], cs, 4 + 3 * i, stream));   // [z, z]: halves added
+        CAR_TRY(car_chain_pack(w->phi_fc_0_w[i], kD, nullptr, kD, kD, 1, base + p.fc0_c[i], cs, 5 + 3 * i, stream));
+        CAR_TRY(car_chain_pack(w->phi_fc_1_w[i], kD, nullptr, kD, kD, 1, base + p.fc1_c[i], cs, 6 + 3 * i, stream));
     }
-    CAR_TRY(car_chain_pack(w->phi_lin_out_w, kD, nullptr, kD, 3, base + p.lout_c, stream));
-    if (hipMemsetAsync(base + p.tail_bias, 0, sizeof(float) * (3 * kBlocks * kD + 32), st) != hipSuccess) { car_set_error("car_plan_build: memset failed"); return CAR_E_LAUNCH; }
+    CAR_TRY(car_chain_pack(w->phi_lin_out_w, kD, nullptr, kD, 3, 1, base + p.lout_c, cs, 13, stream));
+    const int tail_floats = kE + kD + 3 * kBlocks * kD + 32;
+    if (hipMemsetAsync(base + p.tail_bias, 0, sizeof(float) * tail_floats, st) != hipSuccess) { car_set_error("car_plan_build: memset failed"); return CAR_E_LAUNCH; }
     auto d2d = [&](float* dst, const float* src, int n) { return hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, st) == hipSuccess; };
-    bool ok = d2d(base + p.mid_bias, w->encode_latent_b, kD);
+    bool ok = d2d(base + p.mid_bias, w->latent_value_b, kE) && d2d(base + p.mid_bias + kE, w->encode_latent_b, kD);
+    float* tb = base + p.tail_bias;
+    ok = ok && d2d(tb, w->latent_value_b, kE) && d2d(tb + kE, w->phi_lin_in_b, kD);
+    tb += kE + kD;
     for (int i = 0; i < kBlocks; ++i)
-        ok = ok && d2d(base + p.tail_bias + (3 * i + 0) * kD, w->phi_lin_z_b[i], kD) && d2d(base + p.tail_bias + (3 * i + 1) * kD, w->phi_fc_0_b[i], kD) &&
-             d2d(base + p.tail_bias + (3 * i + 2) * kD, w->phi_fc_1_b[i], kD);
-    ok = ok && d2d(base + p.tail_bias + 3 * kBlocks * kD, w->phi_lin_out_b, 3);
+        ok = ok && d2d(tb + (3 * i + 0) * kD, w->phi_lin_z_b[i], kD) && d2d(tb + (3 * i + 1) * kD, w->phi_fc_0_b[i], kD) &&
+             d2d(tb + (3 * i + 2) * kD, w->phi_fc_1_b[i], kD);
+    ok = ok && d2d(tb + 3 * kBlocks * kD, w->phi_lin_out_b, 3);
     if (!ok) { car_set_error("car_plan_build: bias copy failed"); return CAR_E_LAUNCH; }
     return CAR_OK;
 }
@@ -599,8 +608,9 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
         {   // a15, per ray: z1 = Wv ebar + bv; uh = Wr1[:, :128] encode_latent(z1)
             Stage stage("ray_layers_1", st);
             nch = 0;
-            chunks(p.latent_value, 19, 9); chunks(p.enc_c, 9, 4); chunks(p.qreh_c, 4, 4);
-            CAR_TRY(car_ray_mid(pl, offs, nts, nch, pl + p.mid_bias, ws + w.ebar, kC, ws + w.z1, ws + w.uh, BR, stream));
+            chunks(p.latent_value, 18, 9); chunks(p.enc_c, 9, 4); chunks(p.qreh_c, 4, 4);
+            const int layers[3] = {0, 1, 2};
+            CAR_TRY(car_ray_mid(pl, offs, nts, nch, pl + p.mid_bias, pl + p.chain_scale, layers, 3, ws + w.ebar, kC, ws + w.z1, ws + w.uh, BR, stream));
         }
         {   // a15, per sample: second-round query and logits
             Stage stage("round2_logits", st);
@@ -618,11 +628,12 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
     {   // z = (Wv ebar + bv) + V z1 (models.py:561-565), light-field decoder (resnet_block_fc.py:132-168), valid mask / white background
         Stage stage("ray_layers_2", st);
         nch = 0;
-        chunks(p.latent_value, 19, 9); chunks(p.lin_in, 1, 4);
+        chunks(p.latent_value, 18, 9); chunks(p.lin_in, 1, 4);
         for (int i = 0; i < kBlocks; ++i) { chunks(p.lz_c[i], 9, 4); chunks(p.fc0_c[i], 4, 4); chunks(p.fc1_c[i], 4, 4); }
         chunks(p.lout_c, 4, 1);
-        CAR_TRY(car_ray_tail(pl, offs, nts, nch, pl + p.tail_bias, ws + w.ebar, kC, ws + w.phi_x, kPhiLd, ws + w.z1, ws + w.rays, b, V, R, out->rgb, valid,
-                             stream));
+        const int layers[12] = {0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13};
+        CAR_TRY(car_ray_tail(pl, offs, nts, nch, pl + p.tail_bias, pl + p.chain_scale, layers, 12, ws + w.ebar, kC, ws + w.phi_x, kPhiLd, ws + w.z1,
+                             ws + w.rays, b, V, R, out->rgb, valid, stream));
     }
     return CAR_OK;
 }

@@ -178,24 +178,28 @@ int car_round2_logits(const float* g, const float* uh, const float* qry, const f
 int car_add_ray_bias_relu(float* r, const float* u, int b, int V, int R, int P, int C, void* stream);
 
 /* ---- the per-ray layers as two kernels (csrc/car_raychain.hip): a layer's outputs stay in the MFMA accumulators of the wave that owns
- * the 32 rays and are the next layer's B operands (exact fp32, v_mfma_f32_32x32x2_f32).
- *   car_chain_pack : weights of a layer fed that way, K order of the accumulator layout, no bias column; W2 (optional, same shape and
- *                    row stride) is added element-wise.  car_chain_packed_floats(K, N) floats.
+ * the 32 rays and are the next layer's B operands; f16 matrix pipe with fp16 hi/lo operand halves (three products per term, fp32
+ * accumulate), weights scaled by a power of two per layer, activations by one per ray and layer, both undone exactly.
+ *   car_chain_pack : split-fp16 tiles of one layer, car_chain_packed_floats(K, N) floats.  chained != 0: the layer is fed by another
+ *                    layer's accumulators (their K order); 0: by rows in memory.  W2 (optional, same shape and row stride) is added
+ *                    element-wise.  scale: device array of 32 floats shared by the layers of a plan; the layer's 2^shift goes to
+ *                    scale[slot], 2^-shift to scale[16 + slot] (slot < 16).
  *   car_ray_mid    : z1 = latent_value(ebar) [M,288];  uh = query_repeat_embed[:, :128] encode_latent(z1) [M,128]   (models.py:487, 548, 552)
  *   car_ray_tail   : z = latent_value(ebar) + V z1;  rgb = phi([z, z], coords) valid + (1 - valid), valid [b R]   (models.py:561-565, 597-617;
  *                    resnet_block_fc.py:132-168)
  * `arena` + host arrays offs / nts (n_chunks entries): where every K = 32 weight chunk lives (float offset from `arena`) and how many
- * 32-output tiles it has, in consumption order — mid: latent_value (car_linear_pack layout, 19 x 9), encode_latent (9 x 4),
- * query_repeat_embed[:, :128] (4 x 4); tail: latent_value, lin_in (1 x 4), 3 x {lin_z halves added (9 x 4), fc_0 (4 x 4), fc_1 (4 x 4)},
- * lin_out (4 x 1).  bias — mid: encode_latent.bias; tail: 3 x {lin_z, fc_0, fc_1 biases}, lin_out.bias padded to 32.
+ * 32-output tiles it has, in consumption order — mid: latent_value (18 x 9), encode_latent (9 x 4), query_repeat_embed[:, :128]
+ * (4 x 4); tail: latent_value, lin_in (1 x 4), 3 x {lin_z halves added (9 x 4), fc_0 (4 x 4), fc_1 (4 x 4)}, lin_out (4 x 1).
+ * bias — mid: latent_value.bias (288), encode_latent.bias (128); tail: latent_value.bias (288), lin_in.bias (128), 3 x {lin_z, fc_0,
+ * fc_1 biases}, lin_out.bias padded to 32.  layers (host array, n_layers = 3 / 12): the scale slot of every layer in that order.
  * car_plan_build / car_render_forward set all of this up. */
 size_t car_chain_packed_floats(int K, int N);
-int car_chain_pack(const float* W, int ldw, const float* W2, int K, int N, float* packed, void* stream);
-int car_ray_mid(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* ebar, int ld_ebar,
-                float* z1, float* uh, long M, void* stream);
-int car_ray_tail(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* ebar, int ld_ebar,
-                 const float* phi_x, int ld_phi, const float* z1, const float* rays, int b, int V, int R, float* rgb, float* valid,
-                 void* stream);
+int car_chain_pack(const float* W, int ldw, const float* W2, int K, int N, int chained, float* packed, float* scale, int slot, void* stream);
+int car_ray_mid(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* scale,
+                const int* layers, int n_layers, const float* ebar, int ld_ebar, float* z1, float* uh, long M, void* stream);
+int car_ray_tail(const float* arena, const unsigned* offs, const int* nts, int n_chunks, const float* bias, const float* scale,
+                 const int* layers, int n_layers, const float* ebar, int ld_ebar, const float* phi_x, int ld_phi, const float* z1,
+                 const float* rays, int b, int V, int R, float* rgb, float* valid, void* stream);
 
 /* ---- a18: valid mask and white background (models.py:614-617).
  * rays [b*V,R,CAR_RAY_FLOATS]; rgb_in [b,R,ld_in] (first 3 columns used) -> rgb [b,R,3], valid [b,R]. */
