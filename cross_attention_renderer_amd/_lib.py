@@ -117,19 +117,37 @@ def source_hash() -> str:
 def _rebuild_stale() -> None:
     """The library on disk was built from other sources than the tree's: rebuild it with the tree's own build() when hipcc is here
     (always the real HIP library, never a substitute), refuse otherwise."""
+    import fcntl
     import importlib.util
     import shutil
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     entry = os.path.join(root, "__graft_entry__.py")
     if os.path.exists(entry) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
-        spec = importlib.util.spec_from_file_location("_car_graft_entry", entry)
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        mod.build_library()
-        if open(LIB_PATH + ".srchash").read().strip() == source_hash():
+        # one builder at a time: ranks spawned together (experiment_scripts --gpus N, bench.py under torchrun) all land here at once.
+        # The others wait on the lock, find the stamp current and load the library the first one linked (build_library links to a
+        # temporary file and renames it into place, so a concurrent dlopen never sees a half-written .so).
+        with open(LIB_PATH + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not _stamp_current():
+                    spec = importlib.util.spec_from_file_location("_car_graft_entry", entry)
+                    mod = importlib.util.module_from_spec(spec)
+                    spec.loader.exec_module(mod)
+                    mod.build_library()
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+        if _stamp_current():
             return
     raise RuntimeError(f"{LIB_PATH} was built from other sources than the ones in this tree (csrc/, include/car_hip.h): rebuild it "
                        "with `python __graft_entry__.py`")
+
+
+def _stamp_current() -> bool:
+    stamp = LIB_PATH + ".srchash"
+    try:
+        return os.path.exists(LIB_PATH) and open(stamp).read().strip() == source_hash()
+    except OSError:
+        return False
 
 
 def load() -> ctypes.CDLL:
@@ -144,8 +162,7 @@ def load() -> ctypes.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
             "The render path has no CPU/PyTorch fallback.")
-    stamp = LIB_PATH + ".srchash"
-    if os.path.exists(stamp) and open(stamp).read().strip() != source_hash():
+    if not _stamp_current():                      # a missing stamp counts as stale: the library's sources are unknown
         _rebuild_stale()
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():

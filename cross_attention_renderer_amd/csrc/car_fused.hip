@@ -89,7 +89,9 @@ __device__ __forceinline__ int chunk_tiles(int g) {
 // barriers); probes of the texture-address path on top of 5: 6 odd rows masked off (whole quads of lanes inactive), 7 odd channel
 // quads masked off (half of every quad of lanes inactive); 11 the full kernel without the barrier of the weight stream (racy);
 // 12 = 3 + no A-operand reads from LDS (matrix pipe + VALU only); 13 the full kernel without the A-operand reads;
-// 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val)
+// 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val);
+// 14: four taps per sample and source from ONE map (the caller hands a lattice of the full three-level size, 521 x 521 nodes for a
+// 256 x 256 frame, with arbitrary contents): the cost side of merging the finest level into the lattice too
 template <int ABL>
 __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -202,6 +204,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
         if constexpr (ABL == 1 || ABL == 2 || ABL == 3 || ABL == 12) return;
         if constexpr (ABL == 6) { if (r0 & 1) return; }
         if constexpr (ABL == 7) { if (qd & 1) return; }
+        if constexpr (ABL == 14) { if (l == 0) return; l = 0; }          // the lattice's four taps ride in the finest level's slots, nothing else is fetched
         const int chunk_off = 128 * c;                                 // the chunk's 32 channels: scalar offset, not range-checked
         // ABL 8: lane = (sample s, k group q4) as the MFMA's B operand wants it, the two row groups become the two 16-byte pieces
         const int row = ABL == 8 ? s : r0 + 8 * it;
@@ -216,6 +219,7 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
     };
     auto blend_row = [&](const f32x4 (&tap)[4], int sv, int l, int it) {
         if constexpr (ABL == 2 || ABL == 3 || ABL == 12) return;
+        if constexpr (ABL == 14) { if (l == 0) return; l = 0; }
         const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 8 + 4 * l);
         const float ww[4] = {w.x, w.y, w.z, w.w};
         f32x2 lo2 = {hacc[it].x, hacc[it].y}, hi2 = {hacc[it].z, hacc[it].w};          // v_pk_fma_f32: two FMAs per instruction
@@ -437,7 +441,7 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     switch (abl) {
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 5: kern = fused_kernel<5>; break;   case 6: kern = fused_kernel<6>; break;   case 7: kern = fused_kernel<7>; break;
-        case 8: kern = fused_kernel<8>; break;   case 11: kern = fused_kernel<11>; break;   case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;
+        case 8: kern = fused_kernel<8>; break;   case 11: kern = fused_kernel<11>; break;   case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;   case 14: kern = fused_kernel<14>; break;
         case 4: kern = fused_kernel<4>; break;
         default: break;
     }

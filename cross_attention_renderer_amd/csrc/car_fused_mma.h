@@ -89,7 +89,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], float p, half8& hi, 
 // power of two p with m p in [2^13, 2^14) for m > 0 (exponent clamped for tiny / huge m), and inv = 1 / p
 __device__ __forceinline__ void pow2_scale(float m, float& p, float& inv) {
     int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
-    e = e < 40 ? 40 : (e > 230 ? 230 : e);
+    e = e < 97 ? 97 : (e > 230 ? 230 : e);          // p in [2^-90, 2^43]: an all-zero vector or matrix must not push p_x * p_W past fp32
     p = __uint_as_float((unsigned)(267 - e) << 23);
     inv = __uint_as_float((unsigned)(e - 13) << 23);
 }

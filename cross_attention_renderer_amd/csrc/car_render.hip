@@ -36,7 +36,7 @@ inline size_t up64(size_t x) { return (x + 63) & ~(size_t)63; }
 // power of two p with m p in [2^13, 2^14) (the window of the split-fp16 operands, car_fused_mma.h)
 __device__ __forceinline__ float pow2_for(float m) {
     int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
-    e = e < 40 ? 40 : (e > 230 ? 230 : e);
+    e = e < 97 ? 97 : (e > 230 ? 230 : e);          // p in [2^-90, 2^43]: an all-zero vector or matrix must not push p_x * p_W past fp32
     return __uint_as_float((unsigned)(267 - e) << 23);
 }
 __device__ __forceinline__ float block_max(float v, float* red) {

@@ -117,11 +117,44 @@ def square_crop_img(img: np.ndarray) -> np.ndarray:
     return img[c[0] - m // 2:c[0] + m // 2, c[1] - m // 2:c[1] + m // 2]
 
 
+def _linear_coefs(n_dst: int, n_src: int):
+    """Source index and the two 11-bit fixed-point weights of every destination index, as OpenCV's ``resize`` computes them for
+    INTER_LINEAR on 8-bit images: centre-aligned coordinate ``(d + 0.5) * scale - 0.5`` in float32, clamped at both ends,
+    weights rounded to 1/2048."""
+    scale = 1.0 / (float(n_dst) / float(n_src))
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    i0 = np.floor(f).astype(np.int64)
+    f = f - i0.astype(np.float32)
+    lo, hi = i0 < 0, i0 >= n_src - 1
+    f = np.where(lo | hi, np.float32(0), f)
+    i0 = np.where(lo, 0, np.where(hi, n_src - 1, i0))
+    i1 = np.minimum(i0 + 1, n_src - 1)
+    w1 = np.rint(f.astype(np.float32) * np.float32(2048)).astype(np.int64)
+    w0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+    return i0, i1, w0, w1
+
+
+def resize_linear_u8(img: np.ndarray, width: int, height: int) -> np.ndarray:
+    """``cv2.resize(img, (width, height))`` (INTER_LINEAR) for a uint8 H x W x C image, restated from OpenCV's fixed-point path
+    (imgproc/resize.cpp: 11-bit coefficients, horizontal pass in int32, vertical pass ``((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4))
+    >> 16) + 2) >> 2``).  The reference resizes its 360-line frames this way when an item is read (realestate10k_dataio.py:606-607).
+    cv2 is not installed in this image, so the restatement is unpinned against cv2 itself (tests check it against float bilinear
+    interpolation to one grey level)."""
+    if img.dtype != np.uint8 or img.ndim != 3:
+        raise ValueError("resize_linear_u8 expects a uint8 H x W x C image")
+    x0, x1, a0, a1 = _linear_coefs(width, img.shape[1])
+    y0, y1, b0, b1 = _linear_coefs(height, img.shape[0])
+    src = img.astype(np.int64)
+    rows = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]               # horizontal pass: values x 2048
+    out = (((b0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 class RealEstate10kVis:
     """Evaluation dataset of the reference's eval scripts (eval_realestate10k.py:101-105, eval_acid.py): ``img_root`` holds one
-    directory per scene with a ``*.npz`` of frames, ``pose_root`` is a ``.mat`` file mapping scene name -> pose table.  Frames are
-    expected at the reference's working size 256 x 455 (its 360-line sources are resized with cv2 when the data is downloaded;
-    cv2 is not available here, so a scene that still needs that resize is rejected) and centre-cropped to 256 x 256."""
+    directory per scene with a ``*.npz`` of frames, ``pose_root`` is a ``.mat`` file mapping scene name -> pose table.  The
+    download scripts store raw 360-line frames; like the reference (realestate10k_dataio.py:606-607) the reader resizes such a frame
+    to the working size 256 x 455 (``resize_linear_u8``: OpenCV's INTER_LINEAR restated) before the centre crop to 256 x 256."""
 
     H, W = 256, 455
 
@@ -152,7 +185,7 @@ class RealEstate10kVis:
     def _frame(self, data, name, pose, stamp):
         rgb = data[name]
         if rgb.shape[0] == 360:
-            raise NotImplementedError("frame of 360 lines: resize the scene to 256 x 455 first (the reference uses cv2.resize, not available here)")
+            rgb = resize_linear_u8(np.ascontiguousarray(rgb), self.W, self.H)
         if self.square_crop:
             rgb = square_crop_img(rgb)
         cam = parse_pose(pose, stamp)

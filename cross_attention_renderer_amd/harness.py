@@ -19,8 +19,19 @@ from . import sharding, synthetic
 CHUNK_RAYS = 8192          # render_realestate10k_traj.py:96
 
 
-def to_device(inp, device):
-    return {k: {kk: (vv.to(device) if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in inp.items()}
+CAMERA_KEYS = ("cam2world", "intrinsics")
+
+
+def to_device(inp, device, cameras: str = "host"):
+    """Moves an input dict to the device.  ``cameras="host"`` (default) leaves the 4x4 camera matrices on the CPU: the engine then
+    runs the reference's own ``torch.inverse`` / ``matmul`` on them (poses.pack_poses) and uploads 768 bytes per frame — the
+    strict-parity route (the reference's fixtures reproduce to 1e-4).  ``cameras="device"`` moves them too, which selects
+    ``car_pose_setup`` (no host work per frame; equal to the host algebra to a few ulp, which the fp64 Pluecker intersection
+    amplifies on near-parallel samples: DESIGN.md section 2)."""
+    if cameras not in ("host", "device"):
+        raise ValueError("cameras must be 'host' or 'device'")
+    keep = CAMERA_KEYS if cameras == "host" else ()
+    return {k: {kk: (vv.to(device) if torch.is_tensor(vv) and kk not in keep else vv) for kk, vv in v.items()} for k, v in inp.items()}
 
 
 @torch.no_grad()
@@ -49,7 +60,7 @@ def trajectory(inp, n_frames: int) -> List[Dict]:
     frames = []
     for i in range(n_frames):
         q = torch.stack([torch.from_numpy(paths[s][i]).float() for s in range(b)])[:, None]
-        frames.append({"context": inp["context"], "query": dict(inp["query"], cam2world=q.to(c2w.device))})
+        frames.append({"context": inp["context"], "query": dict(inp["query"], cam2world=q.to(inp["query"]["cam2world"].device))})
     return frames
 
 

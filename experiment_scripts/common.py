@@ -41,6 +41,9 @@ def parser(description: str) -> argparse.ArgumentParser:
                    help="build the DPT encoder and run get_z on the context images even without a checkpoint (random weights)")
     p.add_argument("--n_frames", type=int, default=8, help="frames of the rendered trajectory")
     p.add_argument("--out_dir", type=str, default=None)
+    p.add_argument("--cameras", choices=("host", "device"), default="host",
+                   help="where the 4x4 pose algebra runs: host = the reference's torch.inverse calls (strict parity, default); "
+                        "device = car_pose_setup (no host work per frame, last-ulp differences)")
     p.add_argument("--port", type=int, default=1492)          # the reference rendezvous port (eval_realestate10k.py:97)
     return p
 

@@ -40,20 +40,26 @@ def evaluate(rank, opt, default_data=DEFAULT_DATA):
     for k, (inp, z) in enumerate(items):
         if real:
             inp = {part: {kk: (vv[None] if torch.is_tensor(vv) else vv) for kk, vv in d.items()} for part, d in inp.items()}   # batch of 1
-            inp = harness.to_device(inp, dev)
+            inp = harness.to_device(inp, dev, opt.cameras)
             with torch.no_grad():
                 z = model.get_z(inp)
         else:
-            inp, z = harness.to_device(inp, dev), [t.to(dev) for t in z]
+            inp, z = harness.to_device(inp, dev, opt.cameras), [t.to(dev) for t in z]
         start = time.time()
         tile = harness.render_frame(model, inp, z, chunk_rays=-(-H * H // n_chunks), rank=rank, world=opt.gpus)
         torch.cuda.synchronize()
         elapsed = time.time() - start
-        rgb = (tile[0, :, :3].clamp(-1, 1) + 1) / 2
+        # the reference's protocol (eval_realestate10k.py:170-181): prediction and target are both composited over 0.5 grey with the
+        # rendered valid mask — rays that see neither context view contribute no error — and nothing is clamped
+        valid = tile[0, :, 4:5]
+
+        def composite(img):
+            return ((img + 1) * 0.5) * valid + 0.5 * (1 - valid)
         if real:
-            target, what = (inp["query"]["rgb"][0, 0].clamp(-1, 1) + 1) / 2, "psnr"
+            target, what = inp["query"]["rgb"][0, 0].reshape(-1, 3).to(tile.device), "psnr"
         else:
-            target, what = (harness.render_frame(model, inp, z, chunk_rays=16384)[0, :, :3].clamp(-1, 1) + 1) / 2, "psnr vs un-chunked render"
+            target, what = harness.render_frame(model, inp, z, chunk_rays=16384)[0, :, :3], "psnr vs un-chunked render"
+        rgb, target = composite(tile[0, :, :3]), composite(target)
         psnrs.append(harness.psnr(rgb, target))
         if rank == 0:
             print(f"item {k}: elapsed {elapsed:.3f} s, {what} {psnrs[-1]:.2f} dB, valid {tile[0, :, 4].mean().item():.3f}")

@@ -20,7 +20,7 @@ def _scene_inputs(opt, H, dev, model):
     from cross_attention_renderer_amd import dataio, harness, synthetic
     if not opt.data_root or opt.synthetic:
         inp, z = harness.synthetic_pair(H, opt.views)
-        frames = harness.trajectory(harness.to_device(inp, dev), opt.n_frames)
+        frames = harness.trajectory(harness.to_device(inp, dev, opt.cameras), opt.n_frames)
         yield "synthetic", frames, [t.to(dev) for t in z]
         return
     if not opt.pose_root:
@@ -32,7 +32,7 @@ def _scene_inputs(opt, H, dev, model):
         for part in ("query", "context"):
             full[part]["intrinsics"] = full[part]["intrinsics"].clone()
             full[part]["intrinsics"][..., :2, :3] *= scale
-        full = harness.to_device(full, dev)
+        full = harness.to_device(full, dev, opt.cameras)
         nq = min(opt.n_frames, full["query"]["cam2world"].shape[1])
         frames = [{"context": full["context"],
                    "query": {"cam2world": full["query"]["cam2world"][:, i:i + 1], "intrinsics": full["query"]["intrinsics"][:, i:i + 1],

@@ -47,11 +47,11 @@ def render(rank, opt):
         R = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]]).T
         inp = trajectory.unposed_pair_input(g.random((H, H, 3)), g.random((H, H, 3)), R, -R @ np.array([0.6, 0.03, 0.05]), uv)
         z = [t.to(dev) for t in synthetic.feature_maps(1, 2, H, seed=1)]
-        inp = harness.to_device(inp, dev)
+        inp = harness.to_device(inp, dev, opt.cameras)
     else:
         model = common.build_model(opt, dev, with_encoder=True)
         rt = np.load(opt.pose)
-        inp = harness.to_device(trajectory.unposed_pair_input(_read_image(opt.im1), _read_image(opt.im2), rt["R"], rt["t"], uv), dev)
+        inp = harness.to_device(trajectory.unposed_pair_input(_read_image(opt.im1), _read_image(opt.im2), rt["R"], rt["t"], uv), dev, opt.cameras)
         with torch.no_grad():
             z = model.get_z(inp)
     out_dir = opt.out_dir or os.path.join(opt.logging_root, opt.experiment_name, "unposed")

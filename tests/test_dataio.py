@@ -76,3 +76,41 @@ def test_eval_reader_rejects_training_options_and_unresized_frames():
     img = np.zeros((256, 455, 3), np.uint8)
     assert dataio.square_crop_img(img).shape == (256, 256, 3)
     assert dataio.ACIDVis is dataio.RealEstate10kVis
+
+
+def test_resize_of_360_line_frames_follows_opencv_bilinear():
+    """cv2.resize(INTER_LINEAR) restated (dataio.resize_linear_u8): against float bilinear interpolation with the same centre-aligned
+    coordinates it may differ by the fixed-point rounding only (one grey level); constants and edges are exact."""
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (360, 640, 3), generator=g, dtype=torch.uint8).numpy()
+    out = dataio.resize_linear_u8(img, 455, 256)
+    assert out.shape == (256, 455, 3) and out.dtype == np.uint8
+    ref = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].double(), size=(256, 455), mode="bilinear",
+                                          align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(out.astype(np.float64) - ref).max() <= 1.0
+    assert np.abs(out.astype(np.float64) - ref).mean() < 0.3
+    flat = np.full((360, 640, 3), 77, np.uint8)
+    assert np.array_equal(dataio.resize_linear_u8(flat, 455, 256), np.full((256, 455, 3), 77, np.uint8))
+    assert np.array_equal(dataio.resize_linear_u8(img, 640, 360), img)                    # identity size: weights (2048, 0)
+
+
+def test_eval_reader_resizes_raw_360_line_scenes(tmp_path):
+    """A scene as the download scripts write it (raw 360 x 640 frames, generate_realestate.py:58-72) is read like the reference does:
+    resized to 256 x 455 per frame, then centre-cropped."""
+    import random
+    import shutil
+    from scipy.io import loadmat
+    src = np.load(os.path.join(VIS, "scenes", "sceneA", "data.npz"))
+    g = np.random.default_rng(0)
+    raw = {k: g.integers(0, 256, (360, 640, 3), dtype=np.uint8) for k in src.keys()}
+    os.makedirs(tmp_path / "scenes" / "sceneA")
+    np.savez(tmp_path / "scenes" / "sceneA" / "data.npz", **raw)
+    shutil.copy(os.path.join(VIS, "poses.mat"), tmp_path / "poses.mat")
+    ds = dataio.RealEstate10kVis(str(tmp_path / "scenes"), str(tmp_path / "poses.mat"), num_ctxt_views=2)
+    random.seed(0)
+    item, _ = ds[0]
+    assert tuple(item["context"]["rgb"].shape) == (2, 256, 256, 3) and tuple(item["query"]["rgb"].shape) == (1, 65536, 3)
+    first = sorted(raw.keys(), key=lambda n: int(n.split(".")[0]))[0]
+    want = dataio.square_crop_img(dataio.resize_linear_u8(raw[first], 455, 256)).astype(np.float32) / 127.5 - 1
+    assert np.array_equal(item["context"]["rgb"][0].numpy(), want)
+    assert loadmat(str(tmp_path / "poses.mat"))["sceneA"].shape[1] == 19

@@ -450,6 +450,25 @@ def test_split_fp16_with_outliers_in_the_feature_maps():
     assert (np.asarray(out["valid_mask"]) == np.asarray(ora["valid_mask"])).all()
 
 
+@pytest.mark.parametrize("route", ["one-call", "staged"])
+def test_all_zero_layers_and_dead_relu_rows_stay_finite(route):
+    """The reference initialises ResnetBlockFC.fc_1.weight to zero (resnet_block_fc.py:39) and a ReLU can kill a whole row: the
+    split-fp16 power-of-two scaling sees an all-zero weight matrix / input vector there.  The scale is clamped to [2^-90, 2^43], so the
+    products are exact zeros and the fp32 side passes the residual / bias through — no Inf * 0."""
+    def sd_edit(sd):
+        sd = dict(sd)
+        for i in range(3):
+            sd[f"phi.blocks.{i}.fc_1.weight"] = torch.zeros_like(sd[f"phi.blocks.{i}.fc_1.weight"])
+        sd["phi.blocks.1.fc_0.bias"] = torch.full_like(sd["phi.blocks.1.fc_0.bias"], -1e3)      # relu(net) == 0 for every ray
+        sd["key_map.bias"] = torch.full_like(sd["key_map.bias"], -1e3)                           # relu(k1) == 0: key = bias of key_map_2
+        sd["query_repeat_embed_2.weight"] = torch.zeros_like(sd["query_repeat_embed_2.weight"])
+        return sd
+    c, fx, ora, out = run_case("t1_c1", sd_edit=sd_edit, fuse_samples=(route == "one-call"))
+    for k in ("rgb", "depth_ray", "at_wt"):
+        assert torch.isfinite(out[k]).all(), k
+    _check_outputs(out, lambda k: ora[k], f"zero layers, {route}")
+
+
 # ----------------------------------------------------------------------------------------------------------
 # a3 on the device: car_pose_setup (fp64 Gauss-Jordan) against the host pose algebra (torch.inverse, the reference's call)
 # ----------------------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 product kernel (variant 0) and the timing-only ablation variants of the development build (tools/build_dev.py; results of
 variants > 0 are wrong by construction):
   1 no tap loads | 2 no gather work | 3 = 2 + no weight DMA / barriers | 5 the gather alone
+  14 four taps per sample and source from a full three-level lattice (521 x 521 nodes, random contents)
   texture-address probes on top of 5:  6 odd rows masked off | 7 odd channel quads masked off | 8 lanes in the MFMA's B-operand
   order | 9 no level-0 taps | 10 level-2 taps only in the first two chunks
 Usage (GPU box): python tools/bench_fused.py [variants...]"""
@@ -78,12 +79,18 @@ def main():
     S = 2 * R * bench.P
     flop = 2.0 * S * bench.FUSED_MACS
     variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 5, 6, 7, 8]
+    big = None
     for v in variants:
         lat = []
+        lat_ptr, lat_h, lat_w, lat_pad = eng._pair.data_ptr(), lh.value, lw.value, lpad.value
+        if v == 14:                                        # a lattice of the full three-level size (timing only: random contents)
+            if big is None:
+                big = torch.randn(2 * 2 * 521 * 521 * 576, device=dev)
+            lat_ptr, lat_h, lat_w, lat_pad = big.data_ptr(), 521, 521, 5
         for it in range(7):
             a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            rc = fn(v, eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), eng._pair.data_ptr(), lh.value, lw.value, lpad.value,
+            rc = fn(v, eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), lat_ptr, lat_h, lat_w, lat_pad,
                     fine_ptr, fh, fw, gmeta, wpt.data_ptr(), blob.data_ptr(),
                     bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
                     pixel_val.data_ptr(), st)
