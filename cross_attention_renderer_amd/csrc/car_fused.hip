@@ -93,7 +93,7 @@ __device__ __forceinline__ int chunk_tiles(int g) {
 // 14: four taps per sample and source from ONE map (the caller hands a lattice of the full three-level size, 521 x 521 nodes for a
 // 256 x 256 frame, with arbitrary contents): the cost side of merging the finest level into the lattice too
 template <int ABL>
-__global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
+__global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : 768) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 15, q4 = lane >> 4;
@@ -268,6 +268,33 @@ __global__ void __launch_bounds__(768) fused_kernel(const FusedArgs a) {
         split8(x, hp, bhi, blo);
     };
 
+    if constexpr (ABL == 15 || ABL == 16 || ABL == 17) {
+        // development build: the gather alone (as 5) with whole chunks of tap loads in flight — 15: one chunk ahead (16-32 loads per
+        // wave), 16: two chunks ahead (32-48), 17: three ahead (48-64) — against 5's two batches of four.  How far the gather is
+        // bound by the latency of its far misses times the loads a wave can keep in flight.  16 and 17 run 8 waves per workgroup
+        // (256 registers each; two thirds of the samples are gathered: scale their time by 1.5).
+        constexpr int NS = ABL == 15 ? 2 : ABL == 16 ? 3 : 4;
+        f32x4 ring[NS][4][4];
+#pragma unroll
+        for (int m = 0; m < 2 * kKS + NS - 1; ++m) {
+            if (m < 2 * kKS) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) issue_row(ring[m % NS][k], m / kKS, m % kKS, 1 - (k >> 1), k & 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);                          // keep the whole chunk's loads ahead of the blends below
+            const int d = m - (NS - 1);
+            if (d >= 0) {
+                affine_row(d / kKS, d % kKS, 0); affine_row(d / kKS, d % kKS, 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) blend_row(ring[d % NS][k], d / kKS, 1 - (k >> 1), k & 1);
+                finish_row(0); finish_row(1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (lds[kLdsStage + tid] == 123.456f) a.logit[0] = 1.0f;
+        return;
+    }
     // first chunk of source 0: nothing to hide it under
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -441,7 +468,7 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     switch (abl) {
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 5: kern = fused_kernel<5>; break;   case 6: kern = fused_kernel<6>; break;   case 7: kern = fused_kernel<7>; break;
-        case 8: kern = fused_kernel<8>; break;   case 11: kern = fused_kernel<11>; break;   case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;   case 14: kern = fused_kernel<14>; break;
+        case 8: kern = fused_kernel<8>; break;   case 11: kern = fused_kernel<11>; break;   case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;   case 14: kern = fused_kernel<14>; break;   case 15: kern = fused_kernel<15>; break;   case 16: kern = fused_kernel<16>; break;   case 17: kern = fused_kernel<17>; break;
         case 4: kern = fused_kernel<4>; break;
         default: break;
     }
@@ -451,7 +478,7 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e1 != hipSuccess) { car_set_error("car_fused_samples: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(768), kLdsBytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3((abl == 16 || abl == 17) ? 512 : 768), kLdsBytes, (hipStream_t)stream, a);
     CAR_CHECK_LAUNCH("car_fused_samples");
     return CAR_OK;
 }
