@@ -111,18 +111,26 @@ def cpu_baseline(rays: int):
             t0 = time.perf_counter()
             O.render_forward(sd, inp, z, cfg)
             best = min(best, time.perf_counter() - t0)
-    cores = torch.get_num_threads()
-    model_name = "unknown"
+    threads = torch.get_num_threads()
+    model_name, phys = "unknown", None
     try:
+        sockets, per_socket = set(), None
         with open("/proc/cpuinfo") as f:
             for line in f:
-                if line.startswith("model name"):
+                if line.startswith("model name") and model_name == "unknown":
                     model_name = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
+                elif line.startswith("physical id"):
+                    sockets.add(line.split(":", 1)[1].strip())
+                elif line.startswith("cpu cores") and per_socket is None:
+                    per_socket = int(line.split(":", 1)[1])
+        if sockets and per_socket:
+            phys = len(sockets) * per_socket
+    except (OSError, ValueError):
         pass
-    return {"value": rays / best, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{rays} rays of the same 256x256x64 frame, best of 2 after warm-up, oracle/car_oracle.py on {model_name}"}
+    return {"value": rays / best, "unit": "rays/s", "cores": threads, "physical_cores": phys, "logical_cpus": os.cpu_count(),
+            "kind": "port",
+            "sample": f"{rays} rays of the same 256x256x64 frame, best of 2 after warm-up, oracle/car_oracle.py with {threads} torch threads on "
+                      f"{model_name} ({phys if phys else '?'} physical cores, {os.cpu_count()} logical CPUs)"}
 
 
 def gather_stage(model, inp, z, rays: int = CHUNK):
@@ -246,7 +254,14 @@ def main():
             t2 = timed_loop(model, full, z, tile2, g2, k2, args.chunk_rays, dist)
             per_rank = (k2, t2)
 
+    rank_stages = None
     if dist is not None:
+        mine = {}
+        for name, ms in stages:
+            mine.setdefault(name, []).append(ms)
+        mine = {k: sum(v) / len(v) for k, v in mine.items()}
+        rank_stages = [None] * world
+        dist.all_gather_object(rank_stages, mine)            # every rank's mean stage times: a short scaling curve can be read from one run
         t = torch.tensor([elapsed, per_rank[1] if per_rank else 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t[0].item()
@@ -285,13 +300,18 @@ def main():
                     "frac_of_fp32_pipe_peak": flop / mean / FP32_MFMA_PEAK,
                     "ta_busy": pmc.get("ta_busy"), "mfma_busy": pmc.get("mfma_busy"), "l1_bytes": pmc.get("l1_bytes_per_launch"),
                     "traffic": pmc.get("bytes_per_launch"), "traffic_source": pmc.get("source"),
+                    # which of these fields this run measured and which it copied from the committed counter passes
+                    "live_fields": ["achieved", "frac", "frac_of_fp32_pipe_peak", "launches", "ms_per_launch", "flop_per_launch"],
+                    "static_fields": ["bound", "ta_busy", "mfma_busy", "l1_bytes", "traffic"],
+                    "static": "profiles/traffic.json: rocprofv3 --pmc passes of an earlier run of this kernel (separate passes, not collected here)",
                     "launches": len(lat), "ms_per_launch": mean * 1e3, "flop_per_launch": flop}
         fr = prof.get("frame")
         hbm = None
         if fr and args.chunk_rays >= R and world == 1:
             per_frame = fr["bytes_per_frame"]
             hbm = {"bytes_per_frame": per_frame, "achieved": per_frame / (elapsed / args.steps) / 1e12, "peak": 8.0, "unit": "TB/s",
-                   "frac": per_frame / (elapsed / args.steps) / HBM_PEAK, "source": fr["source"]}
+                   "frac": per_frame / (elapsed / args.steps) / HBM_PEAK, "source": fr["source"],
+                   "static": "bytes_per_frame comes from profiles/traffic.json (PMC passes, not collected in this run); the time is this run's"}
         gs = None
         if world == 1 and not args.no_extras:
             with torch.no_grad():
@@ -308,6 +328,7 @@ def main():
                        "rays_per_step": R_frame, "rays_per_step_per_gpu": R,
                        "parallelism": "one GPU" if world == 1 else f"one frame's rays banded over {world} ranks, RCCL all-gather of tiles"},
             "stage_ms": {k: sum(v) / len(v) for k, v in by_stage.items()},
+            "stage_ms_per_rank": rank_stages,
             "roofline": roof,
             "hbm": hbm,
             "gather_stage": gs,

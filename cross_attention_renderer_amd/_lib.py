@@ -93,6 +93,13 @@ SIGNATURES = {
     "car_render_forward": (c_int, [ctypes.POINTER(CarDims), _P, ctypes.POINTER(CarInputs), ctypes.POINTER(CarOutputs), _P,
                                    c_size_t, _P]),
     "car_linspace": (None, [c_float, c_float, c_int, _P]),
+    "car_linear_wgrad": (c_int, [_P, c_int, _P, c_int, c_long, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "car_attend_backward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "car_gather_bilinear_backward": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_long, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "car_relu_mask": (c_int, [_P, c_int, _P, c_int, c_long, c_int, _P]),
+    "car_scale_rows": (c_int, [_P, c_int, _P, c_int, _P, c_long, c_float, c_long, c_int, c_int, _P]),
+    "car_add": (c_int, [_P, c_int, _P, c_int, c_float, _P, c_int, c_float, c_long, c_int, _P]),
+    "car_reduce_samples": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -179,7 +186,7 @@ def check_exports() -> None:
     missing = [n for n in SIGNATURES if not hasattr(lib, n)]
     if missing:
         raise RuntimeError(f"libcar_hip.so lacks symbols: {missing}")
-    if lib.car_version() < 200:
+    if lib.car_version() < 300:
         raise RuntimeError("libcar_hip.so is older than the Python package")
 
 

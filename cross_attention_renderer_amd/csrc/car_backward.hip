@@ -1,0 +1,364 @@
+// car_backward.hip — backward kernels of the staged render route (the reference trains with torch autograd over
+// models.py:190-626, training.py:92-136).  Gradients flow to the renderer's parameters and to the feature pyramid z (from there,
+// through torch autograd, into the encoder); the geometry (poses, rays, sample positions, pt, g) is not differentiated — none of it
+// depends on a parameter.
+//
+//   car_linear_wgrad           dW += dY^T X, db += column sums of dY                       fp32 matrix pipe (v_mfma_f32_32x32x2_f32)
+//   car_attend_backward        softmax-attention backward of one round (+ the depth read-out's term)      one workgroup per ray
+//   car_gather_bilinear_backward   scatter-add of the gathered rows' gradients into the channel-last pyramid (grid_sample backward)
+//   car_relu_mask / car_scale_rows / car_add / car_reduce_samples      the element-wise pieces between them
+// The data gradients dX = dY W of the linear layers are car_linear itself with the transposed weight packed (car_linear_pack).
+#include "car_common.h"
+#include "car_geom.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dW[n][k] += sum_m dY[m][n] X[m][k]  (k == K: the bias column, X = 1).  A wave owns a 64 x 128 tile of dW (2 x 4 MFMA tiles of
+// 32 x 32) over a slab of rows: D += A B with A = dY^T (32 outputs x 2 rows), B = X (2 rows x 32 inputs), so lane l feeds
+// dY[m + l / 32][n0 + l % 32] and X[m + l / 32][k0 + l % 32]: both reads are 128 contiguous bytes per half wave.  Eight row
+// pairs are loaded ahead of their 64 MFMAs.  The tile is added to dW with fp32 atomics (slabs of different workgroups meet there).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kWgTN = 2, kWgTK = 4, kWgUnroll = 8;
+
+__global__ void __launch_bounds__(256) wgrad_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, long M, int N,
+                                                    int K, int relu_x, int slab_rows, float* __restrict__ dW, int lddw, float* __restrict__ db) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * (32 * kWgTN), k0 = blockIdx.y * (32 * kWgTK);
+    const int Kb = db ? K + 1 : K;                                    // the bias rides as column K
+    const long m_begin = ((long)blockIdx.z * 4 + wave) * slab_rows;
+    const long m_end = m_begin + slab_rows < M ? m_begin + slab_rows : M;
+    f32x16 acc[kWgTN][kWgTK];
+#pragma unroll
+    for (int i = 0; i < kWgTN; ++i)
+#pragma unroll
+        for (int j = 0; j < kWgTK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int half = lane >> 5, col = lane & 31;
+    for (long m = m_begin; m < m_end; m += 2 * kWgUnroll) {
+        float a[kWgUnroll][kWgTN], bq[kWgUnroll][kWgTK];
+#pragma unroll
+        for (int u = 0; u < kWgUnroll; ++u) {
+            const long row = m + 2 * u + half;
+            const bool on = row < m_end;
+            const long rr = on ? row : m_begin;
+#pragma unroll
+            for (int i = 0; i < kWgTN; ++i) {
+                const int n = n0 + 32 * i + col;
+                a[u][i] = (on && n < N) ? dY[rr * ldy + n] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < kWgTK; ++j) {
+                const int k = k0 + 32 * j + col;
+                float x = 0.0f;
+                if (on && k < K) { x = X[rr * ldx + k]; if (relu_x) x = fmaxf(x, 0.0f); }
+                else if (on && k == K && db) x = 1.0f;
+                bq[u][j] = x;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kWgUnroll; ++u)
+#pragma unroll
+            for (int i = 0; i < kWgTN; ++i)
+#pragma unroll
+                for (int j = 0; j < kWgTK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], bq[u][j], acc[i][j], 0, 0, 0);
+    }
+    // accumulator register r of lane l holds D[8 (r / 4) + 4 (l / 32) + r % 4][l % 32]
+#pragma unroll
+    for (int i = 0; i < kWgTN; ++i)
+#pragma unroll
+        for (int j = 0; j < kWgTK; ++j) {
+            const int k = k0 + 32 * j + col;
+            if (k >= Kb) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
+                if (n >= N) continue;
+                const float v = acc[i][j][r];
+                if (k < K) atomicAdd(dW + (long)n * lddw + k, v);
+                else atomicAdd(db + n, v);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One attention round, backward.  Forward (car_attend): w = softmax_s(logit_s) over the ray's V P samples, zbar = sum_s w_s val_s,
+// depth = clamp((inv_q sum_s w_s clamp(pt_s, +-100)).z, 0, 10).  Given dz [b R, D] (gradient of zbar) and optionally ddepth [b R]:
+//   a_s = <dz, val_s> + ddepth [0 < depth_pre < 10] inv_q[2, :3] . clamp(pt_s)          dlogit_s = w_s (a_s - sum_t w_t a_t)
+//   dval_s (+)= w_s dz
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kMaxSamples = CAR_MAX_VIEWS * 256;
+
+__global__ void __launch_bounds__(256) attend_bwd_kernel(const float* __restrict__ w_in, const float* __restrict__ val, int D, int b, int V, int R,
+                                                         int P, const float* __restrict__ dz, int ld_dz, const float* __restrict__ ddepth,
+                                                         const float* __restrict__ pt, const CarPose* __restrict__ poses, float* __restrict__ dval,
+                                                         int accumulate, float* __restrict__ dlogit) {
+    __shared__ float s_w[kMaxSamples], s_a[kMaxSamples];
+    __shared__ float s_red[4];
+    const int sc = blockIdx.x / R, r = blockIdx.x % R;
+    const int S = V * P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = tid & 15, grp = tid >> 4;
+    auto row_of = [&](int s) -> long { return ((long)(sc * V + s / P) * R + r) * P + (s % P); };
+    const float* dzr = dz + ((long)sc * R + r) * ld_dz;
+    for (int s = tid; s < S; s += 256) s_w[s] = w_in[row_of(s)];
+    __syncthreads();
+    // depth term: the pre-clamp depth of this ray and the row of inv_q that reads it out
+    float dd = 0.0f, mz[3] = {0.f, 0.f, 0.f};
+    if (ddepth) {
+        float acc3[3] = {0.f, 0.f, 0.f};
+        if (wave == 0) {
+            for (int s = lane; s < S; s += 64) {
+                const float* q = pt + row_of(s) * 3;
+                for (int k = 0; k < 3; ++k) acc3[k] += s_w[s] * fminf(fmaxf(q[k], -100.0f), 100.0f);
+            }
+            for (int k = 0; k < 3; ++k) acc3[k] = wave_sum(acc3[k]);
+            if (lane == 0) {
+                const float* Mi = poses[sc * V].inv_q;
+                const float zc = ((acc3[0] * Mi[8] + acc3[1] * Mi[9]) + acc3[2] * Mi[10]) + Mi[11];
+                s_red[0] = (zc > 0.0f && zc < 10.0f) ? ddepth[(long)sc * R + r] : 0.0f;
+            }
+        }
+        __syncthreads();
+        dd = s_red[0];
+        const float* Mi = poses[sc * V].inv_q;
+        mz[0] = Mi[8]; mz[1] = Mi[9]; mz[2] = Mi[10];
+        __syncthreads();
+    }
+    // a_s: 16 lanes per sample walk the row
+    for (int s = grp; s < S; s += 16) {
+        const long row = row_of(s);
+        const float* v = val + row * D;
+        float acc = 0.0f;
+        for (int k = 4 * sub; k + 3 < D; k += 64) {
+            const float4 x = *reinterpret_cast<const float4*>(v + k);
+            const float4 g4 = *reinterpret_cast<const float4*>(dzr + k);
+            acc += x.x * g4.x + x.y * g4.y + x.z * g4.z + x.w * g4.w;
+        }
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
+        if (sub == 0) {
+            if (dd != 0.0f) {
+                const float* q = pt + row * 3;
+                acc += dd * ((mz[0] * fminf(fmaxf(q[0], -100.0f), 100.0f) + mz[1] * fminf(fmaxf(q[1], -100.0f), 100.0f)) +
+                             mz[2] * fminf(fmaxf(q[2], -100.0f), 100.0f));
+            }
+            s_a[s] = acc;
+        }
+    }
+    __syncthreads();
+    float t = 0.0f;
+    for (int s = tid; s < S; s += 256) t += s_w[s] * s_a[s];
+    t = wave_sum(t);
+    if (lane == 0) s_red[wave] = t;
+    __syncthreads();
+    t = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    for (int s = tid; s < S; s += 256) dlogit[row_of(s)] = s_w[s] * (s_a[s] - t);
+    // dval_s (+)= w_s dz
+    for (int s = grp; s < S; s += 16) {
+        const float w = s_w[s];
+        float* o = dval + row_of(s) * D;
+        for (int k = 4 * sub; k + 3 < D; k += 64) {
+            const float4 g4 = *reinterpret_cast<const float4*>(dzr + k);
+            float4 y = accumulate ? *reinterpret_cast<const float4*>(o + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            y.x = fmaf(w, g4.x, y.x); y.y = fmaf(w, g4.y, y.y); y.z = fmaf(w, g4.z, y.z); y.w = fmaf(w, g4.w, y.w);
+            *reinterpret_cast<float4*>(o + k) = y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// grid_sample backward with respect to the maps: the gradient of the gathered row goes to its four taps of every level with the
+// forward's weights (car_bilinear_taps; zeros padding: taps outside the map have weight 0, border: clamped taps).  Same placement
+// rule for the row of a point as car_gather_bilinear.  fp32 atomics (a texel is shared by many samples).
+// ---------------------------------------------------------------------------------------------------------------------
+struct ScatterLevels {
+    float* map[CAR_MAX_LEVELS];
+    int c[CAR_MAX_LEVELS], h[CAR_MAX_LEVELS], w[CAR_MAX_LEVELS];
+    int q0[CAR_MAX_LEVELS + 1];
+    int n_levels;
+};
+
+__global__ void __launch_bounds__(256) gather_bwd_kernel(ScatterLevels L, int n_maps, const float* __restrict__ grid, long pts, int mode, int place,
+                                                         int V, const float* __restrict__ dout, int ld_out, int col_out) {
+    const int qpr = L.q0[L.n_levels];
+    const long total = (long)n_maps * pts * qpr;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % qpr);
+        const long mp = idx / qpr;
+        const int m = (int)(mp / pts);
+        const long i = mp % pts;
+        long row;
+        if (place == CAR_PLACE_PLAIN) row = mp;
+        else if (place == CAR_PLACE_OWN) row = mp * V + (m % V);
+        else { const int sc = m / 2, s = m % 2; row = (((long)(sc * 2 + (1 - s))) * pts + i) * 2 + s; }
+        int l = 0;
+        while (l + 1 < L.n_levels && q >= L.q0[l + 1]) ++l;
+        int tidx[4];
+        float tw[4];
+        car_bilinear_taps(grid[2 * mp], grid[2 * mp + 1], L.w[l], L.h[l], mode, tidx, tw);
+        const float4 g4 = *reinterpret_cast<const float4*>(dout + row * ld_out + col_out + 4 * q);
+        float* base = L.map[l] + (long)m * L.h[l] * L.w[l] * L.c[l] + 4 * (q - L.q0[l]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (tw[t] == 0.0f) continue;
+            float* p = base + (long)tidx[t] * L.c[l];
+            atomicAdd(p + 0, tw[t] * g4.x); atomicAdd(p + 1, tw[t] * g4.y); atomicAdd(p + 2, tw[t] * g4.z); atomicAdd(p + 3, tw[t] * g4.w);
+        }
+    }
+}
+
+// ---- element-wise pieces --------------------------------------------------------------------------------------------
+__global__ void relu_mask_kernel(float* __restrict__ grad, int ldg, const float* __restrict__ act, int lda, long M, int N) {
+    const long total = M * N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / N;
+        const int n = (int)(idx % N);
+        if (!(act[m * lda + n] > 0.0f)) grad[m * ldg + n] = 0.0f;
+    }
+}
+// out[m][:] (+)= scale * s[m / group] * x[m][:]
+__global__ void scale_rows_kernel(float* __restrict__ out, int ldo, const float* __restrict__ x, int ldx, const float* __restrict__ s, long group,
+                                  float scale, long M, int N, int accumulate) {
+    const long total = M * N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / N;
+        const int n = (int)(idx % N);
+        const float v = scale * s[m / group] * x[m * ldx + n];
+        out[m * ldo + n] = accumulate ? out[m * ldo + n] + v : v;
+    }
+}
+// out = alpha a + beta b  (b may be NULL)
+__global__ void add_kernel(float* __restrict__ out, int ldo, const float* __restrict__ a, int lda, float alpha, const float* __restrict__ bq, int ldb,
+                           float beta, long M, int N) {
+    const long total = M * N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx / N;
+        const int n = (int)(idx % N);
+        float v = alpha * a[m * lda + n];
+        if (bq) v += beta * bq[m * ldb + n];
+        out[m * ldo + n] = v;
+    }
+}
+// du[sc][ray][c] = sum over the V P samples of the ray of d[row][c]      (backward of the per-ray broadcast of car_add_ray_bias_relu)
+__global__ void __launch_bounds__(256) reduce_samples_kernel(const float* __restrict__ d, int b, int V, int R, int P, int C, float* __restrict__ du) {
+    const int sc = blockIdx.x / R, r = blockIdx.x % R;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.0f;
+        for (int v = 0; v < V; ++v) {
+            const float* base = d + (((long)(sc * V + v) * R + r) * P) * C + c;
+            for (int p = 0; p < P; ++p) acc += base[(long)p * C];
+        }
+        du[((long)sc * R + r) * C + c] = acc;
+    }
+}
+
+unsigned grid_for(long total) {
+    const long blocks = (total + 255) / 256;
+    return (unsigned)(blocks < 1 ? 1 : (blocks < 65536 ? blocks : 65536));
+}
+
+}  // namespace
+
+extern "C" int car_linear_wgrad(const float* dY, int ldy, const float* X, int ldx, long M, int N, int K, int flags, float* dW, int lddw,
+                                float* db, void* stream) {
+    CAR_REQUIRE(dY && X && dW, "car_linear_wgrad: null pointer");
+    CAR_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && lddw >= K, "car_linear_wgrad: bad sizes M=%ld N=%d K=%d", M, N, K);
+    const int Kb = db ? K + 1 : K;
+    const unsigned gx = car_div_up(N, 32 * kWgTN), gy = car_div_up(Kb, 32 * kWgTK);
+    // slabs: enough workgroups to fill the chip (>= ~2048 waves), rows per wave a multiple of the unrolled step
+    long want = 2048 / ((long)gx * gy * 4);
+    if (want < 1) want = 1;
+    long slab = (M + want * 4 - 1) / (want * 4);
+    slab = (slab + 2 * kWgUnroll - 1) / (2 * kWgUnroll) * (2 * kWgUnroll);
+    const unsigned gz = car_div_up(M, slab * 4);
+    CAR_REQUIRE(gz <= 65535, "car_linear_wgrad: too many row slabs");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(wgrad_kernel, dim3(gx, gy, gz), dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K, (flags & CAR_LIN_RELU_IN) ? 1 : 0,
+                       (int)slab, dW, lddw, db);
+    CAR_CHECK_LAUNCH("car_linear_wgrad");
+    return CAR_OK;
+}
+
+extern "C" int car_attend_backward(const float* w, const float* val, int D, int b, int V, int R, int P, const float* dz, int ld_dz,
+                                   const float* ddepth, const float* pt, const float* poses, float* dval, int accumulate, float* dlogit,
+                                   void* stream) {
+    CAR_REQUIRE(w && val && dz && dval && dlogit, "car_attend_backward: null pointer");
+    CAR_REQUIRE(b > 0 && V > 0 && V <= CAR_MAX_VIEWS && R > 0 && P > 0 && V * P <= kMaxSamples, "car_attend_backward: bad sizes");
+    CAR_REQUIRE(D > 0 && D % 4 == 0 && ld_dz >= D && ld_dz % 4 == 0, "car_attend_backward: D = %d must be a multiple of 4", D);
+    CAR_REQUIRE(!ddepth || (pt && poses), "car_attend_backward: ddepth needs pt and poses");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(attend_bwd_kernel, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, w, val, D, b, V, R, P, dz, ld_dz, ddepth,
+                       pt, (const CarPose*)poses, dval, accumulate, dlogit);
+    CAR_CHECK_LAUNCH("car_attend_backward");
+    return CAR_OK;
+}
+
+extern "C" int car_gather_bilinear_backward(float* const* dmaps, const int* level_c, const int* level_h, const int* level_w, int n_levels,
+                                            int n_maps, const float* grid, long pts, int mode, int place, int V, const float* dout, int ld_out,
+                                            int col_out, void* stream) {
+    CAR_REQUIRE(dmaps && level_c && level_h && level_w && grid && dout, "car_gather_bilinear_backward: null pointer");
+    CAR_REQUIRE(n_levels > 0 && n_levels <= CAR_MAX_LEVELS && n_maps > 0 && pts > 0, "car_gather_bilinear_backward: bad sizes");
+    CAR_REQUIRE(mode == 0 || mode == 1, "car_gather_bilinear_backward: mode must be 0 (border) or 1 (zeros)");
+    CAR_REQUIRE(place == CAR_PLACE_PLAIN || place == CAR_PLACE_OWN || (place == CAR_PLACE_OTHER2 && V == 2 && n_maps % 2 == 0),
+                "car_gather_bilinear_backward: bad placement %d for V=%d", place, V);
+    ScatterLevels L;
+    L.n_levels = n_levels;
+    int q = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        CAR_REQUIRE(dmaps[l] && level_c[l] > 0 && level_c[l] % 4 == 0 && level_h[l] > 0 && level_w[l] > 0,
+                    "car_gather_bilinear_backward: level %d needs a channel count that is a positive multiple of 4", l);
+        L.map[l] = dmaps[l]; L.c[l] = level_c[l]; L.h[l] = level_h[l]; L.w[l] = level_w[l];
+        L.q0[l] = q;
+        q += level_c[l] / 4;
+    }
+    L.q0[n_levels] = q;
+    for (int l = n_levels; l < CAR_MAX_LEVELS; ++l) { L.map[l] = nullptr; L.c[l] = L.h[l] = L.w[l] = 0; if (l > n_levels) L.q0[l] = q; }
+    CAR_REQUIRE(ld_out % 4 == 0 && col_out % 4 == 0 && col_out >= 0 && col_out + 4 * q <= ld_out,
+                "car_gather_bilinear_backward: window [%d,%d) must be float4-aligned inside a row of %d", col_out, col_out + 4 * q, ld_out);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(gather_bwd_kernel, dim3(grid_for((long)n_maps * pts * q)), dim3(256), 0, (hipStream_t)stream, L, n_maps, grid, pts, mode, place, V,
+                       dout, ld_out, col_out);
+    CAR_CHECK_LAUNCH("car_gather_bilinear_backward");
+    return CAR_OK;
+}
+
+extern "C" int car_relu_mask(float* grad, int ldg, const float* act, int lda, long M, int N, void* stream) {
+    CAR_REQUIRE(grad && act && M > 0 && N > 0 && ldg >= N && lda >= N, "car_relu_mask: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(M * N)), dim3(256), 0, (hipStream_t)stream, grad, ldg, act, lda, M, N);
+    CAR_CHECK_LAUNCH("car_relu_mask");
+    return CAR_OK;
+}
+
+extern "C" int car_scale_rows(float* out, int ldo, const float* x, int ldx, const float* s, long group, float scale, long M, int N, int accumulate,
+                              void* stream) {
+    CAR_REQUIRE(out && x && s && M > 0 && N > 0 && group > 0 && ldo >= N && ldx >= N, "car_scale_rows: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(M * N)), dim3(256), 0, (hipStream_t)stream, out, ldo, x, ldx, s, group, scale, M, N, accumulate);
+    CAR_CHECK_LAUNCH("car_scale_rows");
+    return CAR_OK;
+}
+
+extern "C" int car_add(float* out, int ldo, const float* a, int lda, float alpha, const float* b, int ldb, float beta, long M, int N, void* stream) {
+    CAR_REQUIRE(out && a && M > 0 && N > 0 && ldo >= N && lda >= N && (!b || ldb >= N), "car_add: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(M * N)), dim3(256), 0, (hipStream_t)stream, out, ldo, a, lda, alpha, b, ldb, beta, M, N);
+    CAR_CHECK_LAUNCH("car_add");
+    return CAR_OK;
+}
+
+extern "C" int car_reduce_samples(const float* d, int b, int V, int R, int P, int C, float* du, void* stream) {
+    CAR_REQUIRE(d && du && b > 0 && V > 0 && R > 0 && P > 0 && C > 0, "car_reduce_samples: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(reduce_samples_kernel, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, d, b, V, R, P, C, du);
+    CAR_CHECK_LAUNCH("car_reduce_samples");
+    return CAR_OK;
+}

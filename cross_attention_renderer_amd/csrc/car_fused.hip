@@ -21,10 +21,17 @@
 
 namespace {
 
-constexpr int kWaves = 12, kRows = 16, kGroup = kWaves * kRows;      // 192 samples per workgroup
-constexpr int kStepsPerGroup = 4, kBundles = kWaves / kStepsPerGroup;  // 3 bundles of 16 rays x 4 steps
+#ifndef CAR_FUSED_WAVES
+#define CAR_FUSED_WAVES 12
+#endif
+constexpr int kWaves = CAR_FUSED_WAVES, kRows = 16, kGroup = kWaves * kRows;      // samples per workgroup
+constexpr int kStepsPerGroup = 4, kBundles = kWaves / kStepsPerGroup;  // bundles of 16 rays x 4 steps
+constexpr int kThreads = 64 * kWaves;
 
-constexpr int kPieces = 3;                         // LDS-DMA pieces per chunk: 12 waves x 1 KB each
+constexpr int kPieces = (36 + kWaves - 1) / kWaves;                    // LDS-DMA pieces per chunk: kWaves x 1 KB each
+// tap batches (4 loads = 16 registers each) a wave keeps in flight: the gather is bound by the latency of its far misses times the
+// loads in flight (gather alone: 2.5 ms per 8192 rays with 8 loads per wave, 1.2 ms with 32), and registers are what holds them
+constexpr int kRing = kWaves == 8 ? 6 : 2;
 constexpr unsigned kDeadTap = 0xfffffe00u;         // tap-table entry of a sample that reads exact zeros: beyond any map, no wrap with the column offset
 constexpr long kMaxMapBytes = 0xfffff000L;         // a map of one call stays below it
 
@@ -69,7 +76,7 @@ struct FusedArgs {
 constexpr int kChK1 = 5;
 constexpr int kG_W2b = kKS, kG_K1b = 2 * kKS, kG_K1a = kG_K1b + kChK1, kG_K2 = kG_K1a + kChK1, kG_Q1 = kG_K2 + 2, kG_Q2 = kG_Q1 + 1;
 static_assert(kG_Q2 + 2 == kNumChunks, "chunk count");
-__device__ __forceinline__ int chunk_tile_offset(int g) {
+__device__ __forceinline__ constexpr int chunk_tile_offset(int g) {
     if (g < kG_W2b) return kOffW2 + g * kTE;
     if (g < kG_K1b) return kOffW2 + (g - kG_W2b) * kTE;
     if (g < kG_K1a) return kOffK1 + 9 * kTD + (g - kG_K1b) * 2 * kTD;
@@ -78,10 +85,20 @@ __device__ __forceinline__ int chunk_tile_offset(int g) {
     if (g < kG_Q2) return kOffQ1;
     return kOffQ2 + (g - kG_Q2) * 2 * kTD;
 }
-__device__ __forceinline__ int chunk_tiles(int g) {
+__device__ __forceinline__ constexpr int chunk_tiles(int g) {
     if (g < kG_K1b) return kTE;
     if (g == kG_K1a - 1 || g == kG_K2 - 1 || g == kG_Q1) return kTD;                      // odd last K1 step, Q1
     return 2 * kTD;
+}
+// the chunk after g inside the two source passes (g + 1 in [1, 36]): selects only, no branch tree in the hot loop
+__device__ __forceinline__ NextChunk next_chunk_w2(const float* __restrict__ blob, float* lds, int gn) {
+    const bool w2 = gn < kG_K1b;
+    const int step = gn >= kG_W2b ? gn - kG_W2b : gn;
+    NextChunk n;
+    n.src = blob + (long)(w2 ? kOffW2 + step * kTE : chunk_tile_offset(kG_K1b)) * kTile;
+    n.dst = lds + kLdsW + (gn & 1) * kChunkTiles * kTile;
+    n.nkb = w2 ? 2 * kTE : 2 * chunk_tiles(kG_K1b);
+    return n;
 }
 
 // ABL > 0: timing-only ablations (wrong results), instantiated only in the -DCAR_ABLATION development build (tools/):
@@ -93,7 +110,7 @@ __device__ __forceinline__ int chunk_tiles(int g) {
 // 14: four taps per sample and source from ONE map (the caller hands a lattice of the full three-level size, 521 x 521 nodes for a
 // 256 x 256 frame, with arbitrary contents): the cost side of merging the finest level into the lattice too
 template <int ABL>
-__global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : 768) fused_kernel(const FusedArgs a) {
+__global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : kThreads) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 15, q4 = lane >> 4;
@@ -116,8 +133,8 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : 768) fused_ke
     long long stamp[12];
     auto mark = [&](int k) { if constexpr (ABL == 4) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); };
     mark(0);
-    for (int k = tid; k < kC; k += 768) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
-    for (int k = tid; k < kBiasFloats; k += 768) lds[kLdsBias + k] = a.bias[k];
+    for (int k = tid; k < kC; k += kThreads) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
+    for (int k = tid; k < kBiasFloats; k += kThreads) lds[kLdsBias + k] = a.bias[k];
     int g = 0;
     stream_issue_all<ABL>(a.blob, lds, 0, lane, wave);
 
@@ -212,10 +229,17 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : 768) fused_ke
         const unsigned tbv = reinterpret_cast<const unsigned*>(lds + kLdsTapB)[((wave * kRows + row) * 2 + sv) * 2 + l];
         const unsigned o00 = (tbv & ~3u) + col, dx = (tbv & 1u) ? (unsigned)(kC * 4) : 0u, dy = (tbv & 2u) ? row_step[l] : 0u;
         auto ld = [&](unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc[l], (int)off, chunk_off, 0)); };
+        if constexpr (ABL == 18) {            // gather alone, taps in the order nw, sw, ne, se: the east taps (neighbouring rays' west taps) one instruction later
+            tap[0] = ld(o00); tap[2] = ld(o00 + dy); tap[1] = ld(o00 + dx); tap[3] = ld(o00 + dx + dy);
+        } else if constexpr (ABL == 19) {     // gather alone, east taps moved 16 nodes over: no line shared with a neighbouring ray's west taps (timing only)
+            const unsigned far = dx ? 16u * (unsigned)(kC * 4) : 0u;
+            tap[0] = ld(o00); tap[1] = ld(o00 + far); tap[2] = ld(o00 + dy); tap[3] = ld(o00 + far + dy);
+        } else {
         tap[0] = ld(o00);
         tap[1] = ld(o00 + dx);
         tap[2] = ld(o00 + dy);
         tap[3] = ld(o00 + dx + dy);
+        }
     };
     auto blend_row = [&](const f32x4 (&tap)[4], int sv, int l, int it) {
         if constexpr (ABL == 2 || ABL == 3 || ABL == 12) return;
@@ -295,6 +319,89 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : 768) fused_ke
         if (lds[kLdsStage + tid] == 123.456f) a.logit[0] = 1.0f;
         return;
     }
+    f32x4 acc[kTE];
+    float m0 = 0.0f;                                                   // largest |e_0| of this lane's sample
+    half8 bhi, blo;
+    constexpr bool kTapsLive = (ABL == 0 || ABL >= 5);
+    if constexpr (kRing > 2) {
+        // ---- ring schedule (8 waves, 256 registers): kRing = 6 tap batches in flight per wave.  Batch j = 4 m + k is batch k of flat
+        //      chunk m = 18 sv + c, in the order (map, row group) = (1,0) (1,1) (0,0) (0,1); it lives in ring[j % 6].  While the
+        //      matrix pipe works on chunk m, the wave blends the four batches of chunk m + 1 and re-issues each freed buffer with
+        //      batch j + 6 (chunks m + 2 / m + 3).  The chunk loop is unrolled by 3 so that every buffer index is a constant. ----
+        f32x4 ring[kRing][4];
+        auto batch_l = [](int k) { return 1 - (k >> 1); };
+        auto issue_flat = [&](f32x4 (&tap)[4], int mm, int k) {        // batch k of flat chunk mm (past the end: re-reads source 1)
+            const int me = mm < 2 * kKS ? mm : mm - kKS;
+            const int bsv = me >= kKS ? 1 : 0;
+            issue_row(tap, bsv, me - bsv * kKS, batch_l(k), k & 1);
+        };
+        // chunk 0: nothing to hide it under
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            affine_row(0, 0, it);
+#pragma unroll
+            for (int l = 1; l >= 0; --l) {
+                issue_row(ring[0], 0, 0, l, it);
+                blend_row(ring[0], 0, l, it);
+            }
+            finish_row(it);
+        }
+        stream_sync();                                                 // weight chunk 0 landed
+        mark(2);
+#pragma unroll
+        for (int j = 4; j < 4 + kRing; ++j) issue_flat(ring[j % kRing], j >> 2, j & 3);      // prologue: the ring's first turn
+        read_b(bhi, blo);
+#pragma unroll 1
+        for (int sv = 0; sv < 2; ++sv) {
+            init_bias<kTE>(acc, lds + kLdsBias + kBiasE, q4, e_up);
+#pragma unroll 1
+            for (int c0 = 0; c0 < kKS; c0 += 3) {
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int m = kKS * sv + c0 + u;                   // chunk on the matrix pipe; chunk m + 1 is being gathered
+                    const int ne = m + 1 < 2 * kKS ? m + 1 : m + 1 - kKS;
+                    const int nsv = ne >= kKS ? 1 : 0, nc = ne - nsv * kKS;
+                    const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
+                    const NextChunk nx = next_chunk_w2(a.blob, lds, g + 1);
+                    // every DMA piece of the next weight chunk goes out before this chunk's tap loads: at the chunk's end
+                    // "at most 16 outstanding" then means the weights have landed while four tap batches stay in flight
+                    auto piece = [&](int qs) {
+                        if (qs == 0) {
+#pragma unroll
+                            for (int pp_ = 0; pp_ < 3 && pp_ < kPieces; ++pp_) stream_issue_piece<ABL>(nx, pp_, lane, wave);
+                            affine_row(nsv, nc, 0); affine_row(nsv, nc, 1);
+                        } else if (qs == 1) {
+#pragma unroll
+                            for (int pp_ = 3; pp_ < kPieces; ++pp_) stream_issue_piece<ABL>(nx, pp_, lane, wave);
+                        } else if (qs == 2 || qs == 3 || qs == 6 || qs == 7) {
+                            const int k = qs == 2 ? 0 : qs == 3 ? 1 : qs == 6 ? 2 : 3;
+                            constexpr int dummy = 0; (void)dummy;
+                            f32x4 (&buf)[4] = ring[(4 * (u + 1) + k) % kRing];
+                            blend_row(buf, nsv, batch_l(k), k & 1);
+                            if (k >= 2) finish_row(k & 1);
+                            issue_flat(buf, m + 1 + (k + kRing) / 4, (k + kRing) & 3);
+                        }
+                    };
+#pragma unroll
+                    for (int qs = 0; qs < kTE / 2; ++qs) {
+                        const float* w0 = wl + (2 * qs * 2) * 256;
+                        if constexpr (ABL < 5 || (ABL >= 11 && ABL < 18)) mfma_pair<ABL>(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
+                        piece(qs);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    read_b(bhi, blo);                                  // next chunk's B operand (own LDS tile, in-order LDS)
+                    stream_sync<ABL, kTapsLive ? 16 : 0>();            // the 16 tap loads of this chunk stay in flight over the barrier
+                    ++g;
+                }
+            }
+            scale_acc<kTE>(acc, e_down);
+            mark(3 + sv);
+            if (sv == 0) {
+                m0 = sample_max<kTE, false>(acc);
+                if (live) store_rows<kTE>(acc, a.e + i * (2 * kE), q4);
+            }
+        }
+    } else {
     // first chunk of source 0: nothing to hide it under
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -308,13 +415,9 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : 768) fused_ke
     }
     stream_sync();                                                     // weight chunk 0 landed
     mark(2);
-    constexpr bool kTapsLive = (ABL == 0 || ABL >= 5);
     issue_row(bufA, 0, 1, 1, 0);                                       // pipeline prologue: the finest level of chunk (0, 1), both row groups
     issue_row(bufB, 0, 1, 1, 1);
 
-    f32x4 acc[kTE];
-    float m0 = 0.0f;                                                   // largest |e_0| of this lane's sample
-    half8 bhi, blo;
     read_b(bhi, blo);
 #pragma unroll 1
     for (int sv = 0; sv < 2; ++sv) {
@@ -328,7 +431,7 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : 768) fused_ke
             const int n2sv = (c + 2 < kKS) ? sv : 1;
             const int n2c = (c + 2 < kKS) ? c + 2 : c + 2 - kKS;
             const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
-            const NextChunk nx = next_chunk(a.blob, lds, g + 1);
+            const NextChunk nx = next_chunk_w2(a.blob, lds, g + 1);
             // 9 slots of (4 ds_read_b128 + 6 MFMAs of 16 cycles); between them one piece of the gather / DMA issue.  Batches (map, row
             // group) in the order (1,0) (1,1) (0,0) (0,1); batch k is blended in slot {2,3,6,7}[k] and batch k+2 issued into the buffer
             // it frees; slots 0-2 also carry the DMA pieces, slot 0 the affine start values.
@@ -343,7 +446,7 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : 768) fused_ke
 #pragma unroll
             for (int qs = 0; qs < kTE / 2; ++qs) {
                 const float* w0 = wl + (2 * qs * 2) * 256;
-                if constexpr (ABL < 5 || ABL >= 11) mfma_pair<ABL>(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
+                if constexpr (ABL < 5 || (ABL >= 11 && ABL < 18)) mfma_pair<ABL>(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
                 piece(qs);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -358,6 +461,7 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : 768) fused_ke
             m0 = sample_max<kTE, false>(acc);
             if (live) store_rows<kTE>(acc, a.e + i * (2 * kE), q4);
         }
+    }
     }
     // ---- k1 = Wk1 [e_0 ; e_1] + bk1: first the e_1 half, chained from the accumulators; then e_1 is stored and its registers take
     //      e_0 back from the output tensor (written by this wave one source pass ago: L2), same layout, for the other half ----
@@ -379,16 +483,16 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : 768) fused_ke
             acc[t] = *reinterpret_cast<const f32x4*>(erow + 16 * t);
         }
     };
-    chained_layer<kTE, false, ABL, 4>(k1, acc, p, a.blob, lds, g, lane, wave, swap_tiles);
+    chained_layer<kTE, false, ABL, kG_K1b, 4>(k1, acc, p, a.blob, lds, lane, wave, swap_tiles);
     mark(7);
     if constexpr (ABL == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mark(9); }
-    chained_layer<kTE, false, ABL>(k1, acc, p, a.blob, lds, g, lane, wave);
+    chained_layer<kTE, false, ABL, kG_K1a>(k1, acc, p, a.blob, lds, lane, wave);
     mark(8);
     scale_acc<kTD>(k1, lsc[kLayerK1] * pinv);
     f32x4 key[kTD];
     pow2_scale(fmaxf(sample_max<kTD, true>(k1), 1e-30f), p, pinv);
     init_bias<kTD>(key, lds + kLdsBias + kBiasK2, q4, p / lsc[kLayerK2]);
-    chained_layer<kTD, true, ABL>(key, k1, p, a.blob, lds, g, lane, wave);
+    chained_layer<kTD, true, ABL, kG_K2>(key, k1, p, a.blob, lds, lane, wave);
     scale_acc<kTD>(key, lsc[kLayerK2] * pinv);
 
     mark(5);
@@ -410,14 +514,13 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : 768) fused_ke
     f32x4 t1[kTD], qv[kTD];
 #pragma unroll
     for (int t = 0; t < kTD; ++t) t1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    stream_issue_all<ABL>(a.blob, lds, g + 1, lane, wave);
-    small_layer(t1, ghi, glo, lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane);          // q1
+    stream_issue_all<ABL>(a.blob, lds, kG_Q1 + 1, lane, wave);
+    small_layer(t1, ghi, glo, lds + kLdsW + (kG_Q1 & 1) * kChunkTiles * kTile + 4 * lane);          // q1
     stream_sync<ABL>();
-    ++g;
     scale_acc<kTD>(t1, lsc[kLayerQ1] * pinv);
     pow2_scale(fmaxf(sample_max<kTD, true>(t1), 1e-30f), p, pinv);
     init_bias<kTD>(qv, lds + kLdsBias + kBiasQ2, q4, p / lsc[kLayerQ2]);
-    chained_layer<kTD, true, ABL>(qv, t1, p, a.blob, lds, g, lane, wave);
+    chained_layer<kTD, true, ABL, kG_Q2>(qv, t1, p, a.blob, lds, lane, wave);
     scale_acc<kTD>(qv, lsc[kLayerQ2] * pinv);
     float dot = 0.0f;
 #pragma unroll
@@ -468,7 +571,7 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     switch (abl) {
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 5: kern = fused_kernel<5>; break;   case 6: kern = fused_kernel<6>; break;   case 7: kern = fused_kernel<7>; break;
-        case 8: kern = fused_kernel<8>; break;   case 11: kern = fused_kernel<11>; break;   case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;   case 14: kern = fused_kernel<14>; break;   case 15: kern = fused_kernel<15>; break;   case 16: kern = fused_kernel<16>; break;   case 17: kern = fused_kernel<17>; break;
+        case 8: kern = fused_kernel<8>; break;   case 11: kern = fused_kernel<11>; break;   case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;   case 14: kern = fused_kernel<14>; break;   case 15: kern = fused_kernel<15>; break;   case 16: kern = fused_kernel<16>; break;   case 17: kern = fused_kernel<17>; break;   case 18: kern = fused_kernel<18>; break;   case 19: kern = fused_kernel<19>; break;
         case 4: kern = fused_kernel<4>; break;
         default: break;
     }
@@ -478,7 +581,7 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e1 != hipSuccess) { car_set_error("car_fused_samples: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3((abl == 16 || abl == 17) ? 512 : 768), kLdsBytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3((abl == 16 || abl == 17) ? 512 : kThreads), kLdsBytes, (hipStream_t)stream, a);
     CAR_CHECK_LAUNCH("car_fused_samples");
     return CAR_OK;
 }

@@ -24,8 +24,8 @@ constexpr int kStageLd = 36;       // row stride of the wave-private h tile (flo
 // ---- dynamic LDS carve-up (floats) --------------------------------------------------------------------------------
 constexpr int kLdsW = 0;                                        // [2][18][512]           weight chunks          72 KB
 
-__device__ __forceinline__ int chunk_tile_offset(int g);      // defined by the including kernel file
-__device__ __forceinline__ int chunk_tiles(int g);
+__device__ __forceinline__ constexpr int chunk_tile_offset(int g);      // defined by the including kernel file
+__device__ __forceinline__ constexpr int chunk_tiles(int g);
 
 // Descriptor of the chunk to prefetch, resolved once per chunk with scalar branches so the per-piece issue is straight-line
 struct NextChunk { const float* src; float* dst; int nkb; };
@@ -41,7 +41,7 @@ __device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, 
 // LDS-DMA in inline asm, see car_linear.hip.  Must only run after the barrier that retired the buffer's previous chunk.
 template <int ABL = 0>
 __device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, int lane, int wave) {
-    if constexpr (ABL == 3 || ABL == 12 || (ABL >= 5 && ABL < 11)) return;
+    if constexpr (ABL == 3 || ABL == 12 || (ABL >= 5 && ABL < 11) || ABL == 18 || ABL == 19) return;
     int kb = kWaves * p + wave;
     kb = kb < n.nkb ? kb : kb - n.nkb;
     kb = kb < n.nkb ? kb : kb - n.nkb;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void stream_issue_all(const float* __restrict__ blob,
 // order, so "at most KEEP outstanding" still means every DMA piece has landed).
 template <int ABL = 0, int KEEP = 0>
 __device__ __forceinline__ void stream_sync() {
-    if constexpr (ABL == 3 || ABL == 12 || (ABL >= 5 && ABL < 11)) return;
+    if constexpr (ABL == 3 || ABL == 12 || (ABL >= 5 && ABL < 11) || ABL == 18 || ABL == 19) return;
     if constexpr (KEEP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -150,13 +150,16 @@ __device__ __forceinline__ void store_rows(const f32x4 (&acc)[NT], float* row, i
 // source tiles are consumed by then); HOOK_OPS = the number of vector memory instructions it issues per call (they are younger
 // than the chunk's DMA pieces and may stay in flight across the chunk barrier).
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
-template <int NSRC, bool RELU, int ABL, int HOOK_OPS = 0, class Hook = NoHook>
+// G0: index of the layer's first weight chunk.  The chunk order is static, so every chunk's place in the blob, its size and its LDS
+// buffer are constants here (resolving them at run time cost a chain of ~20 scalar branches per chunk).
+template <int NSRC, bool RELU, int ABL, int G0, int HOOK_OPS = 0, class Hook = NoHook>
 __device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&src)[NSRC], float p, const float* __restrict__ blob,
-                                              float* lds, int& g, int lane, int wave, Hook after = Hook()) {
+                                              float* lds, int lane, int wave, Hook after = Hook()) {
     constexpr int kSteps = NSRC / 2;
 #pragma unroll
     for (int m0 = 0; m0 < kSteps; m0 += 2) {
         const int nks = m0 + 1 < kSteps ? 2 : 1;
+        const int g = G0 + m0 / 2;
         const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
         const NextChunk nx = next_chunk(blob, lds, g + 1);
 #pragma unroll
@@ -175,19 +178,21 @@ __device__ __forceinline__ void chained_layer(f32x4 (&acc)[kTD], const f32x4 (&s
                 for (int q = 0; q < kTD / 2; ++q) {
                     const float* w0 = wl + ((kl * kTD + 2 * q) * 2) * 256;
                     mfma_pair<ABL>(acc[2 * q], acc[2 * q + 1], w0, w0 + 512, bhi, blo);
-                    if (kl * 4 + q < kPieces) stream_issue_piece<ABL>(nx, kl * 4 + q, lane, wave);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // a single-step chunk has only 4 slots: issue the remaining pieces of its successor before the hook's memory operations
-                if (kl + 1 == nks) {
+                    // every DMA piece of the successor goes out in the first K step's four slots, ahead of the hook's memory
+                    // operations: the chunk's closing "at most HOOK_OPS outstanding" must cover all of them
+                    if (kl == 0) {
+                        if (q < 3) { if (q < kPieces) stream_issue_piece<ABL>(nx, q, lane, wave); }
+                        else {
 #pragma unroll
-                    for (int p_ = nks * 4; p_ < kPieces; ++p_) stream_issue_piece<ABL>(nx, p_, lane, wave);
+                            for (int p_ = 3; p_ < kPieces; ++p_) stream_issue_piece<ABL>(nx, p_, lane, wave);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 after(m);
             }
         }
         if (nks == 2) stream_sync<ABL, 2 * HOOK_OPS>(); else stream_sync<ABL, HOOK_OPS>();
-        ++g;
     }
 }
 

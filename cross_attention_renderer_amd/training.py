@@ -1,0 +1,378 @@
+"""Training-side entry of the render path: the forward of the staged route with every intermediate kept, its
+backward, and the gradient all-reduce of the reference's training loop.
+
+The reference trains with torch autograd over ``CrossAttentionRenderer.forward`` (training.py:92-136): ``model(model_input)`` on a few
+hundred random rays per scene, a loss on ``rgb`` (and optionally ``depth_ray``, loss_functions.py:74-132), ``backward()``, then
+``average_gradients`` (training.py:21-28) when several GPUs train replicas.  Here ``render_train`` is that forward as a
+``torch.autograd.Function`` whose forward AND backward are HIP kernels of ``libcar_hip.so``:
+
+  forward   the stage entries of ``engine.py`` (geometry, literal gather -> 579-wide GEMM, attention rounds, decoder), none fused away,
+            because the backward needs what the fused inference kernels never write: the gathered rows, the first layer's
+            activations, keys, queries;
+  backward  ``car_linear`` with transposed weights (data gradients), ``car_linear_wgrad`` (weight / bias gradients),
+            ``car_attend_backward``, ``car_gather_bilinear_backward`` (scatter-add into the pyramid), and the element-wise pieces
+            (csrc/car_backward.hip).
+
+Gradients flow to every renderer parameter on the path and to the feature pyramid ``z`` — and through ``z``, by ordinary torch
+autograd, into the encoder when ``z`` came from ``get_z``.  The geometry is not differentiated: nothing in it depends on a parameter.
+PyTorch is plumbing here as everywhere: storage, views, the autograd graph edge, ``torch.distributed``.
+
+Supported: the reference's default configuration family — two context views with the cross-view exchange (``n_view=2``, epipolar
+sampling), with or without the second attention round, any channel widths.  The other constructor variants raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .engine import ACCUM, PLACE_OTHER2, PLACE_OWN, RELU_IN, RELU_OUT, PackedLinear, RenderEngine, _ptr, _round_up, _stream
+
+Tensor = torch.Tensor
+
+
+def _check(code, what):
+    _lib.check(code, what)
+
+
+class _Ops:
+    """Thin typed wrappers over the backward entry points of the C ABI (include/car_hip.h)."""
+
+    def __init__(self, eng: RenderEngine):
+        self.eng, self.lib = eng, eng.lib
+        self._t: Dict[tuple, PackedLinear] = {}
+
+    def transposed(self, name: str, w: Tensor) -> PackedLinear:
+        """W [N, K] -> the layer x -> x W (weight W^T [K, N], no bias): car_linear then computes dX = dY W."""
+        key = (name, w.data_ptr(), w._version, str(w.device))
+        if key not in self._t:
+            self._t = {k: v for k, v in self._t.items() if k[0] != name}
+            self._t[key] = PackedLinear(w.detach().reshape(w.shape[0], -1).t().contiguous(), None, w.device, name + "^T")
+        return self._t[key]
+
+    def wgrad(self, dy: Tensor, ldy: int, x: Tensor, ldx: int, M: int, N: int, K: int, dw: Tensor, lddw: int, db: Optional[Tensor], relu_x=False):
+        _check(self.lib.car_linear_wgrad(_ptr(dy), ldy, _ptr(x), ldx, M, N, K, RELU_IN if relu_x else 0, _ptr(dw), lddw, _ptr(db), _stream()),
+               "car_linear_wgrad")
+
+    def relu_mask(self, grad: Tensor, ldg: int, act: Tensor, lda: int, M: int, N: int):
+        _check(self.lib.car_relu_mask(_ptr(grad), ldg, _ptr(act), lda, M, N, _stream()), "car_relu_mask")
+
+    def scale_rows(self, out: Tensor, ldo: int, x: Tensor, ldx: int, s: Tensor, group: int, scale: float, M: int, N: int, accumulate=False):
+        _check(self.lib.car_scale_rows(_ptr(out), ldo, _ptr(x), ldx, _ptr(s), group, scale, M, N, int(accumulate), _stream()), "car_scale_rows")
+
+    def add(self, out: Tensor, ldo: int, a: Tensor, lda: int, alpha: float, b: Optional[Tensor], ldb: int, beta: float, M: int, N: int):
+        _check(self.lib.car_add(_ptr(out), ldo, _ptr(a), lda, alpha, _ptr(b), ldb, beta, M, N, _stream()), "car_add")
+
+    def reduce_samples(self, d: Tensor, b: int, V: int, R: int, P: int, C: int, du: Tensor):
+        _check(self.lib.car_reduce_samples(_ptr(d), b, V, R, P, C, _ptr(du), _stream()), "car_reduce_samples")
+
+    def attend_backward(self, w, val, D, b, V, R, P, dz, ld_dz, ddepth, pt, poses, dval, accumulate, dlogit):
+        _check(self.lib.car_attend_backward(_ptr(w), _ptr(val), D, b, V, R, P, _ptr(dz), ld_dz, _ptr(ddepth), _ptr(pt), _ptr(poses), _ptr(dval),
+                                            int(accumulate), _ptr(dlogit), _stream()), "car_attend_backward")
+
+    def gather_backward(self, dmaps: List[Tensor], grid: Tensor, pts: int, mode: int, place: int, V: int, dout: Tensor, ld_out: int, col_out: int):
+        L = len(dmaps)
+        ptrs = (ctypes.c_void_p * L)(*[m.data_ptr() for m in dmaps])
+        cs = (ctypes.c_int * L)(*[m.shape[3] for m in dmaps])
+        hs = (ctypes.c_int * L)(*[m.shape[1] for m in dmaps])
+        ws = (ctypes.c_int * L)(*[m.shape[2] for m in dmaps])
+        _check(self.lib.car_gather_bilinear_backward(ptrs, cs, hs, ws, L, dmaps[0].shape[0], _ptr(grid), pts, mode, place, V, _ptr(dout), ld_out,
+                                                     col_out, _stream()), "car_gather_bilinear_backward")
+
+
+# parameters the path reads, in the order their gradients are returned
+def _param_names(m) -> List[str]:
+    names = ["query_encode_latent", "query_encode_latent_2", "latent_value", "key_map", "key_map_2", "query_embed", "query_embed_2"]
+    if m.repeat_attention:
+        names += ["query_repeat_embed", "query_repeat_embed_2", "encode_latent"]
+    names += ["phi.lin_in", "phi.lin_out"]
+    for i in range(m.phi.n_blocks):
+        names += [f"phi.lin_z.{i}", f"phi.blocks.{i}.fc_0", f"phi.blocks.{i}.fc_1"]
+    return [n + k for n in names for k in (".weight", ".bias")]
+
+
+class _RenderTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, inp, n_levels, *tensors):
+        z = list(tensors[:n_levels])
+        eng: RenderEngine = module._engine
+        m, lib = module, eng.lib
+        dev = inp["query"]["uv"].device
+        st = _stream()
+        f32 = dict(device=dev, dtype=torch.float32)
+        b, V = inp["context"]["rgb"].shape[:2]
+        R = inp["query"]["uv"].shape[2]
+        P, H, W = m.npoints, m.H, m.W
+        n, S = b * V, b * V * R * P
+        pk = eng._weights(dev)
+        maps = eng._channel_last(z)
+        C = sum(t.shape[3] for t in maps)
+        Dl, Ce, hid = m.latent_dim, V * (C // 2), m.phi.d_hidden
+        poses = eng._poses(inp, H, n, dev)
+        uv = inp["query"]["uv"].detach().reshape(b, R, 2).float().contiguous()
+        steps = eng._linspace(0.0, 1.0, P, dev)
+
+        # geometry (constant with respect to every parameter)
+        rays = torch.empty(n, R, 12, **f32)
+        coords9 = torch.empty(n, R, 9, **f32)
+        ld_phi = _round_up(9 * V, 4)
+        phi_x = torch.zeros(b * R, ld_phi, **f32)
+        _check(lib.car_ray_setup(_ptr(poses), _ptr(uv), b, V, R, H, W, P, 0, _ptr(steps), _ptr(rays), _ptr(coords9), _ptr(phi_x), ld_phi, st),
+               "car_ray_setup")
+        pixel_val = torch.empty(n, R, P, 2, **f32)
+        pt = torch.empty(n, R, P, 3, **f32)
+        g = torch.empty(S, 16, **f32)
+        grid_in = torch.empty(n, R, P, V, 2, **f32)
+        ld1 = _round_up(C + 3, 32)
+        x1 = torch.zeros(S * V, ld1, **f32)
+        _check(lib.car_sample_setup(_ptr(poses), _ptr(rays), _ptr(steps), b, V, R, P, H, W, 0, _ptr(pixel_val), _ptr(pt), _ptr(g), _ptr(grid_in),
+                                    _ptr(x1), ld1, C, None, st), "car_sample_setup")
+        # a7 / a10: the two gathers, literal
+        eng.gather(maps, pixel_val, R * P, 0, PLACE_OWN, V, x1, ld1, 0, run=P)
+        gi = grid_in.view(b, V, R, P, V, 2)
+        grid_other = torch.stack([gi[:, 1, :, :, 0], gi[:, 0, :, :, 1]], dim=1).contiguous()
+        eng.gather(maps, grid_other, R * P, 1, PLACE_OTHER2, V, x1, ld1, 0, run=P)
+        # a11
+        h1 = torch.empty(S * V, C, **f32)
+        eng.linear(x1, ld1, pk["query_encode_latent"], h1, C, S * V, RELU_OUT)
+        e = torch.empty(S, Ce, **f32)
+        eng.linear(h1, C, pk["query_encode_latent_2"], e, C // 2, S * V)
+        # a12, a13
+        k1 = torch.empty(S, 128, **f32)
+        eng.linear(e, Ce, pk["key_map"], k1, 128, S, RELU_OUT)
+        key = torch.empty(S, 128, **f32)
+        eng.linear(k1, 128, pk["key_map_2"], key, 128, S)
+        q1 = torch.empty(S, 128, **f32)
+        eng.linear(g, 16, pk["query_embed"], q1, 128, S, RELU_OUT)
+        q = torch.empty(S, 128, **f32)
+        eng.linear(q1, 128, pk["query_embed_2"], q, 128, S)
+        # a14, a16
+        at_wt = torch.empty(n, R, P, **f32)
+        depth = torch.empty(b, R, **f32)
+        amax = torch.empty(n, R, dtype=torch.int32, device=dev)
+        ebar1 = torch.empty(b * R, Ce, **f32)
+        _check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt), _ptr(ebar1), Ce, 1, _ptr(pt), _ptr(poses),
+                              _ptr(depth), _ptr(amax), st), "car_attend")
+        zrep = torch.empty(b * R, V * Dl, **f32)
+        saved = dict(x1=x1, h1=h1, e=e, k1=k1, key=key, q1=q1, q=q, at_wt=at_wt, ebar1=ebar1, g=g, pt=pt, poses=poses, rays=rays, phi_x=phi_x,
+                     pixel_val=pixel_val, grid_other=grid_other)
+        ops = _Ops(eng)
+        if m.repeat_attention:
+            z1 = torch.empty(b * R, Dl, **f32)
+            eng.linear(ebar1, Ce, pk["latent_value"], z1, Dl, b * R)
+            hb = torch.empty(b * R, 128, **f32)
+            eng.linear(z1, Dl, pk["encode_latent"], hb, 128, b * R)
+            uh = torch.empty(b * R, 128, **f32)
+            eng.linear(hb, 128, pk["query_repeat_embed.h"], uh, 128, b * R)
+            k1r = torch.empty(S, 128, **f32)
+            eng.linear(g, 16, pk["query_repeat_embed.g"], k1r, 128, S)
+            _check(lib.car_add_ray_bias_relu(_ptr(k1r), _ptr(uh), b, V, R, P, 128, st), "car_add_ray_bias_relu")
+            key2 = torch.empty(S, 128, **f32)
+            eng.linear(k1r, 128, pk["query_repeat_embed_2"], key2, 128, S)
+            at_wt2 = torch.empty(n, R, P, **f32)
+            ebar2 = torch.empty(b * R, Ce, **f32)
+            _check(lib.car_attend(_ptr(key2), _ptr(q), 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt2), _ptr(ebar2), Ce, 1, None, None, None,
+                                  None, st), "car_attend")
+            ops.add(zrep, V * Dl, z1, Dl, float(V), None, 0, 0.0, b * R, Dl)                     # z = V z1 + latent_value(ebar2)
+            eng.linear(ebar2, Ce, pk["latent_value"], zrep, V * Dl, b * R, ACCUM)
+            saved.update(z1=z1, hb=hb, k1r=k1r, key2=key2, at_wt2=at_wt2, ebar2=ebar2)
+        else:
+            eng.linear(ebar1, Ce, pk["latent_value"], zrep, V * Dl, b * R)
+        for v in range(1, V):                                                                    # per-view replication (models.py:541, 565)
+            ops.add(zrep[:, v * Dl:], V * Dl, zrep, V * Dl, 1.0, None, 0, 0.0, b * R, Dl)
+        # a17
+        x = torch.empty(b * R, hid, **f32)
+        eng.linear(phi_x, ld_phi, pk["phi.lin_in"], x, hid, b * R)
+        xas, nets = [], []
+        for i in range(m.phi.n_blocks):
+            xa = x.clone()
+            eng.linear(zrep, V * Dl, pk[f"phi.lin_z.{i}"], xa, hid, b * R, ACCUM)
+            net = torch.empty(b * R, hid, **f32)
+            eng.linear(xa, hid, pk[f"phi.blocks.{i}.fc_0"], net, hid, b * R, RELU_IN)
+            x = xa.clone()
+            eng.linear(net, hid, pk[f"phi.blocks.{i}.fc_1"], x, hid, b * R, RELU_IN | ACCUM)
+            xas.append(xa)
+            nets.append(net)
+        out3 = torch.empty(b * R, 4, **f32)
+        eng.linear(x, hid, pk["phi.lin_out"], out3, 4, b * R, RELU_IN)
+        rgb = torch.empty(b, R, 3, **f32)
+        valid = torch.empty(b, R, **f32)
+        _check(lib.car_finalize(_ptr(rays), _ptr(out3), 4, b, V, R, _ptr(rgb), _ptr(valid), st), "car_finalize")
+        saved.update(zrep=zrep, xas=xas, nets=nets, x3=x, valid=valid)
+        ctx.saved, ctx.ops, ctx.module, ctx.n_levels = saved, ops, module, n_levels
+        ctx.dims = (b, V, R, P, C, Dl, Ce, hid, ld1, ld_phi)
+        ctx.maps = maps
+        ctx.params = {nme: t for nme, t in zip(_param_names(m), tensors[n_levels:])}
+        ctx.z_dtypes = [t.dtype for t in z]
+        outs = (rgb.view(b, 1, R, 3), depth[..., None], valid[..., None], at_wt, amax.long()[..., None], coords9, pixel_val)
+        ctx.mark_non_differentiable(*outs[2:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, *_unused):
+        sv, ops, m = ctx.saved, ctx.ops, ctx.module
+        eng: RenderEngine = m._engine
+        b, V, R, P, C, Dl, Ce, hid, ld1, ld_phi = ctx.dims
+        n, S, bR = b * V, b * V * R * P, b * R
+        dev = sv["e"].device
+        f32 = dict(device=dev, dtype=torch.float32)
+        par = ctx.params
+        with torch.cuda.device(dev):
+            grads: Dict[str, Tensor] = {k: torch.zeros_like(v, dtype=torch.float32) for k, v in par.items()}
+
+            def W(name):
+                return par[name + ".weight"]
+
+            def wgrad(name, dy, ldy, x, ldx, M, relu_x=False, col0=0, K=None, bias=True):
+                w = grads[name + ".weight"]
+                N, Kfull = w.shape[0], w[0].numel()
+                K = Kfull if K is None else K
+                ops.wgrad(dy, ldy, x, ldx, M, N, K, w.view(N, Kfull)[:, col0:], Kfull, grads[name + ".bias"] if bias else None, relu_x)
+
+            def dx(name, dy, ldy, out, ldo, M, flags=0, wt=None):
+                eng.linear(dy, ldy, ops.transposed(name, W(name) if wt is None else wt), out, ldo, M, flags)
+
+            # ---- a18 / a17: white background, decoder
+            d_rgb = torch.zeros(b, R, 3, **f32) if d_rgb is None else d_rgb.detach().reshape(b, R, 3).float().contiguous()
+            d_out3 = torch.zeros(bR, 4, **f32)
+            ops.scale_rows(d_out3, 4, d_rgb, 3, sv["valid"], 1, 1.0, bR, 3)
+            wgrad("phi.lin_out", d_out3, 4, sv["x3"], hid, bR, relu_x=True)
+            d_x = torch.empty(bR, hid, **f32)
+            dx("phi.lin_out", d_out3, 4, d_x, hid, bR)
+            ops.relu_mask(d_x, hid, sv["x3"], hid, bR, hid)
+            d_zrep = torch.zeros(bR, V * Dl, **f32)
+            d_net = torch.empty(bR, hid, **f32)
+            tmp = torch.empty(bR, hid, **f32)
+            for i in reversed(range(m.phi.n_blocks)):
+                fc0, fc1, lz = f"phi.blocks.{i}.fc_0", f"phi.blocks.{i}.fc_1", f"phi.lin_z.{i}"
+                xa, net = sv["xas"][i], sv["nets"][i]
+                wgrad(fc1, d_x, hid, net, hid, bR, relu_x=True)
+                dx(fc1, d_x, hid, d_net, hid, bR)
+                ops.relu_mask(d_net, hid, net, hid, bR, hid)
+                wgrad(fc0, d_net, hid, xa, hid, bR, relu_x=True)
+                dx(fc0, d_net, hid, tmp, hid, bR)
+                ops.relu_mask(tmp, hid, xa, hid, bR, hid)
+                ops.add(d_x, hid, d_x, hid, 1.0, tmp, hid, 1.0, bR, hid)                             # d xa = d x + (d net Wfc0) [xa > 0]
+                wgrad(lz, d_x, hid, sv["zrep"], V * Dl, bR)
+                dx(lz, d_x, hid, d_zrep, V * Dl, bR, ACCUM)
+            wgrad("phi.lin_in", d_x, hid, sv["phi_x"], ld_phi, bR)
+            # the V copies of z
+            d_zf = torch.empty(bR, Dl, **f32)
+            ops.add(d_zf, Dl, d_zrep, V * Dl, 1.0, d_zrep[:, Dl:], V * Dl, 1.0, bR, Dl)
+            for v in range(2, V):
+                ops.add(d_zf, Dl, d_zf, Dl, 1.0, d_zrep[:, v * Dl:], V * Dl, 1.0, bR, Dl)
+
+            d_e = torch.empty(S, Ce, **f32)
+            d_q = torch.empty(S, 128, **f32)
+            d_key = torch.empty(S, 128, **f32)
+            dlogit = torch.empty(S, **f32)
+            d_ebar = torch.empty(bR, Ce, **f32)
+            d_depth_t = None if d_depth is None else d_depth.detach().reshape(bR).float().contiguous()
+            have_e = False
+            if m.repeat_attention:
+                # ---- a15: z = V z1 + latent_value(ebar2)
+                wgrad("latent_value", d_zf, Dl, sv["ebar2"], Ce, bR)
+                dx("latent_value", d_zf, Dl, d_ebar, Ce, bR)
+                ops.attend_backward(sv["at_wt2"], sv["e"], Ce, b, V, R, P, d_ebar, Ce, None, None, None, d_e, False, dlogit)
+                have_e = True
+                ops.scale_rows(d_key, 128, sv["q"], 128, dlogit, 1, 1.0 / 16.0, S, 128)               # d key2
+                ops.scale_rows(d_q, 128, sv["key2"], 128, dlogit, 1, 1.0 / 16.0, S, 128)
+                wgrad("query_repeat_embed_2", d_key, 128, sv["k1r"], 128, S)
+                d_k1r = torch.empty(S, 128, **f32)
+                dx("query_repeat_embed_2", d_key, 128, d_k1r, 128, S)
+                ops.relu_mask(d_k1r, 128, sv["k1r"], 128, S, 128)
+                wr = W("query_repeat_embed").reshape(128, -1)
+                wgrad("query_repeat_embed", d_k1r, 128, sv["g"], 16, S, col0=128, K=16)              # local_coords half + bias
+                d_uh = torch.empty(bR, 128, **f32)
+                ops.reduce_samples(d_k1r, b, V, R, P, 128, d_uh)
+                wgrad("query_repeat_embed", d_uh, 128, sv["hb"], 128, bR, col0=0, K=128, bias=False)  # z_embed half
+                d_hb = torch.empty(bR, 128, **f32)
+                dx("query_repeat_embed.h", d_uh, 128, d_hb, 128, bR, wt=wr[:, :128])
+                wgrad("encode_latent", d_hb, 128, sv["z1"], Dl, bR)
+                d_z1 = torch.empty(bR, Dl, **f32)
+                ops.add(d_z1, Dl, d_zf, Dl, float(V), None, 0, 0.0, bR, Dl)
+                dx("encode_latent", d_hb, 128, d_z1, Dl, bR, ACCUM)
+                d_zf = d_z1
+            # ---- a14 / a16: z1 (or z) = latent_value(ebar1); depth read-out
+            wgrad("latent_value", d_zf, Dl, sv["ebar1"], Ce, bR)
+            dx("latent_value", d_zf, Dl, d_ebar, Ce, bR)
+            ops.attend_backward(sv["at_wt"], sv["e"], Ce, b, V, R, P, d_ebar, Ce, d_depth_t, sv["pt"], sv["poses"], d_e, have_e, dlogit)
+            ops.scale_rows(d_key, 128, sv["q"], 128, dlogit, 1, 1.0 / 16.0, S, 128)
+            ops.scale_rows(d_q, 128, sv["key"], 128, dlogit, 1, 1.0 / 16.0, S, 128, accumulate=m.repeat_attention)
+            # ---- a12, a13
+            wgrad("key_map_2", d_key, 128, sv["k1"], 128, S)
+            d_k1 = torch.empty(S, 128, **f32)
+            dx("key_map_2", d_key, 128, d_k1, 128, S)
+            ops.relu_mask(d_k1, 128, sv["k1"], 128, S, 128)
+            wgrad("key_map", d_k1, 128, sv["e"], Ce, S)
+            dx("key_map", d_k1, 128, d_e, Ce, S, ACCUM)
+            wgrad("query_embed_2", d_q, 128, sv["q1"], 128, S)
+            dx("query_embed_2", d_q, 128, d_k1, 128, S)                                               # d q1 (buffer reused)
+            ops.relu_mask(d_k1, 128, sv["q1"], 128, S, 128)
+            wgrad("query_embed", d_k1, 128, sv["g"], 16, S)
+            # ---- a11
+            wgrad("query_encode_latent_2", d_e, C // 2, sv["h1"], C, S * V)
+            d_h1 = torch.empty(S * V, C, **f32)
+            dx("query_encode_latent_2", d_e, C // 2, d_h1, C, S * V)
+            ops.relu_mask(d_h1, C, sv["h1"], C, S * V, C)
+            wgrad("query_encode_latent", d_h1, C, sv["x1"], ld1, S * V)
+            d_x1 = torch.empty(S * V, ld1, **f32)
+            dx("query_encode_latent", d_h1, C, d_x1, ld1, S * V)
+            # ---- a7 / a10: scatter into the pyramid
+            dmaps = [torch.zeros_like(t) for t in ctx.maps]
+            ops.gather_backward(dmaps, sv["pixel_val"], R * P, 0, PLACE_OWN, V, d_x1, ld1, 0)
+            ops.gather_backward(dmaps, sv["grid_other"], R * P, 1, PLACE_OTHER2, V, d_x1, ld1, 0)
+            dz = [t.permute(0, 3, 1, 2).contiguous().to(dt) for t, dt in zip(dmaps, ctx.z_dtypes)]
+        out = [None, None, None] + dz + [grads[k].view_as(par[k]).to(par[k].dtype) for k in _param_names(m)]
+        return tuple(out)
+
+
+def render_train(module, inp, z: Optional[List[Tensor]] = None) -> Dict[str, Tensor]:
+    """``model(model_input)`` of the reference's training loop (training.py:92): the render forward with autograd, on the HIP engine.
+    ``rgb`` and ``depth_ray`` carry gradients to the renderer's parameters and to ``z`` (``z=None``: ``get_z`` runs under autograd, so
+    the encoder trains too)."""
+    m = module
+    if m.n_view != 2 or m.no_latent_concat or m.no_sample:
+        raise NotImplementedError("render_train covers the reference's default configuration family (n_view = 2, epipolar sampling, "
+                                  "cross-view exchange); the constructor variants have no backward yet")
+    dev = inp["query"]["uv"].device
+    if dev.type != "cuda":
+        raise RuntimeError("render_train runs on the HIP engine only: move the model, the input dict and z to a ROCm device")
+    if z is None:
+        z = m.get_z(inp)
+    elif not hasattr(m, "H"):
+        m.H, m.W = inp["context"]["rgb"].shape[2:4]
+    if inp["query"]["uv"].shape[1] != 1:
+        raise ValueError("one query view per scene (reference models.py:213, 619)")
+    if m._engine is None:
+        m._engine = RenderEngine(m)
+    sd = dict(m.named_parameters())
+    params = [sd[k] for k in _param_names(m)]
+    with torch.cuda.device(dev):
+        rgb, depth, valid, at_wt, amax, coords, pixel_val = _RenderTrain.apply(m, inp, len(z), *z, *params)
+    return {"rgb": rgb, "depth_ray": depth, "valid_mask": valid, "at_wt": at_wt, "at_wts": [at_wt], "at_wt_max": amax, "coords": coords,
+            "uv": inp["query"]["uv"], "pixel_val": pixel_val, "z": z}
+
+
+def average_gradients(module, group=None) -> None:
+    """The reference's gradient all-reduce (training.py:21-28): every parameter's gradient summed over the ranks and divided by the
+    world size — here as ONE flat bucket per dtype over RCCL (xGMI is point-to-point: one large ring all-reduce instead of one
+    latency-bound collective per tensor), copied back in place."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    by_dtype: Dict[torch.dtype, List[Tensor]] = {}
+    for p in module.parameters():
+        if p.grad is not None:
+            by_dtype.setdefault(p.grad.dtype, []).append(p.grad)
+    for grads in by_dtype.values():
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= world
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CAR_VERSION 200           /* 0.2.0 */
+#define CAR_VERSION 300           /* 0.3.0 */
 
 #define CAR_OK            0
 #define CAR_E_ARG        (-1)     /* invalid argument (null pointer, bad size, unsupported shape) */
@@ -205,6 +205,37 @@ int car_ray_tail(const float* arena, const unsigned* offs, const int* nts, int n
  * rays [b*V,R,CAR_RAY_FLOATS]; rgb_in [b,R,ld_in] (first 3 columns used) -> rgb [b,R,3], valid [b,R]. */
 int car_finalize(const float* rays, const float* rgb_in, int ld_in, int b, int V, int R, float* rgb, float* valid,
                  void* stream);
+
+/* =====================================================================================================================
+ * Backward of the staged route.  The reference trains by torch autograd over models.py:190-626
+ * (training.py:92-136: loss on `rgb` and `depth_ray`, loss_functions.py:74-132); these are the kernels a host needs to push
+ * the gradient of (rgb, depth_ray) back to every renderer parameter and to the feature pyramid z.  The data gradient of a
+ * linear layer, dX = dY W, is car_linear with the transposed weight packed by car_linear_pack.
+ *
+ *  car_linear_wgrad   dW[N, K] += dY[M, N]^T X[M, K]  and, with db != NULL, db[N] += column sums of dY (fp32 matrix pipe, fp32
+ *                     atomics into dW / db: zero them first).  flags: CAR_LIN_RELU_IN = X is used as relu(X).
+ *  car_attend_backward   one attention round (models.py:532-541 / 555-565, depth read-out 577-590).  w [b*V,R,P] the round's
+ *                     softmax weights, val [b*V,R,P,D]; dz [b,R,ld_dz]: gradient of sum_s w_s val_s; ddepth [b,R] (optional, with
+ *                     pt [b*V,R,P,3] and poses): gradient of depth_ray.  dval [b*V,R,P,D] (+)= w_s dz, dlogit [b*V,R,P].
+ *  car_gather_bilinear_backward   grid_sample backward w.r.t. the maps: dmaps[l] [n_maps,Hl,Wl,Cl] += tap weight x the gradient of
+ *                     the gathered row (same arguments and row placement as car_gather_bilinear; fp32 atomics).
+ *  car_relu_mask      grad[m][n] = act[m][n] > 0 ? grad[m][n] : 0
+ *  car_scale_rows     out[m][:] (+)= scale * s[m / group] * x[m][:]        (logit gradients to keys / queries, valid mask)
+ *  car_add            out = alpha a + beta b (b may be NULL)
+ *  car_reduce_samples du[b,R,C] = sum over the V*P samples of a ray of d[b*V,R,P,C]   (backward of car_add_ray_bias_relu's broadcast) */
+int car_linear_wgrad(const float* dY, int ldy, const float* X, int ldx, long M, int N, int K, int flags, float* dW, int lddw,
+                     float* db, void* stream);
+int car_attend_backward(const float* w, const float* val, int D, int b, int V, int R, int P, const float* dz, int ld_dz,
+                        const float* ddepth, const float* pt, const float* poses, float* dval, int accumulate, float* dlogit,
+                        void* stream);
+int car_gather_bilinear_backward(float* const* dmaps, const int* level_c, const int* level_h, const int* level_w, int n_levels,
+                                 int n_maps, const float* grid, long pts, int mode, int place, int V, const float* dout, int ld_out,
+                                 int col_out, void* stream);
+int car_relu_mask(float* grad, int ldg, const float* act, int lda, long M, int N, void* stream);
+int car_scale_rows(float* out, int ldo, const float* x, int ldx, const float* s, long group, float scale, long M, int N, int accumulate,
+                   void* stream);
+int car_add(float* out, int ldo, const float* a, int lda, float alpha, const float* b, int ldb, float beta, long M, int N, void* stream);
+int car_reduce_samples(const float* d, int b, int V, int R, int P, int C, float* du, void* stream);
 
 /* =====================================================================================================================
  * One-call forward for hosts without the Python engine: the launch sequence of

@@ -61,7 +61,7 @@ def run_case(name: str) -> None:
     for k, g in grads.items():
         assert k in og, f"oracle has no gradient for {k}"
         w, frac = G.deviation(og[k].numpy(), g.numpy(), max(g.double().abs().max().item(), 1e-12), 1e-4)
-        assert frac <= G.FLIP_FRACTION and w <= G.FLIP_WORST, (k, w, frac)
+        assert G.within_flip_budget(frac, g.numel()) and w <= G.FLIP_WORST, (k, w, frac)
         if w > 1e-4:
             flips.append(f"{k} {w:.1e} ({frac:.1e} of its entries)")
         else:

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.car_version() == 200
+    assert lib.car_version() == 300
 
 
 def test_bad_arguments_return_codes_not_crashes(lib):

@@ -1,0 +1,113 @@
+"""SURVEY.md §8 f4 on the device: ``training.render_train`` (forward of the staged route + HIP backward, csrc/car_backward.hip) against
+the REFERENCE's autograd gradients (tests/golden/grad_*.npz) — every renderer parameter on the path and every pyramid level, for the
+scalar L = sum(rgb * c_rgb) + sum(depth_ray * c_depth) with the fixtures' seeded cotangents."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import grad_cases as G
+from golden_util import load_case, rel_err
+from hip_harness import build_module, oracle_cfg, to_device
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from cross_attention_renderer_amd import _lib as L
+    return L.load()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("name", G.GRAD_CASES)
+def test_hip_backward_matches_the_reference_gradients(name):
+    from cross_attention_renderer_amd.training import render_train
+    dev = torch.device("cuda:0")
+    c, inp, z, sd, fx_fwd = load_case(name)
+    fx = np.load(G.grad_fixture_path(name))
+    m = build_module(c, sd, dev).train()
+    zr = [t.to(dev).requires_grad_(True) for t in z]
+    out = render_train(m, to_device(inp, dev, cameras_on_host=True), z=zr)
+    # the training forward is the staged route: same results as the inference path's fixtures
+    assert rel_err(out["rgb"].detach().cpu(), fx_fwd["out_rgb"]) < 1e-4
+    assert rel_err(out["depth_ray"].detach().cpu(), fx_fwd["out_depth_ray"]) < 1e-4
+    c_rgb, c_depth = G.cotangents(out["rgb"].shape, out["depth_ray"].shape)
+    loss = (out["rgb"] * c_rgb.to(dev)).sum() + (out["depth_ray"] * c_depth.to(dev)).sum()
+    assert abs(loss.item() - float(fx["loss"])) <= 1e-4 * max(1.0, abs(float(fx["loss"])))
+    loss.backward()
+    torch.cuda.synchronize()
+    got = {"param." + k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    got.update({f"z.{l}": t.grad for l, t in enumerate(zr)})
+    stored = G.keys(fx)
+    assert sorted(got) == stored, sorted(set(got) ^ set(stored))
+    report = {k: G.compare(fx, k, got[k], tol=1e-3) for k in stored}
+    worst = max(v[0] for v in report.values())
+    print(f"{name}: worst deviation {worst:.2e} of a tensor's largest entry; beyond 1e-3: " +
+          ", ".join(f"{k} {v[1]:.1e}" for k, v in report.items() if v[1] > 0))
+    for k in fx["unused"].tolist():
+        p = dict(m.named_parameters())[k]
+        assert p.grad is None, k
+
+
+def test_wgrad_kernel_matches_torch():
+    """car_linear_wgrad alone: dW += dY^T X, db += sum dY, ragged sizes, strides, the relu-on-load flag and accumulation."""
+    lib, dev = _lib(), torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    for M, N, K, relu in ((1000, 128, 16, False), (777, 3, 128, True), (4099, 288, 576, False), (513, 576, 579, False), (64, 128, 144, True)):
+        ldy, ldx = N + (4 - N % 4) % 4 + 4, K + (4 - K % 4) % 4
+        dy = torch.randn(M, ldy, generator=g).to(dev)
+        x = torch.randn(M, ldx, generator=g).to(dev)
+        dw = torch.randn(N, K + 5, generator=g).to(dev)
+        db = torch.randn(N, generator=g).to(dev)
+        dw0, db0 = dw.clone(), db.clone()
+        rc = lib.car_linear_wgrad(_ptr(dy), ldy, _ptr(x), ldx, M, N, K, 1 if relu else 0, _ptr(dw), K + 5, _ptr(db), _stream())
+        assert rc == 0, lib.car_last_error()
+        torch.cuda.synchronize()
+        xs = (x[:, :K].clamp_min(0) if relu else x[:, :K]).double()
+        want_w = dw0[:, :K].double() + dy[:, :N].double().t() @ xs
+        want_b = db0.double() + dy[:, :N].double().sum(0)
+        scale = want_w.abs().max().item()
+        assert (dw[:, :K].double() - want_w).abs().max().item() <= 2e-5 * scale, (M, N, K)
+        assert torch.equal(dw[:, K:], dw0[:, K:]), "columns beyond K were touched"
+        assert (db.double() - want_b).abs().max().item() <= 2e-5 * want_b.abs().max().item(), (M, N, K)
+
+
+def test_gather_backward_is_the_adjoint_of_the_gather():
+    """<gather(maps), dout> == <maps, gather_backward(dout)> for both padding modes and every placement (the adjoint identity of a
+    linear map), with coordinates inside, on the edge of and far outside the maps."""
+    from cross_attention_renderer_amd.engine import PLACE_OTHER2, PLACE_OWN, PLACE_PLAIN
+    lib, dev = _lib(), torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    n_maps, pts, V = 4, 300, 2
+    maps = [torch.randn(n_maps, h, h, cch, generator=g).to(dev) for h, cch in ((5, 8), (9, 12), (17, 4))]
+    C = sum(t.shape[3] for t in maps)
+    grid = (torch.rand(n_maps, pts, 2, generator=g) * 3 - 1.5)
+    grid[0, 0] = torch.tensor([1e10, -1e10])
+    grid[1, 1] = torch.tensor([-1.0, 1.0])
+    grid = grid.to(dev)
+    L = len(maps)
+    cs = (ctypes.c_int * L)(*[t.shape[3] for t in maps])
+    hs = (ctypes.c_int * L)(*[t.shape[1] for t in maps])
+    ws = (ctypes.c_int * L)(*[t.shape[2] for t in maps])
+    for mode in (0, 1):
+        for place, rows, ld in ((PLACE_PLAIN, n_maps * pts, C + 4), (PLACE_OWN, n_maps * pts * V, C + 8), (PLACE_OTHER2, n_maps * pts * V, C)):
+            out = torch.zeros(rows, ld, device=dev)
+            ptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in maps])
+            assert lib.car_gather_bilinear(ptrs, cs, hs, ws, L, n_maps, _ptr(grid), pts, 1, mode, place, V, _ptr(out), ld, 0, _stream()) == 0
+            dout = torch.randn(rows, ld, generator=g).to(dev)
+            dmaps = [torch.zeros_like(t) for t in maps]
+            dptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in dmaps])
+            rc = lib.car_gather_bilinear_backward(dptrs, cs, hs, ws, L, n_maps, _ptr(grid), pts, mode, place, V, _ptr(dout), ld, 0, _stream())
+            assert rc == 0, lib.car_last_error()
+            torch.cuda.synchronize()
+            lhs = (out[:, :C].double() * dout[:, :C].double()).sum().item()
+            rhs = sum((a.double() * b_.double()).sum().item() for a, b_ in zip(maps, dmaps))
+            assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs)), (mode, place, lhs, rhs)

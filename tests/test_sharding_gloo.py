@@ -102,3 +102,36 @@ def test_tile_gather_over_rccl_single_rank():
         assert torch.equal(Sh.gather_rays(tile, 65), tile)
     finally:
         dist.destroy_process_group()
+
+
+# ---- the training loop's gradient all-reduce (reference training.py:21-28) over a world-2 gloo group ----------------------------
+def _grad_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cross_attention_renderer_amd.training import average_gradients
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+        frozen = torch.nn.Linear(2, 2)                       # a module whose parameters never get a gradient (latent_avg_* in the renderer)
+        model = torch.nn.ModuleList([net, frozen])
+        x = torch.full((4, 5), float(rank + 1))
+        net(x).sum().backward()
+        mine = [p.grad.clone() for p in net.parameters()]
+        average_gradients(model)
+        # the reference's arithmetic: sum over ranks / world size, per parameter
+        for p, g0 in zip(net.parameters(), mine):
+            parts = [torch.zeros_like(g0) for _ in range(world)]
+            dist.all_gather(parts, g0)
+            assert torch.allclose(p.grad, sum(parts) / world, rtol=0, atol=1e-6)
+        assert all(p.grad is None for p in frozen.parameters())
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_average_gradients_world2():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_grad_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert sorted(ret.keys()) == [0, 1]

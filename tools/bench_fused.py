@@ -80,6 +80,8 @@ def main():
     flop = 2.0 * S * bench.FUSED_MACS
     variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 5, 6, 7, 8]
     big = None
+    prod = lib.car_fused_samples                        # variant 100: the product library's kernel, timed the same way
+    outs = {}
     for v in variants:
         lat = []
         lat_ptr, lat_h, lat_w, lat_pad = eng._pair.data_ptr(), lh.value, lw.value, lpad.value
@@ -90,10 +92,11 @@ def main():
         for it in range(7):
             a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            rc = fn(v, eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), lat_ptr, lat_h, lat_w, lat_pad,
+            args = (eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), lat_ptr, lat_h, lat_w, lat_pad,
                     fine_ptr, fh, fw, gmeta, wpt.data_ptr(), blob.data_ptr(),
                     bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
                     pixel_val.data_ptr(), st)
+            rc = prod(*args) if v == 100 else fn(v, *args)
             b_.record()
             assert rc == 0, dev_lib.car_last_error()
             lat.append((a, b_))
@@ -110,6 +113,13 @@ def main():
                 x = (st8[:, seq[j + 1]] - st8[:, seq[j]]).mean().item()
                 print(f"   {n_:38s} {x:10.0f}  {100 * x / tot:5.1f} %")
             print(f"   total {tot:.0f} ticks")
+        if v in (0, 100):                                  # keep the results: the development kernel must equal the product's bit for bit
+            outs[v] = [torch.empty(cnt_, device=dev).copy_(eng._work[o_:o_ + cnt_]) for o_, cnt_ in
+                       [(lambda n_: (lib.car_workspace_find(ctypes.byref(d), n_.encode(), ctypes.byref(off), ctypes.byref(cnt)), (off.value, cnt.value))[1])(n_)
+                        for n_ in ("e", "qry", "logit", "pt", "g")]]
+            if len(outs) == 2:
+                for n_, x, y in zip(("e", "qry", "logit", "pt", "g"), outs[0], outs[100]):
+                    print(f"   dev(0) vs product(100) {n_:6s} max |diff| {(x - y).abs().max().item():.3e}  equal {torch.equal(x, y)}")
         print(f"ABL={v}: fused kernel median {ms[len(ms) // 2]:.3f} ms  min {ms[0]:.3f} ms  -> {flop / ms[len(ms) // 2] / 1e9:.1f} TFLOP/s (nominal flops)", flush=True)
 
 

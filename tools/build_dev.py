@@ -12,15 +12,19 @@ DEV_LIB = os.path.join(DEV_DIR, "libcar_dev.so")
 
 
 def build_dev() -> str:
+    """CAR_DEV_FLAGS (environment of the BUILD, e.g. -DCAR_FUSED_WAVES=8): extra flags for the development copy of car_fused.hip."""
     import __graft_entry__ as ge
     ge.build()
     os.makedirs(DEV_DIR, exist_ok=True)
     obj = os.path.join(DEV_DIR, "car_fused_dev.o")
     src = os.path.join(ge.CSRC, "car_fused.hip")
     deps = [src] + [os.path.join(ge.CSRC, f) for f in os.listdir(ge.CSRC) if f.endswith(".h")]
-    if ge._stale(obj, deps):
-        subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCAR_ABLATION", "-c", src, "-o", obj,
+    extra = os.environ.get("CAR_DEV_FLAGS", "").split()
+    stamp = os.path.join(DEV_DIR, "flags.txt")
+    if ge._stale(obj, deps) or not os.path.exists(stamp) or open(stamp).read() != " ".join(extra):
+        subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCAR_ABLATION", *extra, "-c", src, "-o", obj,
                                "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS["car_fused.hip"]])
+        open(stamp, "w").write(" ".join(extra))
     objs = [os.path.join(ge.CSRC, "_obj", u.replace(".hip", ".o")) for u in ge.UNITS if u != "car_fused.hip"] + [obj]
     if ge._stale(DEV_LIB, objs):
         subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", DEV_LIB, *objs])
