@@ -36,7 +36,7 @@ class CarWeights(ctypes.Structure):
 
 
 class CarInputs(ctypes.Structure):
-    _fields_ = [("poses", _P), ("uv", _P), ("lattice", _P), ("fine", _P), ("gmeta", _P), ("steps", _P)]
+    _fields_ = [("poses", _P), ("uv", _P), ("lattice", _P), ("gmeta", _P), ("steps", _P)]
 
 
 class CarOutputs(ctypes.Structure):
@@ -58,7 +58,7 @@ SIGNATURES = {
     "car_gather_encode": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_long, _P, c_int, _P]),
     "car_fused_blob_floats": (c_size_t, []),
     "car_fused_bias_floats": (c_size_t, []),
-    "car_fused_samples": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+    "car_fused_samples": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                   _P, _P, _P, _P, _P, _P, _P]),
     "car_linear_packed_floats": (c_size_t, [c_int, c_int]),
     "car_linear_pack": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
@@ -79,9 +79,7 @@ SIGNATURES = {
     "car_plan_bytes": (c_size_t, [ctypes.POINTER(CarDims)]),
     "car_plan_build": (c_int, [ctypes.POINTER(CarDims), ctypes.POINTER(CarWeights), _P, _P]),
     "car_gmaps_floats": (c_size_t, [ctypes.POINTER(CarDims)]),
-    "car_lattice_shape": (c_int, [ctypes.POINTER(CarDims), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int),
-                                  ctypes.POINTER(c_int)]),
-    "car_fine_offset": (c_size_t, [ctypes.POINTER(CarDims)]),
+    "car_lattice_shape": (c_int, [ctypes.POINTER(CarDims), ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "car_gmeta_offset": (c_size_t, [ctypes.POINTER(CarDims)]),
     "car_workspace_find": (c_int, [ctypes.POINTER(CarDims), c_char_p, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     "car_profile_enable": (None, [c_int]),

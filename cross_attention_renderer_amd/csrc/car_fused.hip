@@ -1,8 +1,8 @@
 // car_fused.hip — the fused per-sample kernel (SURVEY.md §8a rows a6-a13 + the logits of a14; reference models.py:261-344,
 // 487-532).  Per sample, without touching HBM in between: geometry (car_geom.h, fp64 Pluecker intersection) -> per 32-channel
-// chunk an 8-tap gather of the per-texel projected maps (the first point-MLP layer applied once per texel): four taps
-// of the finest pyramid level and four taps of the merged lattice, on which the coarser levels are summed once per stereo pair
-// (car_geom.h car_lattice_taps) ->
+// chunk a FOUR-tap gather of the per-texel projected pyramid: the first point-MLP layer is applied once per texel and ALL levels are
+// summed once per stereo pair on the integer lattice their texel centres share (car_geom.h car_lattice_taps), so
+// grid_sample over three levels is one bilinear lookup ->
 // e_s = W2 relu(h_s) + b2 for both source views -> k1 = Wk1 [e_0 ; e_1] -> key -> qry -> logit = <key, qry>/16.  Every layer
 // runs on the f16 matrix pipe as three v_mfma_f32_16x16x32_f16 products of fp16 hi/lo operand halves (car_fused_mma.h); a
 // layer's accumulators are the next layer's B operands.
@@ -10,10 +10,10 @@
 // Three waves per SIMD (<= 168 registers per wave), which needs
 //   * the key layer's accumulators (k1, 32 registers) out of the e path: k1 = Wk1 [e_0 ; e_1] is computed after both
 //     sources, chained from the accumulators for e_1 and from e_0 read back from the output tensor it was just stored to (L2);
-//   * half-size tap batches (one map of one row group: 4 float4) in two alternating buffers;
+//   * two tap batches (one row group each: 4 float4) in flight, each issued a whole chunk before it is blended;
 //   * no read-ahead of the weight operands (the third wave hides the LDS latency instead).
 // One workgroup = 12 waves = 192 samples = 48 consecutive rays x 4 consecutive steps (wave = (16-ray bundle, step)); the weight
-// stream is shared by 192 samples.  The tap tables are stored compactly (base offset + two flags, four weights).
+// stream is shared by 192 samples.  The tap tables are stored compactly (byte offset + two flags, four weights).
 // The geometric query g (16 floats per sample) is written out for the second attention round (car_round2.hip recomputes the
 // 16 -> 128 half of query_repeat_embed from it instead of reading a 128-wide row back).
 #include "car_common.h"
@@ -21,26 +21,20 @@
 
 namespace {
 
-#ifndef CAR_FUSED_WAVES
-#define CAR_FUSED_WAVES 12
-#endif
-constexpr int kWaves = CAR_FUSED_WAVES, kRows = 16, kGroup = kWaves * kRows;      // samples per workgroup
-constexpr int kStepsPerGroup = 4, kBundles = kWaves / kStepsPerGroup;  // bundles of 16 rays x 4 steps
+constexpr int kWaves = 12, kRows = 16, kGroup = kWaves * kRows;      // 192 samples per workgroup
+constexpr int kStepsPerGroup = 4, kBundles = kWaves / kStepsPerGroup;  // 3 bundles of 16 rays x 4 steps
 constexpr int kThreads = 64 * kWaves;
 
-constexpr int kPieces = (36 + kWaves - 1) / kWaves;                    // LDS-DMA pieces per chunk: kWaves x 1 KB each
-// tap batches (4 loads = 16 registers each) a wave keeps in flight: the gather is bound by the latency of its far misses times the
-// loads in flight (gather alone: 2.5 ms per 8192 rays with 8 loads per wave, 1.2 ms with 32), and registers are what holds them
-constexpr int kRing = kWaves == 8 ? 6 : 2;
+constexpr int kPieces = 3;                         // LDS-DMA pieces per chunk: 12 waves x 1 KB each
 constexpr unsigned kDeadTap = 0xfffffe00u;         // tap-table entry of a sample that reads exact zeros: beyond any map, no wrap with the column offset
-constexpr long kMaxMapBytes = 0xfffff000L;         // a map of one call stays below it
+constexpr long kMaxMapBytes = 0xfffff000L;         // the lattice of one (view, padding mode) stays below it
 
 #include "car_fused_mma.h"
 
 constexpr int kLdsStage = kLdsW + 2 * kChunkTiles * kTile;      // [12][16][36]           h tiles, wave private     27 KB
-constexpr int kLdsTapB = kLdsStage + kGroup * kStageLd;         // [192][2][2] uint       byte offset of the nw node / texel | 1: x1 != x0 | 2: y1 != y0   3 KB
-constexpr int kLdsTapW = kLdsTapB + kGroup * 4;                 // [192][2][2][4]         tap weights (nw, ne, sw, se)   12 KB
-constexpr int kLdsPe = kLdsTapW + kGroup * 16;                  // [192][2][4]            tanh(pt_s/5)                6 KB
+constexpr int kLdsTapB = kLdsStage + kGroup * kStageLd;         // [192][2] uint          byte offset of the nw node | 1: x1 != x0 | 2: y1 != y0   1.5 KB
+constexpr int kLdsTapW = kLdsTapB + kGroup * 2;                 // [192][2][4]            tap weights (nw, ne, sw, se)    6 KB
+constexpr int kLdsPe = kLdsTapW + kGroup * 8;                   // [192][2][4]            tanh(pt_s/5)                6 KB
 constexpr int kLdsWpt = kLdsPe + kGroup * 8;                    // [576][4]               (W1[:,C:C+3], b1)           9 KB
 constexpr int kLdsBias = kLdsWpt + kC * 4;                      // [672]
 constexpr int kLdsG = kLdsBias + kBiasFloats;                   // [192][16]              geometric query g per sample 12 KB
@@ -52,13 +46,11 @@ struct FusedArgs {
     const CarPose* poses;
     const CarRay* rays;
     const float* steps;
-    const float* gmap[2];      // 0: merged lattice of the coarser levels [b*V][2 padding modes][lh][lw][kC]; 1: the finest level, projected,
-                               // [b*V][fh][fw][kC] (car_project_maps)
+    const float* lattice;      // [b*V][2 padding modes][lh][lw][kC]: every pyramid level, projected, summed on the common lattice (car_project_maps)
     int lh, lw, pad;
-    float sx, sy;              // lattice coordinate u = (x + 1) * sx - 1: width / height of the finest of the merged levels
-    int fh, fw;
-    unsigned gbytes[2];        // sizes of the two maps of this call: the range of the gather's buffer loads
-    const float* gmeta;        // [2] max |lattice|, max |finest level| (car_project_maps)
+    float sx, sy;              // lattice coordinate u = (x + 1) * sx - 1: width / height of the finest level
+    unsigned map_bytes;        // one (view, padding mode) lattice: the range of a source pass's buffer loads
+    const float* gmeta;        // [1] max |lattice| (car_project_maps)
     const float* wpt;
     const float* blob;
     const float* bias;
@@ -102,27 +94,24 @@ __device__ __forceinline__ NextChunk next_chunk_w2(const float* __restrict__ blo
 }
 
 // ABL > 0: timing-only ablations (wrong results), instantiated only in the -DCAR_ABLATION development build (tools/):
-// 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers, 5 the gather alone (no e-path MFMAs, no weight DMA, no
-// barriers); probes of the texture-address path on top of 5: 6 odd rows masked off (whole quads of lanes inactive), 7 odd channel
-// quads masked off (half of every quad of lanes inactive); 11 the full kernel without the barrier of the weight stream (racy);
+// 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers, 5 no e-path MFMAs, weight DMA or barriers in the two source
+// passes (the gather + the key / query layers); 11 the full kernel without the barrier of the weight stream (racy);
 // 12 = 3 + no A-operand reads from LDS (matrix pipe + VALU only); 13 the full kernel without the A-operand reads;
-// 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val);
-// 14: four taps per sample and source from ONE map (the caller hands a lattice of the full three-level size, 521 x 521 nodes for a
-// 256 x 256 frame, with arbitrary contents): the cost side of merging the finest level into the lattice too
+// 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val)
 template <int ABL>
-__global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : kThreads) fused_kernel(const FusedArgs a) {
+__global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = lane & 15, q4 = lane >> 4;
     const int nblk = gridDim.x;
     int blk = blockIdx.x;
     {   // workgroup b runs on XCD b % 8 (observed, speed only): give every XCD a contiguous band of sample groups so that the
-        // texel rows its workgroups share stay in one L2
+        // lattice rows its workgroups share stay in one L2
         const int q8 = nblk / 8, r8 = nblk % 8, xcd = blk % 8, idx = blk / 8;
         blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
     // 192 samples = 48 consecutive rays x 4 consecutive steps: wave = (bundle of 16 rays, step), lane & 15 = ray of the bundle, so the
-    // 16 rows a wave gathers together are the same step of neighbouring rays (shared texel rows)
+    // 16 rows a wave gathers together are the same step of neighbouring rays (shared lattice rows)
     const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + kBundles * kRows - 1) / (kBundles * kRows);
     const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
     const int ray_i = bun * (kBundles * kRows) + (wave / kStepsPerGroup) * kRows + s, pp = pg * kStepsPerGroup + wave % kStepsPerGroup;
@@ -158,32 +147,21 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : kThreads) fus
 #pragma unroll
         for (int sv = 0; sv < 2; ++sv) {
             float gx, gy;
-            int mode, m;
-            if (sv == v) { gx = smp.grid[0]; gy = smp.grid[1]; mode = 0; m = n; }
-            else { gx = sv == 0 ? smp.grid_in[0][0] : smp.grid_in[1][0]; gy = sv == 0 ? smp.grid_in[0][1] : smp.grid_in[1][1]; mode = 1; m = sc * V + sv; }
-            unsigned* tb = reinterpret_cast<unsigned*>(lds + kLdsTapB) + (sg * 2 + sv) * 2;
-            float* tw = lds + kLdsTapW + (sg * 2 + sv) * 8;
-            {   // the four taps are nw + {0, 1 node} + {0, 1 row}; a node's row is kC*4 = 2304 B, a multiple of 256, so the two flags ride
-                // in the low bits of the nw node's byte offset
-                int node, flags;
-                float w[4];
-                car_lattice_taps(gx, gy, a.lw, a.lh, a.pad, a.sx, a.sy, &node, &flags, w);
-                // zeros padding, point on or beyond the outer ring: the four nodes are exactly zero.  Such a sample (its projection
-                // misses the other view: a third of them on a wide-baseline pair) gets the out-of-range offset kDeadTap: the buffer
-                // loads of its lanes return zeros without touching memory, and weight zero makes the contribution exactly +-0
-                const bool dead = mode == 1 && (flags & 4);
-                tb[0] = dead ? kDeadTap : (unsigned)((m * 2 + mode) * a.lh * a.lw + node) * (unsigned)(kC * 4) | (unsigned)(flags & 3);
-                *reinterpret_cast<float4*>(tw) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w[0], w[1], w[2], w[3]);
-            }
-            {   // the finest level: (x0|x1, y0|y1) after clamping, weight 0 for a tap outside the map
-                int idx[4];
-                float w[4];
-                car_bilinear_taps(gx, gy, a.fw, a.fh, mode, idx, w);
-                const bool dead = w[0] == 0.0f && w[1] == 0.0f && w[2] == 0.0f && w[3] == 0.0f;      // every tap outside the map: nothing to fetch
-                tb[1] = dead ? kDeadTap
-                             : (unsigned)(m * a.fh * a.fw + idx[0]) * (unsigned)(kC * 4) | (idx[1] != idx[0] ? 1u : 0u) | (idx[2] != idx[0] ? 2u : 0u);
-                *reinterpret_cast<float4*>(tw + 4) = make_float4(w[0], w[1], w[2], w[3]);
-            }
+            int mode;
+            if (sv == v) { gx = smp.grid[0]; gy = smp.grid[1]; mode = 0; }
+            else { gx = sv == 0 ? smp.grid_in[0][0] : smp.grid_in[1][0]; gy = sv == 0 ? smp.grid_in[0][1] : smp.grid_in[1][1]; mode = 1; }
+            // the four taps are nw + {0, 1 node} + {0, 1 row}; a node's row is kC*4 = 2304 B, a multiple of 256, so the two flags ride in
+            // the low bits of the nw node's byte offset inside the lattice of this (source view, padding mode)
+            int node, flags;
+            float w[4];
+            car_lattice_taps(gx, gy, a.lw, a.lh, a.pad, a.sx, a.sy, &node, &flags, w);
+            // zeros padding, point on or beyond the outer ring: the four nodes are exactly zero.  Such a sample (its projection
+            // misses the other view: a third of them on a wide-baseline pair) gets the out-of-range offset kDeadTap: the buffer
+            // loads of its lanes return zeros without touching memory — an instruction whose lanes are all out of range costs the
+            // texture path nothing (profiles/round3_fused_experiments.md) — and weight zero makes the contribution exactly +-0
+            const bool dead = mode == 1 && (flags & 4);
+            reinterpret_cast<unsigned*>(lds + kLdsTapB)[sg * 2 + sv] = dead ? kDeadTap : (unsigned)node * (unsigned)(kC * 4) | (unsigned)(flags & 3);
+            *reinterpret_cast<float4*>(lds + kLdsTapW + (sg * 2 + sv) * 4) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w[0], w[1], w[2], w[3]);
             const float px = sv == 0 ? smp.pt_in[0][0] : smp.pt_in[1][0], py = sv == 0 ? smp.pt_in[0][1] : smp.pt_in[1][1],
                         pz = sv == 0 ? smp.pt_in[0][2] : smp.pt_in[1][2];
             *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f), tanhf(py / 5.0f), tanhf(pz / 5.0f), 0.0f);
@@ -204,47 +182,39 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : kThreads) fus
     mark(1);
 
     // ---- gather machinery: lane owns rows rr = (lane>>3) + 8*it (it = 0, 1) and channel quad qd = lane & 7 of a chunk.
-    //      A batch = the 4 tap loads of one row group `it` from one map (l = 1 the finest level, 0 the lattice); two batches (bufA: it 0,
-    //      bufB: it 1) are in flight. ----
+    //      A batch = the 4 tap loads of one row group `it`; two batches (bufA: it 0, bufB: it 1) are in flight, each issued right
+    //      after the previous chunk's batch of the same row group has been blended: a whole chunk ahead of its use. ----
     const int qd = lane & 7, r0 = lane >> 3;
     float* stage = lds + kLdsStage + wave * kRows * kStageLd;
     float4 hacc[2];
     f32x4 bufA[4], bufB[4];
     const unsigned qd16 = 16u * qd;
-    const unsigned row_step[2] = {(unsigned)a.lw * (kC * 4), (unsigned)a.fw * (kC * 4)};
+    const unsigned row_step = (unsigned)a.lw * (kC * 4);
 
-    // Buffer loads (range-checked against the map's size): a lane whose offset is kDeadTap gets zeros and costs no memory access.
+    // Buffer loads, range-checked against ONE (view, padding mode) lattice: the workgroup's samples all lie on the epipolar lines of
+    // context view nn % V, so source view sv reads the border-padded lattice of that view when sv is the view itself and the
+    // zero-padded lattice of view sv otherwise — one descriptor per source pass, 32-bit offsets inside it.
+    const int v_own = nn % a.V, sc_own = nn / a.V;
+    const long map_floats = (long)a.lh * a.lw * kC;
     const __amdgpu_buffer_rsrc_t rsrc[2] = {
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gmap[0]), 0, (int)a.gbytes[0], 0x00027000),
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gmap[1]), 0, (int)a.gbytes[1], 0x00027000)};
-    auto issue_row = [&](f32x4 (&tap)[4], int sv, int c, int l, int it) {
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lattice + ((long)(sc_own * a.V + 0) * 2 + (v_own == 0 ? 0 : 1)) * map_floats), 0,
+                                          (int)a.map_bytes, 0x00027000),
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lattice + ((long)(sc_own * a.V + 1) * 2 + (v_own == 1 ? 0 : 1)) * map_floats), 0,
+                                          (int)a.map_bytes, 0x00027000)};
+    auto issue_row = [&](f32x4 (&tap)[4], int sv, int c, int it) {
         if constexpr (ABL == 1 || ABL == 2 || ABL == 3 || ABL == 12) return;
-        if constexpr (ABL == 6) { if (r0 & 1) return; }
-        if constexpr (ABL == 7) { if (qd & 1) return; }
-        if constexpr (ABL == 14) { if (l == 0) return; l = 0; }          // the lattice's four taps ride in the finest level's slots, nothing else is fetched
         const int chunk_off = 128 * c;                                 // the chunk's 32 channels: scalar offset, not range-checked
-        // ABL 8: lane = (sample s, k group q4) as the MFMA's B operand wants it, the two row groups become the two 16-byte pieces
-        const int row = ABL == 8 ? s : r0 + 8 * it;
-        const unsigned col = ABL == 8 ? 16u * q4 + 64u * it : qd16;
-        const unsigned tbv = reinterpret_cast<const unsigned*>(lds + kLdsTapB)[((wave * kRows + row) * 2 + sv) * 2 + l];
-        const unsigned o00 = (tbv & ~3u) + col, dx = (tbv & 1u) ? (unsigned)(kC * 4) : 0u, dy = (tbv & 2u) ? row_step[l] : 0u;
-        auto ld = [&](unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc[l], (int)off, chunk_off, 0)); };
-        if constexpr (ABL == 18) {            // gather alone, taps in the order nw, sw, ne, se: the east taps (neighbouring rays' west taps) one instruction later
-            tap[0] = ld(o00); tap[2] = ld(o00 + dy); tap[1] = ld(o00 + dx); tap[3] = ld(o00 + dx + dy);
-        } else if constexpr (ABL == 19) {     // gather alone, east taps moved 16 nodes over: no line shared with a neighbouring ray's west taps (timing only)
-            const unsigned far = dx ? 16u * (unsigned)(kC * 4) : 0u;
-            tap[0] = ld(o00); tap[1] = ld(o00 + far); tap[2] = ld(o00 + dy); tap[3] = ld(o00 + far + dy);
-        } else {
+        const unsigned tbv = reinterpret_cast<const unsigned*>(lds + kLdsTapB)[(wave * kRows + r0 + 8 * it) * 2 + sv];
+        const unsigned o00 = (tbv & ~3u) + qd16, dx = (tbv & 1u) ? (unsigned)(kC * 4) : 0u, dy = (tbv & 2u) ? row_step : 0u;
+        auto ld = [&](unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc[sv], (int)off, chunk_off, 0)); };
         tap[0] = ld(o00);
         tap[1] = ld(o00 + dx);
         tap[2] = ld(o00 + dy);
         tap[3] = ld(o00 + dx + dy);
-        }
     };
-    auto blend_row = [&](const f32x4 (&tap)[4], int sv, int l, int it) {
+    auto blend_row = [&](const f32x4 (&tap)[4], int sv, int it) {
         if constexpr (ABL == 2 || ABL == 3 || ABL == 12) return;
-        if constexpr (ABL == 14) { if (l == 0) return; l = 0; }
-        const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 8 + 4 * l);
+        const float4 w = *reinterpret_cast<const float4*>(lds + kLdsTapW + ((wave * kRows + r0 + 8 * it) * 2 + sv) * 4);
         const float ww[4] = {w.x, w.y, w.z, w.w};
         f32x2 lo2 = {hacc[it].x, hacc[it].y}, hi2 = {hacc[it].z, hacc[it].w};          // v_pk_fma_f32: two FMAs per instruction
 #pragma unroll
@@ -274,14 +244,14 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : kThreads) fus
             make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
     };
     // Scales of the split-fp16 arithmetic (car_fused_mma.h).  Packed weights carry 2^shift per layer (dW.. = 2^-shift, from the
-    // bias table).  h is bounded by the largest lattice value plus the largest value of the finest level plus the point / bias
-    // term, because a map's tap weights are non-negative and sum to at most one and |tanh| <= 1: one power of two hp per launch.
+    // bias table).  h is bounded by the largest lattice value plus the point / bias term, because the tap weights are non-negative
+    // and sum to at most one and |tanh| <= 1: one power of two hp per launch.
     const float* lsc = lds + kLdsBias + kBiasScale;
     auto uniform = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };   // keep it in an SGPR
     float hp, e_up, e_down;
     {
         float hinv;
-        pow2_scale(fmaxf((a.gmeta[0] + a.gmeta[1]) + lsc[5], 1e-30f), hp, hinv);
+        pow2_scale(fmaxf(a.gmeta[0] + lsc[5], 1e-30f), hp, hinv);
         const float dW2 = lsc[kLayerW2];
         e_up = uniform(hp / dW2); e_down = uniform(dW2 * hinv); hp = uniform(hp);
     }
@@ -292,166 +262,54 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : kThreads) fus
         split8(x, hp, bhi, blo);
     };
 
-    if constexpr (ABL == 15 || ABL == 16 || ABL == 17) {
-        // development build: the gather alone (as 5) with whole chunks of tap loads in flight — 15: one chunk ahead (16-32 loads per
-        // wave), 16: two chunks ahead (32-48), 17: three ahead (48-64) — against 5's two batches of four.  How far the gather is
-        // bound by the latency of its far misses times the loads a wave can keep in flight.  16 and 17 run 8 waves per workgroup
-        // (256 registers each; two thirds of the samples are gathered: scale their time by 1.5).
-        constexpr int NS = ABL == 15 ? 2 : ABL == 16 ? 3 : 4;
-        f32x4 ring[NS][4][4];
-#pragma unroll
-        for (int m = 0; m < 2 * kKS + NS - 1; ++m) {
-            if (m < 2 * kKS) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) issue_row(ring[m % NS][k], m / kKS, m % kKS, 1 - (k >> 1), k & 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);                          // keep the whole chunk's loads ahead of the blends below
-            const int d = m - (NS - 1);
-            if (d >= 0) {
-                affine_row(d / kKS, d % kKS, 0); affine_row(d / kKS, d % kKS, 1);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) blend_row(ring[d % NS][k], d / kKS, 1 - (k >> 1), k & 1);
-                finish_row(0); finish_row(1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-        if (lds[kLdsStage + tid] == 123.456f) a.logit[0] = 1.0f;
-        return;
-    }
-    f32x4 acc[kTE];
-    float m0 = 0.0f;                                                   // largest |e_0| of this lane's sample
-    half8 bhi, blo;
-    constexpr bool kTapsLive = (ABL == 0 || ABL >= 5);
-    if constexpr (kRing > 2) {
-        // ---- ring schedule (8 waves, 256 registers): kRing = 6 tap batches in flight per wave.  Batch j = 4 m + k is batch k of flat
-        //      chunk m = 18 sv + c, in the order (map, row group) = (1,0) (1,1) (0,0) (0,1); it lives in ring[j % 6].  While the
-        //      matrix pipe works on chunk m, the wave blends the four batches of chunk m + 1 and re-issues each freed buffer with
-        //      batch j + 6 (chunks m + 2 / m + 3).  The chunk loop is unrolled by 3 so that every buffer index is a constant. ----
-        f32x4 ring[kRing][4];
-        auto batch_l = [](int k) { return 1 - (k >> 1); };
-        auto issue_flat = [&](f32x4 (&tap)[4], int mm, int k) {        // batch k of flat chunk mm (past the end: re-reads source 1)
-            const int me = mm < 2 * kKS ? mm : mm - kKS;
-            const int bsv = me >= kKS ? 1 : 0;
-            issue_row(tap, bsv, me - bsv * kKS, batch_l(k), k & 1);
-        };
-        // chunk 0: nothing to hide it under
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            affine_row(0, 0, it);
-#pragma unroll
-            for (int l = 1; l >= 0; --l) {
-                issue_row(ring[0], 0, 0, l, it);
-                blend_row(ring[0], 0, l, it);
-            }
-            finish_row(it);
-        }
-        stream_sync();                                                 // weight chunk 0 landed
-        mark(2);
-#pragma unroll
-        for (int j = 4; j < 4 + kRing; ++j) issue_flat(ring[j % kRing], j >> 2, j & 3);      // prologue: the ring's first turn
-        read_b(bhi, blo);
-#pragma unroll 1
-        for (int sv = 0; sv < 2; ++sv) {
-            init_bias<kTE>(acc, lds + kLdsBias + kBiasE, q4, e_up);
-#pragma unroll 1
-            for (int c0 = 0; c0 < kKS; c0 += 3) {
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int m = kKS * sv + c0 + u;                   // chunk on the matrix pipe; chunk m + 1 is being gathered
-                    const int ne = m + 1 < 2 * kKS ? m + 1 : m + 1 - kKS;
-                    const int nsv = ne >= kKS ? 1 : 0, nc = ne - nsv * kKS;
-                    const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
-                    const NextChunk nx = next_chunk_w2(a.blob, lds, g + 1);
-                    // every DMA piece of the next weight chunk goes out before this chunk's tap loads: at the chunk's end
-                    // "at most 16 outstanding" then means the weights have landed while four tap batches stay in flight
-                    auto piece = [&](int qs) {
-                        if (qs == 0) {
-#pragma unroll
-                            for (int pp_ = 0; pp_ < 3 && pp_ < kPieces; ++pp_) stream_issue_piece<ABL>(nx, pp_, lane, wave);
-                            affine_row(nsv, nc, 0); affine_row(nsv, nc, 1);
-                        } else if (qs == 1) {
-#pragma unroll
-                            for (int pp_ = 3; pp_ < kPieces; ++pp_) stream_issue_piece<ABL>(nx, pp_, lane, wave);
-                        } else if (qs == 2 || qs == 3 || qs == 6 || qs == 7) {
-                            const int k = qs == 2 ? 0 : qs == 3 ? 1 : qs == 6 ? 2 : 3;
-                            constexpr int dummy = 0; (void)dummy;
-                            f32x4 (&buf)[4] = ring[(4 * (u + 1) + k) % kRing];
-                            blend_row(buf, nsv, batch_l(k), k & 1);
-                            if (k >= 2) finish_row(k & 1);
-                            issue_flat(buf, m + 1 + (k + kRing) / 4, (k + kRing) & 3);
-                        }
-                    };
-#pragma unroll
-                    for (int qs = 0; qs < kTE / 2; ++qs) {
-                        const float* w0 = wl + (2 * qs * 2) * 256;
-                        if constexpr (ABL < 5 || (ABL >= 11 && ABL < 18)) mfma_pair<ABL>(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
-                        piece(qs);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    read_b(bhi, blo);                                  // next chunk's B operand (own LDS tile, in-order LDS)
-                    stream_sync<ABL, kTapsLive ? 16 : 0>();            // the 16 tap loads of this chunk stay in flight over the barrier
-                    ++g;
-                }
-            }
-            scale_acc<kTE>(acc, e_down);
-            mark(3 + sv);
-            if (sv == 0) {
-                m0 = sample_max<kTE, false>(acc);
-                if (live) store_rows<kTE>(acc, a.e + i * (2 * kE), q4);
-            }
-        }
-    } else {
     // first chunk of source 0: nothing to hide it under
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         affine_row(0, 0, it);
-#pragma unroll
-        for (int l = 1; l >= 0; --l) {
-            issue_row(bufA, 0, 0, l, it);
-            blend_row(bufA, 0, l, it);
-        }
+        issue_row(bufA, 0, 0, it);
+        blend_row(bufA, 0, it);
         finish_row(it);
     }
     stream_sync();                                                     // weight chunk 0 landed
     mark(2);
-    issue_row(bufA, 0, 1, 1, 0);                                       // pipeline prologue: the finest level of chunk (0, 1), both row groups
-    issue_row(bufB, 0, 1, 1, 1);
+    constexpr bool kTapsLive = (ABL == 0 || ABL >= 4);
+    issue_row(bufA, 0, 1, 0);                                          // pipeline prologue: chunk (0, 1), both row groups
+    issue_row(bufB, 0, 1, 1);
 
+    f32x4 acc[kTE];
+    float m0 = 0.0f;                                                   // largest |e_0| of this lane's sample
+    half8 bhi, blo;
     read_b(bhi, blo);
 #pragma unroll 1
     for (int sv = 0; sv < 2; ++sv) {
         init_bias<kTE>(acc, lds + kLdsBias + kBiasE, q4, e_up);
 #pragma unroll 1
         for (int c = 0; c < kKS; ++c) {
-            // chunk being gathered: m+1 = (nsv, nc); the finest level of chunk m+2 = (n2sv, n2c) is issued at the end.  Branch-free on
-            // purpose: past the last chunk the gather harmlessly re-reads chunks of source 1.
+            // chunk being gathered: m+1 = (nsv, nc); chunk m+2 = (n2sv, n2c) is issued into each buffer as soon as it has been blended.
+            // Branch-free on purpose: past the last chunk the gather harmlessly re-reads chunks of source 1.
             const int nsv = (c + 1 < kKS) ? sv : 1;
             const int nc = (c + 1 < kKS) ? c + 1 : 0;
             const int n2sv = (c + 2 < kKS) ? sv : 1;
             const int n2c = (c + 2 < kKS) ? c + 2 : c + 2 - kKS;
             const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
             const NextChunk nx = next_chunk_w2(a.blob, lds, g + 1);
-            // 9 slots of (4 ds_read_b128 + 6 MFMAs of 16 cycles); between them one piece of the gather / DMA issue.  Batches (map, row
-            // group) in the order (1,0) (1,1) (0,0) (0,1); batch k is blended in slot {2,3,6,7}[k] and batch k+2 issued into the buffer
-            // it frees; slots 0-2 also carry the DMA pieces, slot 0 the affine start values.
+            // 9 slots of (4 ds_read_b128 + 6 MFMAs of 16 cycles); between them one piece of the gather / DMA issue: slots 0-2 carry the
+            // DMA pieces, slot 0 the affine start values, slots 3 and 6 one row group each — blend, store the h rows, re-issue.
             auto piece = [&](int qs) {
                 if (qs < kPieces) stream_issue_piece<ABL>(nx, qs, lane, wave);
                 if (qs == 0) { affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); }
-                else if (qs == 2) { blend_row(bufA, nsv, 1, 0); issue_row(bufA, nsv, nc, 0, 0); }
-                else if (qs == 3) { blend_row(bufB, nsv, 1, 1); issue_row(bufB, nsv, nc, 0, 1); }
-                else if (qs == 6) { blend_row(bufA, nsv, 0, 0); finish_row(0); issue_row(bufA, n2sv, n2c, 1, 0); }
-                else if (qs == 7) { blend_row(bufB, nsv, 0, 1); finish_row(1); issue_row(bufB, n2sv, n2c, 1, 1); }
+                else if (qs == 3) { blend_row(bufA, nsv, 0); finish_row(0); issue_row(bufA, n2sv, n2c, 0); }
+                else if (qs == 6) { blend_row(bufB, nsv, 1); finish_row(1); issue_row(bufB, n2sv, n2c, 1); }
             };
 #pragma unroll
             for (int qs = 0; qs < kTE / 2; ++qs) {
                 const float* w0 = wl + (2 * qs * 2) * 256;
-                if constexpr (ABL < 5 || (ABL >= 11 && ABL < 18)) mfma_pair<ABL>(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
+                if constexpr (ABL != 5) mfma_pair<ABL>(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
                 piece(qs);
                 __builtin_amdgcn_sched_barrier(0);
             }
             read_b(bhi, blo);                                          // next chunk's B operand (own LDS tile, in-order LDS)
-            // the 8 tap loads issued in slots 6 and 7 stay in flight over the barrier
+            // the 8 tap loads issued in slots 3 and 6 stay in flight over the barrier (they are younger than every DMA piece)
             stream_sync<ABL, kTapsLive ? 8 : 0>();
             ++g;
         }
@@ -461,7 +319,6 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : kThreads) fus
             m0 = sample_max<kTE, false>(acc);
             if (live) store_rows<kTE>(acc, a.e + i * (2 * kE), q4);
         }
-    }
     }
     // ---- k1 = Wk1 [e_0 ; e_1] + bk1: first the e_1 half, chained from the accumulators; then e_1 is stored and its registers take
     //      e_0 back from the output tensor (written by this wave one source pass ago: L2), same layout, for the other half ----
@@ -544,22 +401,20 @@ __global__ void __launch_bounds__((ABL == 16 || ABL == 17) ? 512 : kThreads) fus
 
 
 int launch_fused(int abl, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w, int lat_pad,
-                 const float* fine, int fine_h, int fine_w, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,
-                 int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
-    CAR_REQUIRE(poses && rays && steps && lattice && fine && gmeta && wpt && blob && bias, "car_fused_samples: null input");
+                 const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W, float* e,
+                 float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+    CAR_REQUIRE(poses && rays && steps && lattice && gmeta && wpt && blob && bias, "car_fused_samples: null input");
     CAR_REQUIRE(e && qry && g && logit && pt && pixel_val, "car_fused_samples: null output");
     CAR_REQUIRE(V == 2, "car_fused_samples: built for V = 2 (got %d)", V);
     CAR_REQUIRE(b > 0 && R > 0 && P > 0 && H > 1 && W > 1, "car_fused_samples: bad sizes");
     CAR_REQUIRE(lat_pad >= 2 && lat_h > 2 * lat_pad + 1 && lat_w > 2 * lat_pad + 1 && ((lat_h - 2 * lat_pad) & 1) && ((lat_w - 2 * lat_pad) & 1),
                 "car_fused_samples: bad lattice %d x %d, pad %d (car_lattice_shape)", lat_h, lat_w, lat_pad);
-    // nodes and texels are addressed by 32-bit byte offsets inside their map; hosts with more scenes render them in groups (engine.py)
-    CAR_REQUIRE(fine_h > 0 && fine_w > 0 && (long)b * V * 2 * lat_h * lat_w * (kC * 4) < kMaxMapBytes && (long)b * V * fine_h * fine_w * (kC * 4) < kMaxMapBytes,
-                "car_fused_samples: the lattice and the finest level of one call must each stay below 4 GiB (render fewer scenes per call)");
+    // nodes are addressed by 32-bit byte offsets inside the lattice of one (view, padding mode)
+    CAR_REQUIRE((long)lat_h * lat_w * (kC * 4) < kMaxMapBytes, "car_fused_samples: a lattice of %d x %d nodes exceeds 4 GiB per view", lat_h, lat_w);
     FusedArgs a;
     a.poses = (const CarPose*)poses; a.rays = (const CarRay*)rays; a.steps = steps;
-    a.gmap[0] = lattice; a.lh = lat_h; a.lw = lat_w; a.pad = lat_pad;
-    a.gmap[1] = fine; a.fh = fine_h; a.fw = fine_w;
-    a.gbytes[0] = (unsigned)((long)b * V * 2 * lat_h * lat_w * (kC * 4)); a.gbytes[1] = (unsigned)((long)b * V * fine_h * fine_w * (kC * 4));
+    a.lattice = lattice; a.lh = lat_h; a.lw = lat_w; a.pad = lat_pad;
+    a.map_bytes = (unsigned)((long)lat_h * lat_w * (kC * 4));
     a.sx = (float)((lat_w - 2 * lat_pad + 1) / 2); a.sy = (float)((lat_h - 2 * lat_pad + 1) / 2);
     a.gmeta = gmeta; a.wpt = wpt; a.blob = blob; a.bias = bias;
     a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
@@ -570,9 +425,8 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
 #ifdef CAR_ABLATION
     switch (abl) {
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
-        case 5: kern = fused_kernel<5>; break;   case 6: kern = fused_kernel<6>; break;   case 7: kern = fused_kernel<7>; break;
-        case 8: kern = fused_kernel<8>; break;   case 11: kern = fused_kernel<11>; break;   case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;   case 14: kern = fused_kernel<14>; break;   case 15: kern = fused_kernel<15>; break;   case 16: kern = fused_kernel<16>; break;   case 17: kern = fused_kernel<17>; break;   case 18: kern = fused_kernel<18>; break;   case 19: kern = fused_kernel<19>; break;
-        case 4: kern = fused_kernel<4>; break;
+        case 4: kern = fused_kernel<4>; break;   case 5: kern = fused_kernel<5>; break;   case 11: kern = fused_kernel<11>; break;
+        case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;
         default: break;
     }
 #else
@@ -581,7 +435,7 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     if (e1 != hipSuccess) { car_set_error("car_fused_samples: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3((abl == 16 || abl == 17) ? 512 : kThreads), kLdsBytes, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a);
     CAR_CHECK_LAUNCH("car_fused_samples");
     return CAR_OK;
 }
@@ -592,20 +446,19 @@ extern "C" size_t car_fused_blob_floats(void) { return (size_t)kBlobTiles * kTil
 extern "C" size_t car_fused_bias_floats(void) { return (size_t)kBiasFloats; }
 
 extern "C" int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
-                                 int lat_pad, const float* fine, int fine_h, int fine_w, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V,
-                                 int R, int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val,
-                                 void* stream) {
-    return launch_fused(0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, fine, fine_h, fine_w, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt,
-                        pixel_val, stream);
+                                 int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P,
+                                 int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+    return launch_fused(0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt, pixel_val,
+                        stream);
 }
 
 #ifdef CAR_ABLATION
 // development build only (tools/build_dev.py): timing-only variants of the kernel, results are wrong by construction
 extern "C" int car_fused_samples_ablate(int abl, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h,
-                                        int lat_w, int lat_pad, const float* fine, int fine_h, int fine_w, const float* gmeta, const float* wpt, const float* blob, const float* bias,
-                                        int b, int V, int R, int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt,
+                                        int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b,
+                                        int V, int R, int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt,
                                         float* pixel_val, void* stream) {
-    return launch_fused(abl, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, fine, fine_h, fine_w, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit,
-                        pt, pixel_val, stream);
+    return launch_fused(abl, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt,
+                        pixel_val, stream);
 }
 #endif

@@ -41,7 +41,7 @@ __device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, 
 // LDS-DMA in inline asm, see car_linear.hip.  Must only run after the barrier that retired the buffer's previous chunk.
 template <int ABL = 0>
 __device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, int lane, int wave) {
-    if constexpr (ABL == 3 || ABL == 12 || (ABL >= 5 && ABL < 11) || ABL == 18 || ABL == 19) return;
+    if constexpr (ABL == 3 || ABL == 12 || ABL == 5) return;
     int kb = kWaves * p + wave;
     kb = kb < n.nkb ? kb : kb - n.nkb;
     kb = kb < n.nkb ? kb : kb - n.nkb;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void stream_issue_all(const float* __restrict__ blob,
 // order, so "at most KEEP outstanding" still means every DMA piece has landed).
 template <int ABL = 0, int KEEP = 0>
 __device__ __forceinline__ void stream_sync() {
-    if constexpr (ABL == 3 || ABL == 12 || (ABL >= 5 && ABL < 11) || ABL == 18 || ABL == 19) return;
+    if constexpr (ABL == 3 || ABL == 12 || ABL == 5) return;
     if constexpr (KEEP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (KEEP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");

@@ -168,22 +168,18 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
     }
     reinterpret_cast<float4*>(a.lat)[idx] = acc;
 }
-// The level with the most texels ("fine") is gathered directly — merged, it would double the lattice in both directions — and the
-// other levels are summed on their common lattice.
-struct Lattice { int h, w, pad, r[CAR_MAX_LEVELS], fine; bool ok; };
+// Every level is summed on the lattice: it must be an integer factor r_l coarser than the widest level, the same factor in both
+// directions; lat = 2 W_max + 2 r_max + 1 nodes, pad = r_max + 1 (521 x 521 nodes, pad 5, for the 64 / 128 / 256 pyramid of a 256 x 256
+// frame: 2.5 GB per scene for two views and two padding modes).
+struct Lattice { int h, w, pad, r[CAR_MAX_LEVELS]; bool ok; };
 Lattice lattice_of(const car_dims& d) {
     Lattice L{};
     int hm = 0, wm = 0, rmax = 1;
-    L.fine = 0;
-    for (int l = 1; l < d.n_levels; ++l)
-        if ((long)d.level_h[l] * d.level_w[l] >= (long)d.level_h[L.fine] * d.level_w[L.fine]) L.fine = l;
     for (int l = 0; l < d.n_levels; ++l) {
-        if (l == L.fine) continue;
         hm = d.level_h[l] > hm ? d.level_h[l] : hm; wm = d.level_w[l] > wm ? d.level_w[l] : wm;
     }
-    L.ok = d.n_levels > 1;
+    L.ok = d.n_levels > 0;
     for (int l = 0; l < d.n_levels && L.ok; ++l) {
-        if (l == L.fine) continue;
         const int h = d.level_h[l], w = d.level_w[l];
         L.ok = h > 0 && w > 0 && hm % h == 0 && wm % w == 0 && hm / h == wm / w;
         if (L.ok) { L.r[l] = hm / h; rmax = L.r[l] > rmax ? L.r[l] : rmax; }
@@ -240,9 +236,8 @@ int check_dims(const car_dims* d, const char* who) {
     }
     CAR_REQUIRE(csum == kC, "%s: the levels' channels must add up to %d (got %d)", who, kC, csum);
     CAR_REQUIRE(2 * d->P <= 128 * 3, "%s: too many samples per ray", who);
-    CAR_REQUIRE(lattice_of(*d).ok, "%s: below the finest pyramid level every level must be an integer factor coarser than the next, the same "
-                "factor in both directions (the fused kernel gathers them from their common lattice); other pyramids run through the stage "
-                "entries", who);
+    CAR_REQUIRE(lattice_of(*d).ok, "%s: every pyramid level must be an integer factor coarser than the widest one, the same factor in both "
+                "directions (the fused kernel gathers them from their common lattice); other pyramids run through the stage entries", who);
     return CAR_OK;
 }
 
@@ -350,13 +345,10 @@ extern "C" size_t car_workspace_bytes(const car_dims* dims) {
 namespace {
 size_t lattice_floats(const car_dims& d) { const Lattice L = lattice_of(d); return (size_t)d.b * d.V * 2 * L.h * L.w * kC; }
 size_t level_floats(const car_dims& d, int l) { return (size_t)d.b * d.V * d.level_h[l] * d.level_w[l] * kC; }
-// projected levels behind the lattice and gmeta: the finest first (an input of the fused kernel), then the merged ones (scratch)
+// projected levels behind the lattice and gmeta (scratch of car_project_maps: the merge reads them)
 size_t level_offset(const car_dims& d, int level) {
-    const int fine = lattice_of(d).fine;
     size_t n = up64(lattice_floats(d)) + 64;
-    if (level == fine) return n;
-    n += up64(level_floats(d, fine));
-    for (int l = 0; l < level && l < d.n_levels; ++l) if (l != fine) n += up64(level_floats(d, l));
+    for (int l = 0; l < level && l < d.n_levels; ++l) n += up64(level_floats(d, l));
     return n;
 }
 }  // namespace
@@ -364,19 +356,15 @@ extern "C" size_t car_gmeta_offset(const car_dims* dims) {
     if (check_dims(dims, "car_gmeta_offset") != CAR_OK) return 0;
     return up64(lattice_floats(*dims));
 }
-extern "C" size_t car_fine_offset(const car_dims* dims) {
-    if (check_dims(dims, "car_fine_offset") != CAR_OK) return 0;
-    return level_offset(*dims, lattice_of(*dims).fine);
-}
 extern "C" size_t car_gmaps_floats(const car_dims* dims) {
     if (check_dims(dims, "car_gmaps_floats") != CAR_OK) return 0;
     return level_offset(*dims, CAR_MAX_LEVELS + 1);
 }
-extern "C" int car_lattice_shape(const car_dims* dims, int* lat_h, int* lat_w, int* lat_pad, int* fine_level) {
+extern "C" int car_lattice_shape(const car_dims* dims, int* lat_h, int* lat_w, int* lat_pad) {
     CAR_TRY(check_dims(dims, "car_lattice_shape"));
-    CAR_REQUIRE(lat_h && lat_w && lat_pad && fine_level, "car_lattice_shape: null pointer");
+    CAR_REQUIRE(lat_h && lat_w && lat_pad, "car_lattice_shape: null pointer");
     const Lattice L = lattice_of(*dims);
-    *lat_h = L.h; *lat_w = L.w; *lat_pad = L.pad; *fine_level = L.fine;
+    *lat_h = L.h; *lat_w = L.w; *lat_pad = L.pad;
     return CAR_OK;
 }
 extern "C" int car_workspace_find(const car_dims* dims, const char* name, size_t* offset_floats, size_t* n_floats) {
@@ -535,12 +523,6 @@ extern "C" int car_project_maps(const car_dims* dims, const void* plan, const fl
         const long M = (long)dims->b * dims->V * dims->level_h[l] * dims->level_w[l];
         float* gl = gmaps + level_offset(*dims, l);
         CAR_TRY(car_linear(maps[l], dims->level_c[l], base + p.proj[l], dims->level_c[l], kC, gl, kC, M, 0, stream));
-        if (l == L.fine) {
-            (void)hipGetLastError();
-            hipLaunchKernelGGL(absmax_kernel, dim3(2048), dim3(256), 0, st, gl, M * kC / 4, reinterpret_cast<unsigned*>(gmeta + 1));
-            CAR_CHECK_LAUNCH("car_project_maps (absmax)");
-            continue;
-        }
         a.g[nm] = gl; a.h[nm] = dims->level_h[l]; a.w[nm] = dims->level_w[l]; a.r[nm] = L.r[l];
         ++nm;
     }
@@ -560,8 +542,7 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
                                   void* workspace, size_t workspace_bytes, void* stream) {
     CAR_TRY(check_dims(dims, "car_render_forward"));
     CAR_REQUIRE(plan && in && out && workspace, "car_render_forward: null pointer");
-    CAR_REQUIRE(in->poses && in->uv && in->lattice && in->fine && in->gmeta && out->rgb,
-                "car_render_forward: poses, uv, lattice, fine, gmeta and rgb are required");
+    CAR_REQUIRE(in->poses && in->uv && in->lattice && in->gmeta && out->rgb, "car_render_forward: poses, uv, lattice, gmeta and rgb are required");
     const car_dims& d = *dims;
     const Plan p = plan_layout(d);
     const Work w = work_layout(d);
@@ -588,8 +569,7 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
     {   // a6-a13 + round-1 logits: the fused per-sample kernel
         Stage stage("fused_samples", st);
         const Lattice L = lattice_of(d);
-        CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->fine, d.level_h[L.fine], d.level_w[L.fine],
-                                  in->gmeta, pl + p.wpt, pl + p.blob,
+        CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->gmeta, pl + p.wpt, pl + p.blob,
                                   pl + p.fbias, b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
     }
     {   // a14 + a16: attention round 1, depth read-out, argmax

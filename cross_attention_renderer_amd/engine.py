@@ -8,8 +8,8 @@ Two routes:
   * the reference's default configuration (n_view = 2, three pyramid levels, 576 channels, epipolar sampling) goes through the
     ONE-CALL C ABI — ``car_plan_build`` once per set of weights, ``car_project_maps`` once per stereo pair,
     ``car_render_forward`` per batch of rays (csrc/car_render.hip: weight packing and the launch sequence are C++).  This
-    module only sizes the calls: scenes are grouped so that a projected pyramid level stays below 4 GiB per call, and rays are
-    chunked so that the per-call workspace fits the free device memory (rays are independent, so this changes nothing);
+    module only sizes the calls: rays (and, if need be, scenes) are chunked so that the per-call workspace fits the free device
+    memory (rays and scenes are independent, so this changes nothing);
   * the constructor variants (n_view 1 / 3, no_sample, no_latent_concat, other widths) are sequenced here stage by stage —
     also the A/B partner of the first route in the tests.
 
@@ -85,7 +85,7 @@ class RenderEngine:
         self.fuse_round2 = True        # staged route: round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
         # sizing of the one-call route (tests shrink them to force several calls)
         self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
-        self.max_level_bytes = 0xfffff000 - 1              # lattice / finest level of one call: the fused kernel's 32-bit node offsets
+        self.max_level_bytes: Optional[int] = None         # tests: lattice bytes of one call (forces scene groups); None = no limit
         self.last_calls = 0            # number of car_render_forward calls the last forward was split into
         self._round2_key = None
         self._round2 = None
@@ -289,13 +289,11 @@ class RenderEngine:
 
     @staticmethod
     def _common_lattice(z: List[Tensor]) -> bool:
-        """The fused kernel gathers the levels below the finest one from their merged lattice (car_lattice_shape): each must be an
-        integer factor coarser than the widest of them, the same factor in both directions.  Other pyramids take the stage route."""
+        """The fused kernel gathers every level from their common lattice (car_lattice_shape): each must be an integer factor coarser
+        than the widest one, the same factor in both directions.  Other pyramids take the stage route."""
         sizes = [(t.shape[2], t.shape[3]) for t in z]
-        fine = max(range(len(sizes)), key=lambda l: (sizes[l][0] * sizes[l][1], l))
-        rest = [s for l, s in enumerate(sizes) if l != fine]
-        hm, wm = max(h for h, _ in rest), max(w for _, w in rest)
-        return all(hm % h == 0 and wm % w == 0 and hm // h == wm // w for h, w in rest)
+        hm, wm = max(h for h, _ in sizes), max(w for _, w in sizes)
+        return all(hm % h == 0 and wm % w == 0 and hm // h == wm // w for h, w in sizes)
 
     def _workspace_budget(self, device) -> int:
         if self.max_workspace_bytes is not None:
@@ -313,18 +311,15 @@ class RenderEngine:
         d_all = self._dims(b, R, z)
         plan = self._plan_for(d_all, dev)
         pair = self._pair_for(d_all, plan, z, dev)
-        lh, lw, lpad, fine = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        _lib.check(lib.car_lattice_shape(ctypes.byref(d_all), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(lpad), ctypes.byref(fine)),
-                   "car_lattice_shape")
+        lh, lw, lpad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(lib.car_lattice_shape(ctypes.byref(d_all), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(lpad)), "car_lattice_shape")
         lattice_scene = V * 2 * lh.value * lw.value * 576                                        # floats per scene
-        fine_scene = V * z[fine.value].shape[2] * z[fine.value].shape[3] * 576
-        fine_ptr = pair.data_ptr() + 4 * lib.car_fine_offset(ctypes.byref(d_all))
         gmeta_ptr = pair.data_ptr() + 4 * lib.car_gmeta_offset(ctypes.byref(d_all))
 
-        # scenes per call: the merged lattice and the finest projected level must each stay below 4 GiB (32-bit node offsets in the
-        # fused kernel); rays per call: the workspace (~0.44 MB per ray at 64 samples) must fit the free memory.  Rays are
-        # independent, so the split is exact.
-        gs = max(1, min(b, self.max_level_bytes // (4 * max(lattice_scene, fine_scene))))
+        # scenes per call: any number (the fused kernel addresses the lattice of ONE view and padding mode with 32-bit offsets);
+        # max_level_bytes lets tests force scene groups.  Rays per call: the workspace (~0.44 MB per ray at 64 samples) must fit the
+        # free memory.  Rays and scenes are independent, so the split is exact.
+        gs = b if self.max_level_bytes is None else max(1, min(b, self.max_level_bytes // (4 * lattice_scene)))
         budget = self._workspace_budget(dev)
 
         def ws_bytes(nb, nr):
@@ -370,7 +365,6 @@ class RenderEngine:
                 ci.poses = poses.data_ptr() + 4 * 96 * s0 * V
                 ci.uv = uv_c.data_ptr()
                 ci.lattice = pair.data_ptr() + 4 * s0 * lattice_scene
-                ci.fine = fine_ptr + 4 * s0 * fine_scene
                 ci.gmeta = gmeta_ptr
                 ci.steps = steps.data_ptr()
                 co = _lib.CarOutputs(*[tgt[k].data_ptr() for k in order])

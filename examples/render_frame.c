@@ -121,7 +121,7 @@ static int run_fixture(const char* dir, int host_poses) {
     in.poses = poses;
     if (!(in.uv = read_floats(dir, "uv", (size_t)d.b * d.R * 2, 1))) return 2;
     if (!(in.steps = read_floats(dir, "steps", (size_t)d.P, 1))) return 2;            /* torch.linspace of the fixture's host */
-    in.lattice = gmaps; in.fine = gmaps + car_fine_offset(&d); in.gmeta = gmaps + car_gmeta_offset(&d);
+    in.lattice = gmaps; in.gmeta = gmaps + car_gmeta_offset(&d);
     car_outputs out;
     memset(&out, 0, sizeof out);
     const size_t BR = (size_t)d.b * d.R;
@@ -197,7 +197,7 @@ int main(int argc, char** argv) {
     car_inputs in;
     memset(&in, 0, sizeof in);
     in.poses = poses; in.uv = uv;
-    in.lattice = gmaps; in.fine = gmaps + car_fine_offset(&d);
+    in.lattice = gmaps;
     in.gmeta = gmaps + car_gmeta_offset(&d);
     car_outputs out;
     memset(&out, 0, sizeof out);

@@ -120,27 +120,25 @@ int car_gather_encode(const float* const* gmaps, const int* level_h, const int* 
                       int n_maps, int V, long pts, float* out, int ld_out, void* stream);
 
 /* ---- a6-a13 + logits of a14 in ONE kernel for the default configuration (V = 2, C = 576, hidden 128): geometry, the
- * per-texel-projected encode (car_gather_encode's arithmetic; the levels below the finest one are summed on their merged lattice,
- * four taps instead of four per level), 576->288 per source, key MLP, query MLP and the round-1 logits, with e / key / qry chained through the
- * MFMA accumulator registers (csrc/car_fused.hip; models.py:261-344, 487-532).
+ * per-texel-projected encode (car_gather_encode's arithmetic, with ALL pyramid levels summed once per stereo pair on their common
+ * lattice: four taps per sample and source instead of four per level), 576->288 per source, key MLP, query MLP and the round-1
+ * logits, with e / key / qry chained through the MFMA accumulator registers (csrc/car_fused.hip; models.py:261-344, 487-532).
  * Every layer runs on the f16 matrix pipe with both operands split into fp16 high/low halves (three products per term,
  * fp32-class accuracy).  `blob` / `bias` are the layer weights in the kernel's operand order: car_fused_blob_floats() /
  * car_fused_bias_floats() floats, written by car_plan_build (layout: csrc/car_fused_mma.h; the fp16 halves of each layer carry
  * a power of two chosen from the layer's largest weight, recorded in `bias`).
  * `lattice` [b*V][2][lat_h][lat_w][576]: for every context view and padding mode (0 border, 1 zeros) the sum over the pyramid
- * levels below the finest of grid_sample(G_l), evaluated on the integer lattice u = (x + 1) W_m - 1 in [-lat_pad, 2 W_m - 1 + lat_pad]
- * that those levels' texel centres share (W_m: the widest of them; car_project_maps builds it, car_lattice_shape gives its size;
- * csrc/car_geom.h car_lattice_taps).  `fine` [b*V][fine_h][fine_w][576]: the finest level, projected (G_l as in car_gather_encode).
- * `gmeta` [2]: max |lattice|, max |fine| (car_project_maps writes them), from which the kernel derives the power of two that keeps
- * the activations of the first layer inside fp16's range.  Outputs: e [S,576], qry [S,128], g [S,16] (the geometric query
- * local_coords, models.py:528), logit [S], pt [S,3], pixel_val [S,2] with S = b*V*R*P.  The lattice and the finest level of one
- * call must each stay below 4 GiB (six scenes of 256 x 256 images). */
+ * levels of grid_sample(G_l) (G_l as in car_gather_encode), evaluated on the integer lattice u = (x + 1) W_m - 1 in
+ * [-lat_pad, 2 W_m - 1 + lat_pad] that the levels' texel centres share (W_m: the widest level; car_project_maps builds it,
+ * car_lattice_shape gives its size; csrc/car_geom.h car_lattice_taps).  `gmeta` [1]: max |lattice| (car_project_maps writes it),
+ * from which the kernel derives the power of two that keeps the activations of the first layer inside fp16's range.
+ * Outputs: e [S,576], qry [S,128], g [S,16] (the geometric query local_coords, models.py:528), logit [S], pt [S,3],
+ * pixel_val [S,2] with S = b*V*R*P.  The lattice of one (view, padding mode) must stay below 4 GiB (images up to ~650 pixels). */
 size_t car_fused_blob_floats(void);
 size_t car_fused_bias_floats(void);
 int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
-                      int lat_pad, const float* fine, int fine_h, int fine_w, const float* gmeta, const float* wpt, const float* blob,
-                      const float* bias, int b, int V, int R, int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt,
-                      float* pixel_val, void* stream);
+                      int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P,
+                      int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream);
 
 /* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
  *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).
@@ -244,7 +242,7 @@ int car_reduce_samples(const float* d, int b, int V, int R, int P, int C, float*
  *
  *   car_plan_bytes / car_plan_build      once per set of weights: re-lays every layer out for the kernels ("plan", device memory)
  *   car_project_maps                     once per stereo pair: first point-MLP layer applied per texel of the pyramid and the
- *                                        levels below the finest summed on their common lattice (§4.3 DESIGN.md)
+ *                                        levels summed on their common lattice (§4.3 DESIGN.md)
  *   car_workspace_bytes / car_render_forward   once per batch of rays
  *
  * All pointers are device pointers unless marked host; nothing is allocated, nothing is kept.  car_plan_build synchronises
@@ -274,11 +272,9 @@ typedef struct car_weights {
 typedef struct car_inputs {
     const float* poses;            /* [b*V, CAR_POSE_FLOATS]  from car_pose_setup, or filled by the host (poses.py)        */
     const float* uv;               /* [b, R, 2] pixel coordinates (x = column, y = row)                                     */
-    const float* lattice;          /* merged lattice of THESE b scenes, [b*V, 2, lat_h, lat_w, 576]: the start of car_project_maps'
-                                      buffer (a host that renders a sub-range of scenes adds scene0 * V * 2 * lat_h * lat_w * 576 floats) */
-    const float* fine;             /* the finest level of THESE b scenes, projected, [b*V, Hf, Wf, 576]: car_fine_offset() floats into
-                                      that buffer (+ scene0 * V * Hf * Wf * 576 for a sub-range)                                  */
-    const float* gmeta;            /* [CAR_MAX_LEVELS] max |lattice|, max |fine| over all scenes: car_gmeta_offset() floats into that buffer */
+    const float* lattice;          /* lattice of THESE b scenes, [b*V, 2, lat_h, lat_w, 576]: the start of car_project_maps' buffer (a host
+                                      that renders a sub-range of scenes adds scene0 * V * 2 * lat_h * lat_w * 576 floats)      */
+    const float* gmeta;            /* [CAR_MAX_LEVELS] max |lattice| over all scenes: car_gmeta_offset() floats into that buffer   */
     const float* steps;            /* optional [P]: sample positions along the epipolar segment.  NULL = the plan's linspace(0,1,P)
                                       (car_linspace).  torch.linspace itself differs in the last ulp between hosts (its vectorised
                                       kernel depends on the CPU's vector width), so a host that wants torch's exact values passes them. */
@@ -304,13 +300,12 @@ int car_round2_pack(const float* wr1, const float* br1, const float* wr2, const 
 
 size_t car_plan_bytes(const car_dims* dims);
 int car_plan_build(const car_dims* dims, const car_weights* weights, void* plan, void* stream);
-size_t car_gmaps_floats(const car_dims* dims);                 /* lattice + gmeta + the projected levels (the finest first)       */
+size_t car_gmaps_floats(const car_dims* dims);                 /* lattice + gmeta + the projected levels (scratch of the merge)    */
 size_t car_gmeta_offset(const car_dims* dims);                 /* float offset of gmeta inside that buffer                        */
-size_t car_fine_offset(const car_dims* dims);                  /* float offset of the projected finest level inside that buffer   */
-/* Lattice size for these levels and which level is gathered directly (the one with the most texels).  Every other level must be
- * an integer factor r_l coarser than the widest of them (same factor in both directions): lat_w = 2 W_m + 2 r_max + 1,
- * lat_pad = r_max + 1.  Other pyramids return CAR_E_ARG (stage entries). */
-int car_lattice_shape(const car_dims* dims, int* lat_h, int* lat_w, int* lat_pad, int* fine_level);
+/* Lattice size for these levels.  Every level must be an integer factor r_l coarser than the widest one (same factor in both
+ * directions): lat_w = 2 W_m + 2 r_max + 1, lat_pad = r_max + 1 (521 x 521, pad 5 for levels of 64 / 128 / 256: 2.5 GB per scene).
+ * Other pyramids return CAR_E_ARG (stage entries). */
+int car_lattice_shape(const car_dims* dims, int* lat_h, int* lat_w, int* lat_pad);
 /* maps[l]: level l of the encoder's pyramid, channel-last [b*V, Hl, Wl, Cl] (`maps` is a host array of device pointers). */
 int car_project_maps(const car_dims* dims, const void* plan, const float* const* maps, float* gmaps, void* stream);
 size_t car_workspace_bytes(const car_dims* dims);

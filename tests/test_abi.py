@@ -90,14 +90,14 @@ def test_one_call_abi_host_side(lib):
     S = 2 * 8192 * 64
     assert lib.car_workspace_bytes(ctypes.byref(d)) >= 4 * S * (576 + 128 + 16)           # e, qry, g dominate
     assert lib.car_plan_bytes(ctypes.byref(d)) >= 4 * (lib.car_fused_blob_floats() + lib.car_round2_packed_floats())
-    # the 64 x 64 and 128 x 128 levels share the lattice u in [-3, 257] (pad = r_max + 1 = 3); the 256 x 256 level is gathered directly
-    lh, lw, pad, fine = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    assert lib.car_lattice_shape(ctypes.byref(d), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(pad), ctypes.byref(fine)) == 0
-    assert (lh.value, lw.value, pad.value, fine.value) == (261, 261, 3, 2)
-    lattice = 2 * 2 * 261 * 261 * 576
+    # the three levels (64, 128, 256 wide: factors 4, 2, 1) share the lattice u in [-5, 515] (pad = r_max + 1 = 5)
+    lh, lw, pad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.car_lattice_shape(ctypes.byref(d), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(pad)) == 0
+    assert (lh.value, lw.value, pad.value) == (521, 521, 5)
+    lattice = 2 * 2 * 521 * 521 * 576
     up64 = lambda n: (n + 63) // 64 * 64
     texels = 2 * (64 * 64 + 128 * 128 + 256 * 256)
-    assert lib.car_gmeta_offset(ctypes.byref(d)) == up64(lattice) and lib.car_fine_offset(ctypes.byref(d)) == up64(lattice) + 64
+    assert lib.car_gmeta_offset(ctypes.byref(d)) == up64(lattice)
     assert lib.car_gmaps_floats(ctypes.byref(d)) == up64(lattice) + 64 + texels * 576        # lattice, gmeta, the projected levels
     d.level_h[0] = 60                                                                       # 128 is no multiple of 60: no common lattice
     assert lib.car_gmaps_floats(ctypes.byref(d)) == 0 and b"lattice" in lib.car_last_error()

@@ -306,12 +306,11 @@ def test_whole_frame_call_equals_chunked_calls():
 
 
 
-@pytest.mark.parametrize("name,ws_mib,level_mib", [("t2_c3", 30, None), ("t2_c3", None, 200), ("t1_c1", 24, 4), ("t2_c2", 20, None)])
+@pytest.mark.parametrize("name,ws_mib,level_mib", [("t2_c3", 30, None), ("t2_c3", None, 2600), ("t2_c2", 20, None)])
 def test_forward_split_into_several_calls_is_bit_identical(name, ws_mib, level_mib):
     """The engine splits a forward into several car_render_forward calls when the workspace would not fit the free memory (ray
-    chunks) or a projected pyramid level would reach 4 GiB (scene groups, the fused kernel's 32-bit texel offsets).  Rays are
-    independent and every call sees whole sample groups, so the result must not change by a single bit.  The limits are shrunk
-    here to force the split on small cases."""
+    chunks, then scene groups).  Rays and scenes are independent and every call sees whole sample groups, so the result must not
+    change by a single bit.  The limits are shrunk here to force the split on small cases (level_mib: lattice bytes per call)."""
     c, fx, ora, one = run_case(name, debug=False)
 
     def setup(eng):
@@ -566,9 +565,9 @@ def test_pyramid_without_a_common_lattice_takes_the_stage_route():
 # ----------------------------------------------------------------------------------------------------------
 def test_c3_twelve_scenes_at_full_size():
     """BASELINE config 3 (batch_size 12 at 256x256, 64 samples): one forward over 12 scenes x 8192 rays — the per-GPU share when
-    the frame's rays are banded over 8 ranks — through the one-call route (12.6 M samples; the merged lattices of 12 scenes are
-    7.5 GB, a call addresses 4 GiB of them: two calls of six scenes, 18 GB of workspace each), 64 rays of every scene against the
-    oracle."""
+    the frame's rays are banded over 8 ranks — through the one-call route in ONE call (12.6 M samples; the lattices of 12 scenes are
+    30 GB, the workspace 43 GB; the kernel's 32-bit node offsets span one view's lattice, so the scene count is not limited), 64 rays
+    of every scene against the oracle."""
     from cross_attention_renderer_amd import synthetic as S
     from cross_attention_renderer_amd.models import CrossAttentionRenderer
     dev = torch.device("cuda:0")
@@ -585,7 +584,7 @@ def test_c3_twelve_scenes_at_full_size():
     with torch.no_grad():
         out = m(to_device(inp, dev, cameras_on_host=True), z=[t.to(dev) for t in z])
     torch.cuda.synchronize()
-    assert m._engine.last_calls == 2
+    assert m._engine.last_calls == 1
     assert torch.isfinite(out["rgb"]).all()
     idx = torch.linspace(0, R - 1, 64).long()
     sub = {"context": inp["context"], "query": dict(inp["query"], uv=inp["query"]["uv"][:, :, idx].contiguous())}
@@ -597,10 +596,7 @@ def test_c3_twelve_scenes_at_full_size():
     assert torch.equal(out["valid_mask"][:, idx].cpu(), ora["valid_mask"])
     decided, wrong = argmax_exact_where_decided(out["at_wt_max"][:, idx].cpu(), ora["at_wt"])
     assert wrong == 0
-    # 7 scenes of 256 x 256 images would put the merged lattice (2 views x 2 padding modes x 261 x 261 nodes) at 4.4 GB: the engine
-    # renders them in two groups
-    eng = m._engine
-    assert min(eng.max_level_bytes // (4 * 2 * 2 * 261 * 261 * 576), 7) == 6
+    assert m._engine.max_level_bytes is None          # no scene limit: the kernel's 32-bit offsets span one (view, padding mode) lattice
 
 
 def test_forward_without_z_runs_get_z_on_the_device():

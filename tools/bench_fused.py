@@ -69,31 +69,24 @@ def main():
     wpt = torch.empty(576 * 4, device=dev)
     st = P_(torch.cuda.current_stream().cuda_stream)
     _lib.check(lib.car_fused_pack(ctypes.byref(w), blob.data_ptr(), bias.data_ptr(), wpt.data_ptr(), st), "car_fused_pack")
-    lh, lw, lpad, fine = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    _lib.check(lib.car_lattice_shape(ctypes.byref(d), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(lpad), ctypes.byref(fine)), "car_lattice_shape")
-    fine_ptr = eng._pair.data_ptr() + 4 * lib.car_fine_offset(ctypes.byref(d))
-    fh, fw = z[fine.value].shape[2], z[fine.value].shape[3]
+    lh, lw, lpad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(lib.car_lattice_shape(ctypes.byref(d), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(lpad)), "car_lattice_shape")
     gmeta = eng._pair.data_ptr() + 4 * lib.car_gmeta_offset(ctypes.byref(d))
     steps = eng._linspace(0.0, 1.0, bench.P, dev)
     pixel_val = torch.empty(2 * R * bench.P * 2, device=dev)
     S = 2 * R * bench.P
     flop = 2.0 * S * bench.FUSED_MACS
     variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 5, 6, 7, 8]
-    big = None
     prod = lib.car_fused_samples                        # variant 100: the product library's kernel, timed the same way
     outs = {}
     for v in variants:
         lat = []
         lat_ptr, lat_h, lat_w, lat_pad = eng._pair.data_ptr(), lh.value, lw.value, lpad.value
-        if v == 14:                                        # a lattice of the full three-level size (timing only: random contents)
-            if big is None:
-                big = torch.randn(2 * 2 * 521 * 521 * 576, device=dev)
-            lat_ptr, lat_h, lat_w, lat_pad = big.data_ptr(), 521, 521, 5
         for it in range(7):
             a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             args = (eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), lat_ptr, lat_h, lat_w, lat_pad,
-                    fine_ptr, fh, fw, gmeta, wpt.data_ptr(), blob.data_ptr(),
+                    gmeta, wpt.data_ptr(), blob.data_ptr(),
                     bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
                     pixel_val.data_ptr(), st)
             rc = prod(*args) if v == 100 else fn(v, *args)
