@@ -18,11 +18,12 @@ struct GatherLevels {
     int n_levels;
 };
 
-constexpr int kGRows = 16;          // output rows per workgroup
+constexpr int kGatherCfg = 1;       // (rows per group, items in flight) of the product = (32, 3): see launch_gather (tools/bench_gather.py: 52 % of the HBM peak vs 50 % for (16, 3), 46 % for (64, 3), 41-52 % with four items)
 
-// A workgroup handles 16 consecutive sampled points: the bilinear tap indices / weights are computed once per (point,
-// level) into LDS, then every thread moves float4s: 4 tap reads (L2 / Infinity Cache resident maps), one 16-byte store.
-// The stage is bound by the HBM write of the gathered rows.
+// A workgroup handles kGRows sampled points at a time: the bilinear tap indices / weights are computed once per (point,
+// level) into LDS, then every thread moves float4s: 4 tap reads (L1 / L2 resident maps), one 16-byte store, kItems items
+// (4 kItems tap loads) in flight per thread.  The stage is bound by the texture path (five bytes through it per byte written).
+template <int kGRows, int kItems>
 __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps, const float* __restrict__ grid,
                                                      long pts, int run, int mode, int place, int V, float* __restrict__ out,
                                                      int ld_out, int col_out) {
@@ -38,8 +39,8 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps,
     const long groups = run > 1 ? (long)n_maps * rblocks * run : (total_rows + kGRows - 1) / kGRows;
     __shared__ bool s_live[kGRows];
     for (long gidx = blockIdx.x; gidx < groups; gidx += gridDim.x) {
-        if (tid < kGRows * L.n_levels) {
-            const int rl = tid / L.n_levels, l = tid % L.n_levels;
+        for (int job = tid; job < kGRows * L.n_levels; job += 256) {
+            const int rl = job / L.n_levels, l = job % L.n_levels;
             long mp;
             bool live_row;
             if (run > 1) {
@@ -69,16 +70,16 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps,
             }
         }
         __syncthreads();
-        // three items (12 tap loads) in flight per thread before the first store: the stage lives on memory-level parallelism
+        // kItems items (4 kItems tap loads) in flight per thread before the first store: the stage lives on memory-level parallelism
         const int n_items = kGRows * qpr;
-        for (int it0 = tid; it0 < n_items; it0 += 3 * 256) {
-            float4 tp[3][4];
-            float wv[3][4];
-            long orow[3];
-            int oq[3];
-            bool ok[3];
+        for (int it0 = tid; it0 < n_items; it0 += kItems * 256) {
+            float4 tp[kItems][4];
+            float wv[kItems][4];
+            long orow[kItems];
+            int oq[kItems];
+            bool ok[kItems];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < kItems; ++u) {
                 const int item = it0 + u * 256;
                 const int ci = item < n_items ? item : tid;             // clamp: harmless duplicate read, store masked
                 const int rl = ci / qpr, q = ci % qpr;
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps,
                 oq[u] = q;
             }
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
+            for (int u = 0; u < kItems; ++u) {
                 if (!ok[u]) continue;
                 float4 r;   // ((nw + ne) + sw) + se, products rounded individually (ATen's vectorised CPU kernel order)
                 r.x = ((tp[u][0].x * wv[u][0] + tp[u][1].x * wv[u][1]) + tp[u][2].x * wv[u][2]) + tp[u][3].x * wv[u][3];
@@ -114,6 +115,9 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps,
 }
 
 }  // namespace
+
+int launch_gather(int cfg, const GatherLevels& L, int n_maps, const float* grid, long pts, int run, int mode, int place, int V, float* out,
+                  int ld_out, int col_out, void* stream);
 
 extern "C" int car_gather_bilinear(const float* const* maps, const int* level_c, const int* level_h,
                                    const int* level_w, int n_levels, int n_maps, const float* grid, long pts, int run, int mode,
@@ -139,11 +143,48 @@ extern "C" int car_gather_bilinear(const float* const* maps, const int* level_c,
                 "car_gather_bilinear: output window [%d,%d) must be float4-aligned inside a row of %d", col_out, col_out + 4 * q, ld_out);
     CAR_REQUIRE((long)n_maps * level_h[0] * level_w[0] < 2147483647L, "car_gather_bilinear: map too large for 32-bit texel indices");
     if (run < 1 || pts % run != 0) run = 1;
-    const long groups = run > 1 ? (long)n_maps * ((pts / run + kGRows - 1) / kGRows) * run : ((long)n_maps * pts + kGRows - 1) / kGRows;
+    return launch_gather(kGatherCfg, L, n_maps, grid, pts, run, mode, place, V, out, ld_out, col_out, stream);
+}
+
+#ifdef CAR_ABLATION
+// development build only: the same kernel with another (rows per group, items in flight) pair — tools/bench_gather.py
+extern "C" int car_gather_bilinear_cfg(int cfg, const float* const* maps, const int* level_c, const int* level_h, const int* level_w, int n_levels,
+                                       int n_maps, const float* grid, long pts, int run, int mode, int place, int V, float* out, int ld_out,
+                                       int col_out, void* stream) {
+    GatherLevels L;
+    L.n_levels = n_levels;
+    int q = 0;
+    for (int l = 0; l < n_levels; ++l) { L.map[l] = maps[l]; L.c[l] = level_c[l]; L.h[l] = level_h[l]; L.w[l] = level_w[l]; L.q0[l] = q; q += level_c[l] / 4; }
+    L.q0[n_levels] = q;
+    for (int l = n_levels; l < CAR_MAX_LEVELS; ++l) { L.map[l] = nullptr; L.c[l] = L.h[l] = L.w[l] = 0; if (l > n_levels) L.q0[l] = q; }
+    if (run < 1 || pts % run != 0) run = 1;
+    return launch_gather(cfg, L, n_maps, grid, pts, run, mode, place, V, out, ld_out, col_out, stream);
+}
+#endif
+
+namespace {
+template <int ROWS, int ITEMS>
+int launch_cfg(const GatherLevels& L, int n_maps, const float* grid, long pts, int run, int mode, int place, int V, float* out, int ld_out,
+               int col_out, void* stream) {
+    const long groups = run > 1 ? (long)n_maps * ((pts / run + ROWS - 1) / ROWS) * run : ((long)n_maps * pts + ROWS - 1) / ROWS;
     const unsigned blocks = (unsigned)(groups < 65536 ? groups : 65536);
     (void)hipGetLastError();
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L, n_maps, grid, pts, run, mode,
+    hipLaunchKernelGGL((gather_kernel<ROWS, ITEMS>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, L, n_maps, grid, pts, run, mode,
                        place, V, out, ld_out, col_out);
     CAR_CHECK_LAUNCH("car_gather_bilinear");
     return CAR_OK;
+}
+}  // namespace
+
+int launch_gather(int cfg, const GatherLevels& L, int n_maps, const float* grid, long pts, int run, int mode, int place, int V, float* out,
+                  int ld_out, int col_out, void* stream) {
+    switch (cfg) {
+        case 1: return launch_cfg<32, 3>(L, n_maps, grid, pts, run, mode, place, V, out, ld_out, col_out, stream);
+        case 2: return launch_cfg<64, 3>(L, n_maps, grid, pts, run, mode, place, V, out, ld_out, col_out, stream);
+        case 3: return launch_cfg<16, 4>(L, n_maps, grid, pts, run, mode, place, V, out, ld_out, col_out, stream);
+        case 4: return launch_cfg<32, 4>(L, n_maps, grid, pts, run, mode, place, V, out, ld_out, col_out, stream);
+        case 5: return launch_cfg<64, 4>(L, n_maps, grid, pts, run, mode, place, V, out, ld_out, col_out, stream);
+        case 6: return launch_cfg<64, 6>(L, n_maps, grid, pts, run, mode, place, V, out, ld_out, col_out, stream);
+        default: return launch_cfg<16, 3>(L, n_maps, grid, pts, run, mode, place, V, out, ld_out, col_out, stream);
+    }
 }

@@ -111,3 +111,36 @@ def test_gather_backward_is_the_adjoint_of_the_gather():
             lhs = (out[:, :C].double() * dout[:, :C].double()).sum().item()
             rhs = sum((a.double() * b_.double()).sum().item() for a, b_ in zip(maps, dmaps))
             assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs)), (mode, place, lhs, rhs)
+
+
+def test_a_few_optimizer_steps_reduce_the_image_loss():
+    """The reference's training step (training.py:92-136) with render_train in the place of model(model_input): L1 image loss on
+    192 random rays of a synthetic pair, backward through the HIP kernels, Adam on the renderer's parameters AND on the feature
+    pyramid (standing in for the encoder's output) — the loss must fall."""
+    from cross_attention_renderer_amd import synthetic as S
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    from cross_attention_renderer_amd.training import render_train
+    dev = torch.device("cuda:0")
+    H, P, R = 64, 32, 192
+    torch.manual_seed(0)
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).train()
+    S.perturb_parameters(m, seed=0)
+    m.H = m.W = H
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(3)
+    uv = S.pixel_grid(H, H)[torch.randperm(H * H, generator=g)[:R]].contiguous()
+    inp = S.stereo_scene(H, b=2, uv=uv, seed=5)
+    inp = {k: {kk: (vv if kk in ("cam2world", "intrinsics") else vv.to(dev)) for kk, vv in v.items()} for k, v in inp.items()}
+    z = [t.to(dev).requires_grad_(True) for t in S.feature_maps(2, 2, H, seed=1)]
+    target = (torch.rand(2, 1, R, 3, generator=g) * 2 - 1).to(dev)
+    opt = torch.optim.Adam([p for n_, p in m.named_parameters() if not n_.startswith("encoder.")] + z, lr=2e-3)
+    losses = []
+    for _ in range(6):
+        out = render_train(m, inp, z=z)
+        loss = (out["rgb"] - target).abs().mean()                 # loss_functions.image_loss
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1.0)      # training.py:130-134
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0], losses

@@ -24,6 +24,10 @@ TOL = 1e-4                   # the contract: |a-b| <= 1e-4 * max(1,|b|)
 # test_forward_host_poses_vs_reference): at most 2 % of an output's elements may exceed TOL, none by more than 5e-2.
 OUTLIER_FRAC = 2e-2
 OUTLIER_MAX = 5e-2
+# car_pose_setup's fp64 Gauss-Jordan against the fixture's matrices (the reference's fp32 LAPACK on the build host): a whole frame moves
+# 0.8-2 % of its elements by up to 1.3e-2 (profiles/round2_whole_frame_parity.md); the 48-256-ray fixtures get a margin on the fraction
+DEVICE_POSE_FRAC = 2.5e-2
+DEVICE_POSE_MAX = 2e-2
 
 HIP_CASES = list(C.CASES)
 
@@ -522,7 +526,8 @@ def test_forward_on_device_made_poses(name):
         assert torch.equal(auto[k], out[k]), k
     for k in ("rgb", "depth_ray", "at_wt"):
         e = err_stats(out[k], fx["out_" + k])
-        assert e["f1e-4"] <= 3 * OUTLIER_FRAC and e["max"] <= OUTLIER_MAX, f"device poses vs reference fixture {k}: {e}"
+        print(f"device poses vs reference fixture {name} {k}: beyond 1e-4: {e['f1e-4']:.4f}, worst {e['max']:.2e}")
+        assert e["f1e-4"] <= DEVICE_POSE_FRAC and e["max"] <= DEVICE_POSE_MAX, f"device poses vs reference fixture {k}: {e}"
     assert (np.asarray(out["valid_mask"]) == fx["out_valid_mask"]).all()
 
 

@@ -135,3 +135,59 @@ def test_average_gradients_world2():
         ret = mgr.dict()
         mp.spawn(_grad_worker, args=(world, port, ret), nprocs=world, join=True)
         assert sorted(ret.keys()) == [0, 1]
+
+
+# ---- two ranks on two GPUs over RCCL (self-skips on a one-GPU box; the driver's 8-GPU node runs it) -----------------------------
+def _rccl_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        from cross_attention_renderer_amd import synthetic as S
+        from cross_attention_renderer_amd.models import CrossAttentionRenderer
+        from cross_attention_renderer_amd.training import average_gradients
+        dev = torch.device("cuda", rank)
+        H, P = 64, 16
+        torch.manual_seed(0)
+        m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).eval()
+        S.perturb_parameters(m, seed=0)
+        m.H = m.W = H
+        m = m.to(dev)
+        inp = S.stereo_scene(H, b=1, seed=5)
+        z = [t.to(dev) for t in S.feature_maps(1, 2, H, seed=1)]
+        n_rays = inp["query"]["uv"].shape[2]
+        move = lambda d: {k: {kk: (vv if kk in ("cam2world", "intrinsics") else vv.to(dev)) for kk, vv in v.items()} for k, v in d.items()}
+        shard, (s, e) = Sh.shard_query(inp, rank, world)
+        tg = Sh.TileGather(world, e - s, Sh.TILE_CHANNELS, dev)
+        with torch.no_grad():
+            tile = Sh.pack_tile(m(move(shard), z=z))[0]
+            tg(tile)                                             # RCCL all_gather_into_tensor on the side stream ...
+            again = Sh.pack_tile(m(move(shard), z=z))[0]          # ... while this rank renders its band once more
+            banded = tg.wait().reshape(n_rays, Sh.TILE_CHANNELS)
+            whole = Sh.pack_tile(m(move(inp), z=z))[0]
+        torch.cuda.synchronize()
+        assert torch.equal(again, tile)
+        assert torch.equal(banded, whole), "two ray bands over RCCL differ from the one-GPU frame"
+        # the training loop's gradient all-reduce over RCCL (reference training.py:21-28)
+        lin = torch.nn.Linear(4, 3).to(dev)
+        lin(torch.full((2, 4), float(rank + 1), device=dev)).sum().backward()
+        mine = lin.weight.grad.clone()
+        average_gradients(lin)
+        other = torch.full((2, 4), float(2 - rank), device=dev).sum(0).expand(3, 4)
+        assert torch.allclose(lin.weight.grad, (mine + other) / 2)
+        ret[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ray_bands_and_gradient_all_reduce_over_rccl_two_gpus():
+    """Two ranks, two devices, backend "nccl" (= RCCL over xGMI): the banded render of a frame, its tiles exchanged by
+    all_gather_into_tensor on the side stream under a second render, equals the one-GPU frame bit for bit; average_gradients over RCCL."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the build box has one; the driver's multi-GPU node runs this)")
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_rccl_worker, args=(world, port, ret), nprocs=world, join=True)
+        assert sorted(ret.keys()) == [0, 1]

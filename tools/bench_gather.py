@@ -1,42 +1,69 @@
-"""Times the stand-alone epipolar gather stage (car_gather_bilinear) at the bench shape and reports its HBM roofline
-fraction: algorithmic bytes = gathered rows written (V*P*C*4 per ray) + the unique feature-map bytes."""
+"""Times the stand-alone epipolar gather stage (car_gather_bilinear: a7 + a10 of one 8192-ray chunk at the chunk's real epipolar
+sample positions, as bench.py's ``gather_stage`` does) for the (rows per group, items in flight) configurations of the development
+build (tools/build_dev.py: ``car_gather_bilinear_cfg``), and reports the HBM roofline fraction: algorithmic bytes = both gathered
+tensors written + the pyramid once.
+Usage (GPU box): python tools/bench_gather.py [cfg ...]"""
+import ctypes
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
+
+import bench  # noqa: E402
+from build_dev import build_dev  # noqa: E402
+from cross_attention_renderer_amd import _lib  # noqa: E402
+from cross_attention_renderer_amd.engine import RenderEngine  # noqa: E402
+
+CFG = {0: "16 rows, 3 items (product)", 1: "32 rows, 3 items", 2: "64 rows, 3 items", 3: "16 rows, 4 items", 4: "32 rows, 4 items",
+       5: "64 rows, 4 items", 6: "64 rows, 6 items"}
 
 
 def main():
-    import __graft_entry__ as ge
-    ge.build()
-    from cross_attention_renderer_amd import synthetic as S
-    from cross_attention_renderer_amd.engine import RenderEngine
+    dev_lib = ctypes.CDLL(build_dev())
+    fn = dev_lib.car_gather_bilinear_cfg
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int] + _lib.SIGNATURES["car_gather_bilinear"][1]
     dev = torch.device("cuda:0")
-    H, P, R, V = 256, 64, 8192, 2
-    eng = RenderEngine.__new__(RenderEngine)
-    from cross_attention_renderer_amd import _lib
-    eng.lib = _lib.load()
-    maps = [t.permute(0, 2, 3, 1).contiguous().to(dev) for t in S.feature_maps(1, V, H, seed=1)]
-    C = sum(m.shape[3] for m in maps)
-    g = torch.Generator().manual_seed(0)
-    # points along random segments inside the image, like epipolar samples
-    a = torch.rand(V, R, 1, 2, generator=g) * 2 - 1
-    b = torch.rand(V, R, 1, 2, generator=g) * 2 - 1
-    grid = (a + (b - a) * torch.linspace(0, 1, P)[None, None, :, None]).reshape(V, R * P, 2).contiguous().to(dev)
+    model = bench.build_model(dev)
+    eng = model._engine = RenderEngine(model)
+    inp, z = bench.make_frame(0.5, dev)
+    R, P, V = 8192, bench.P, bench.V
+    maps = eng._channel_last(z)
+    C = sum(t.shape[3] for t in maps)
+    sub = {"context": inp["context"], "query": dict(inp["query"], uv=inp["query"]["uv"][:, :, 96 * 256:96 * 256 + R].contiguous())}
+    with torch.no_grad():
+        grid = model(sub, z=z)["pixel_val"].reshape(V, R * P, 2).contiguous()
     out = torch.empty(V * R * P, C, device=dev)
-    for mode, name in ((0, "border"), (1, "zeros")):
-        for _ in range(2):
-            eng.gather(maps, grid, R * P, mode, 0, V, out, C, 0, run=P)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
-        for s, e in ev:
-            s.record(); eng.gather(maps, grid, R * P, mode, 0, V, out, C, 0, run=P); e.record()
+    L = len(maps)
+    ptrs = (ctypes.c_void_p * L)(*[m.data_ptr() for m in maps])
+    cs = (ctypes.c_int * L)(*[m.shape[3] for m in maps])
+    hs = (ctypes.c_int * L)(*[m.shape[1] for m in maps])
+    ws = (ctypes.c_int * L)(*[m.shape[2] for m in maps])
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nbytes = 2 * out.numel() * 4 + sum(t.numel() * 4 for t in maps)
+    ref = None
+    for cfg in [int(a) for a in sys.argv[1:]] or sorted(CFG):
+        ev = []
+        for _ in range(9):
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for mode in (0, 1):
+                rc = fn(cfg, ptrs, cs, hs, ws, L, V, grid.data_ptr(), R * P, P, mode, 0, V, out.data_ptr(), C, 0, st)
+                assert rc == 0
+            b_.record()
+            ev.append((a, b_))
         torch.cuda.synchronize()
-        ms = sorted(s.elapsed_time(e) for s, e in ev)[5]
-        nbytes = out.numel() * 4 + sum(m.numel() * 4 for m in maps)
-        print(f"gather {name}: {ms:.3f} ms per launch, {nbytes / 1e9:.3f} GB algorithmic -> {nbytes / ms / 1e9:.2f} TB/s = "
-              f"{nbytes / ms / 1e9 / 8.0 * 100:.1f} % of the 8 TB/s HBM3E peak")
+        ms = sorted(a.elapsed_time(b_) for a, b_ in ev[2:])[3]
+        same = ""
+        if ref is None:
+            ref = out.clone()
+        else:
+            same = f"  equal to cfg 0: {torch.equal(ref, out)}"
+        print(f"cfg {cfg} ({CFG[cfg]}): {ms:.3f} ms for a7 + a10, {nbytes / 1e9:.3f} GB -> {nbytes / ms / 1e9:.2f} TB/s = {nbytes / ms / 1e9 / 8.0 * 100:.1f} % of 8 TB/s{same}",
+              flush=True)
 
 
 if __name__ == "__main__":

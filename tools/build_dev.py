@@ -16,16 +16,20 @@ def build_dev() -> str:
     import __graft_entry__ as ge
     ge.build()
     os.makedirs(DEV_DIR, exist_ok=True)
-    obj = os.path.join(DEV_DIR, "car_fused_dev.o")
-    src = os.path.join(ge.CSRC, "car_fused.hip")
-    deps = [src] + [os.path.join(ge.CSRC, f) for f in os.listdir(ge.CSRC) if f.endswith(".h")]
     extra = os.environ.get("CAR_DEV_FLAGS", "").split()
     stamp = os.path.join(DEV_DIR, "flags.txt")
-    if ge._stale(obj, deps) or not os.path.exists(stamp) or open(stamp).read() != " ".join(extra):
-        subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCAR_ABLATION", *extra, "-c", src, "-o", obj,
-                               "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS["car_fused.hip"]])
-        open(stamp, "w").write(" ".join(extra))
-    objs = [os.path.join(ge.CSRC, "_obj", u.replace(".hip", ".o")) for u in ge.UNITS if u != "car_fused.hip"] + [obj]
+    fresh = os.path.exists(stamp) and open(stamp).read() == " ".join(extra)
+    headers = [os.path.join(ge.CSRC, f) for f in os.listdir(ge.CSRC) if f.endswith(".h")]
+    dev_units = ("car_fused.hip", "car_gather.hip")            # the units that carry -DCAR_ABLATION variants
+    objs = [os.path.join(ge.CSRC, "_obj", u.replace(".hip", ".o")) for u in ge.UNITS if u not in dev_units]
+    for unit in dev_units:
+        obj = os.path.join(DEV_DIR, unit.replace(".hip", "_dev.o"))
+        src = os.path.join(ge.CSRC, unit)
+        if ge._stale(obj, [src] + headers) or not fresh:
+            subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCAR_ABLATION", *extra, "-c", src, "-o", obj,
+                                   "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS[unit]])
+        objs.append(obj)
+    open(stamp, "w").write(" ".join(extra))
     if ge._stale(DEV_LIB, objs):
         subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", DEV_LIB, *objs])
     return DEV_LIB
