@@ -91,7 +91,10 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
 #pragma unroll
             for (int j = 0; j < kMaxSeg; ++j) {
                 if (j < nseg) {
-                    const float4 x = *reinterpret_cast<const float4*>(rowp + 64 * j);
+                    // streamed once per round (19 GB per frame): non-temporal, so the rows do not displace what the next kernel reads
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    const f32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rowp + 64 * j));
+                    const float4 x = make_float4(xv[0], xv[1], xv[2], xv[3]);
                     part[j].x = fmaf(w, x.x, part[j].x); part[j].y = fmaf(w, x.y, part[j].y);
                     part[j].z = fmaf(w, x.z, part[j].z); part[j].w = fmaf(w, x.w, part[j].w);
                 }

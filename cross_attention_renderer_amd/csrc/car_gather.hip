@@ -18,7 +18,8 @@ struct GatherLevels {
     int n_levels;
 };
 
-constexpr int kGatherCfg = 1;       // (rows per group, items in flight) of the product = (32, 3): see launch_gather (tools/bench_gather.py: 52 % of the HBM peak vs 50 % for (16, 3), 46 % for (64, 3), 41-52 % with four items)
+constexpr int kGatherWave = 7;      // launch_gather: the wave-task kernel (falls back to (32, 3) for channel counts it does not cover)
+constexpr int kGatherCfg = kGatherWave;    // the product's configuration (tools/bench_gather.py: wave-tasks 55-65 % of the HBM peak, (32 rows, 3 items) 52-54 %, (16, 3) 49-50 %)
 
 // A workgroup handles kGRows sampled points at a time: the bilinear tap indices / weights are computed once per (point,
 // level) into LDS, then every thread moves float4s: 4 tap reads (L1 / L2 resident maps), one 16-byte store, kItems items
@@ -114,6 +115,91 @@ __global__ void __launch_bounds__(256) gather_kernel(GatherLevels L, int n_maps,
     }
 }
 
+// ---- the same stage with wave-uniform bookkeeping: a wave-instruction covers whole rows of one level (lanes = rows x channel quads of
+//      that level: 1 row of a 256-channel level, 4 rows of a 64-channel one), so the level, the tap tables' rows and the output
+//      window are found once per wave-task with scalar arithmetic instead of a division and a level search per float4.  Needs
+//      every level's quad count to be a power of two (<= 64 lanes per row, or a multiple of 64).  Same arithmetic, same results. ----
+constexpr int kWRows = 32;          // rows per work group
+
+struct WaveLevels { int lpr[CAR_MAX_LEVELS], rpt[CAR_MAX_LEVELS], lpr_shift[CAR_MAX_LEVELS], seg_shift[CAR_MAX_LEVELS], tasks[CAR_MAX_LEVELS + 1]; };   // lanes per row, rows per task (powers of two)
+
+__global__ void __launch_bounds__(256) gather_wave_kernel(GatherLevels L, WaveLevels WL, int n_maps, const float* __restrict__ grid, long pts, int run,
+                                                          int mode, int place, int V, float* __restrict__ out, int ld_out, int col_out) {
+    __shared__ __attribute__((aligned(16))) int s_idx[kWRows][CAR_MAX_LEVELS][4];
+    __shared__ __attribute__((aligned(16))) float s_w[kWRows][CAR_MAX_LEVELS][4];
+    __shared__ long s_row[kWRows];                                    // output row, -1 for a row past the end
+    const long total_rows = (long)n_maps * pts;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long rays = pts / run, rblocks = (rays + kWRows - 1) / kWRows;
+    const long groups = run > 1 ? (long)n_maps * rblocks * run : (total_rows + kWRows - 1) / kWRows;
+    const int n_tasks = WL.tasks[L.n_levels];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    for (long gidx = blockIdx.x; gidx < groups; gidx += gridDim.x) {
+        for (int job = tid; job < kWRows * L.n_levels; job += 256) {
+            const int rl = job / L.n_levels, l = job % L.n_levels;
+            long mp;
+            bool live_row;
+            if (run > 1) {
+                const long p = gidx % run, rb = (gidx / run) % rblocks, mm = gidx / (run * rblocks);
+                long ray = rb * kWRows + rl;
+                live_row = ray < rays;
+                if (!live_row) ray = rays - 1;
+                mp = mm * pts + ray * run + p;
+            } else {
+                mp = gidx * kWRows + rl;
+                live_row = mp < total_rows;
+                if (!live_row) mp = total_rows - 1;
+            }
+            const int m = (int)(mp / pts);
+            int tidx[4];
+            float tw[4];
+            car_bilinear_taps(grid[2 * mp], grid[2 * mp + 1], L.w[l], L.h[l], mode, tidx, tw);
+            for (int t = 0; t < 4; ++t) { s_idx[rl][l][t] = m * L.h[l] * L.w[l] + tidx[t]; s_w[rl][l][t] = tw[t]; }
+            if (l == 0) {
+                const long i = mp % pts;
+                long row;
+                if (place == CAR_PLACE_PLAIN) row = mp;
+                else if (place == CAR_PLACE_OWN) row = mp * V + (m % V);
+                else { const int sc = m / 2, s = m % 2; row = (((long)(sc * 2 + (1 - s))) * pts + i) * 2 + s; }
+                s_row[rl] = live_row ? row : -1;
+            }
+        }
+        __syncthreads();
+        // wave-tasks of this group, three at a time (12 tap loads in flight per lane)
+        for (int t0 = wave; t0 < n_tasks; t0 += 12) {
+            f32x4 tp[3][4];
+            float4 wv[3];
+            float* dst[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int task = t0 + 4 * u < n_tasks ? t0 + 4 * u : t0;      // clamp: harmless duplicate read, store masked
+                int l = 0;
+                while (l + 1 < L.n_levels && task >= WL.tasks[l + 1]) ++l;    // scalar: the task index is wave-uniform
+                const int tl = task - WL.tasks[l], seg = tl & ((1 << WL.seg_shift[l]) - 1), rb = tl >> WL.seg_shift[l];
+                const int r = rb * WL.rpt[l] + (lane >> WL.lpr_shift[l]), q = seg * WL.lpr[l] + (lane & (WL.lpr[l] - 1));
+                const int4 id = *reinterpret_cast<const int4*>(&s_idx[r][l][0]);
+                wv[u] = *reinterpret_cast<const float4*>(&s_w[r][l][0]);
+                const float* base = L.map[l] + 4 * q;
+                const long cl = L.c[l];
+                tp[u][0] = *reinterpret_cast<const f32x4*>(base + (long)id.x * cl);
+                tp[u][1] = *reinterpret_cast<const f32x4*>(base + (long)id.y * cl);
+                tp[u][2] = *reinterpret_cast<const f32x4*>(base + (long)id.z * cl);
+                tp[u][3] = *reinterpret_cast<const f32x4*>(base + (long)id.w * cl);
+                const long orow = s_row[r];
+                dst[u] = (orow >= 0 && t0 + 4 * u < n_tasks) ? out + orow * ld_out + col_out + 4 * (L.q0[l] + q) : nullptr;
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                if (!dst[u]) continue;
+                f32x4 r;    // ((nw + ne) + sw) + se, products rounded individually (ATen's vectorised CPU kernel order)
+                r = ((tp[u][0] * wv[u].x + tp[u][1] * wv[u].y) + tp[u][2] * wv[u].z) + tp[u][3] * wv[u].w;
+                __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(dst[u]));
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 int launch_gather(int cfg, const GatherLevels& L, int n_maps, const float* grid, long pts, int run, int mode, int place, int V, float* out,
@@ -178,6 +264,35 @@ int launch_cfg(const GatherLevels& L, int n_maps, const float* grid, long pts, i
 
 int launch_gather(int cfg, const GatherLevels& L, int n_maps, const float* grid, long pts, int run, int mode, int place, int V, float* out,
                   int ld_out, int col_out, void* stream) {
+    if (cfg == kGatherWave) {
+        WaveLevels WL;
+        bool ok = true;
+        int tasks = 0;
+        for (int l = 0; l < L.n_levels; ++l) {
+            const int quads = L.c[l] / 4;
+            ok = ok && quads > 0 && (quads & (quads - 1)) == 0 && (quads <= 64 || quads % 64 == 0);
+            WL.lpr[l] = quads < 64 ? quads : 64;
+            WL.rpt[l] = 64 / WL.lpr[l];
+            const int segs = quads / WL.lpr[l];
+            WL.lpr_shift[l] = WL.seg_shift[l] = 0;
+            while ((1 << WL.lpr_shift[l]) < WL.lpr[l]) ++WL.lpr_shift[l];
+            while ((1 << WL.seg_shift[l]) < segs) ++WL.seg_shift[l];
+            WL.tasks[l] = tasks;
+            tasks += (kWRows / WL.rpt[l]) * segs;
+        }
+        for (int l = L.n_levels; l <= CAR_MAX_LEVELS; ++l) WL.tasks[l] = tasks;
+        for (int l = L.n_levels; l < CAR_MAX_LEVELS; ++l) { WL.lpr[l] = WL.rpt[l] = 1; WL.lpr_shift[l] = WL.seg_shift[l] = 0; }
+        if (ok) {
+            const long groups = run > 1 ? (long)n_maps * ((pts / run + kWRows - 1) / kWRows) * run : ((long)n_maps * pts + kWRows - 1) / kWRows;
+            const unsigned blocks = (unsigned)(groups < 65536 ? groups : 65536);
+            (void)hipGetLastError();
+            hipLaunchKernelGGL(gather_wave_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, L, WL, n_maps, grid, pts, run, mode, place, V,
+                               out, ld_out, col_out);
+            CAR_CHECK_LAUNCH("car_gather_bilinear");
+            return CAR_OK;
+        }
+        cfg = 1;                                                       // odd channel counts: the per-float4 kernel
+    }
     switch (cfg) {
         case 1: return launch_cfg<32, 3>(L, n_maps, grid, pts, run, mode, place, V, out, ld_out, col_out, stream);
         case 2: return launch_cfg<64, 3>(L, n_maps, grid, pts, run, mode, place, V, out, ld_out, col_out, stream);

@@ -18,7 +18,7 @@ from cross_attention_renderer_amd import _lib  # noqa: E402
 from cross_attention_renderer_amd.engine import RenderEngine  # noqa: E402
 
 CFG = {0: "16 rows, 3 items (product)", 1: "32 rows, 3 items", 2: "64 rows, 3 items", 3: "16 rows, 4 items", 4: "32 rows, 4 items",
-       5: "64 rows, 4 items", 6: "64 rows, 6 items"}
+       5: "64 rows, 4 items", 6: "64 rows, 6 items", 7: "wave-tasks: 32 rows, a wave-instruction = whole rows of one level"}
 
 
 def main():
