@@ -156,7 +156,7 @@ def gather_stage(model, inp, z, rays: int = CHUNK):
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b_) for a, b_ in ev[2:])[2]
     nbytes = 2 * out.numel() * 4 + sum(t.numel() * 4 for t in maps)
-    return {"kernel": "gather_kernel (car_gather_bilinear), a7 + a10 of one 8192-ray chunk", "bound": "hbm",
+    return {"kernel": "gather_wave_kernel (car_gather_bilinear), a7 + a10 of one 8192-ray chunk", "bound": "hbm",
             "algorithmic_bytes": nbytes, "ms": ms, "achieved": nbytes / (ms * 1e-3) / 1e12, "peak": HBM_PEAK / 1e12, "unit": "TB/s",
             "frac": nbytes / (ms * 1e-3) / HBM_PEAK,
             "note": "stand-alone stage only: the product path fuses the gather into the per-sample kernel and writes no gathered features"}
@@ -292,7 +292,7 @@ def main():
                     pmc[k] = pmc[k] * part
             if part != 1.0 and pmc.get("source"):
                 pmc["source"] += f", scaled by {part:g} to this launch's share of the frame"
-            roof = {"bound": pmc.get("bound", "ta/l1"), "kernel": f"fused_kernel on {int(samples)} samples (geometry, 8-tap gather of the projected maps (finest level + merged lattice), e, key, qry, logits; "
+            roof = {"bound": pmc.get("bound", "ta/l1"), "kernel": f"fused_kernel on {int(samples)} samples (geometry, 4-tap gather of the per-texel-projected pyramid on its lattice, e, key, qry, logits; "
                                                                   "f16 matrix pipe, fp16 hi/lo split x3)",
                     "achieved": flop / mean / 1e12, "peak": F16_MFMA_PEAK / 3 / 1e12, "unit": "TFLOP/s", "frac": flop / mean / (F16_MFMA_PEAK / 3),
                     "peak_note": "dense f16 MFMA peak 2500 / 3 products per fp32 term; the kernel is bound by the texture-address / L1 path "
@@ -326,7 +326,8 @@ def main():
             "config": {"workload": f"256x256 query frame, 64 samples/view, 2 context views (config 2), a new query pose every step (cameras on the {args.cameras}), "
                                    f"{-(-R // args.chunk_rays)} forward call(s) x {min(args.chunk_rays, R)} rays per rank",
                        "rays_per_step": R_frame, "rays_per_step_per_gpu": R,
-                       "parallelism": "one GPU" if world == 1 else f"one frame's rays banded over {world} ranks, RCCL all-gather of tiles"},
+                       "parallelism": "one GPU" if world == 1 else f"one frame's rays banded over {world} ranks, all-gather of tiles over {'RCCL' if args.backend == 'nccl' else args.backend}"
+                                                                      + (f" (all ranks on device {args.device}: a dry run of the code path, no scaling figure)" if args.device is not None else "")},
             "stage_ms": {k: sum(v) / len(v) for k, v in by_stage.items()},
             "stage_ms_per_rank": rank_stages,
             "roofline": roof,

@@ -16,6 +16,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 constexpr int kD = 128, kNT = 4, kTile = 1024, kChunks = 4;
@@ -68,7 +69,10 @@ __global__ void __launch_bounds__(512) round2_kernel(const float* __restrict__ g
         for (int it = 0; it < 4; ++it) {
             const long row = row0 + r8 + 8 * it < S ? row0 + r8 + 8 * it : S - 1;
 #pragma unroll
-            for (int c = 0; c < kChunks; ++c) qs[c][it] = *reinterpret_cast<const float4*>(qry + row * kD + 32 * c + 4 * qd);
+            for (int c = 0; c < kChunks; ++c) {                      // read once: non-temporal
+                const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(qry + row * kD + 32 * c + 4 * qd));
+                qs[c][it] = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
         // this lane's sample: its g half (B operand of the first layer) and the row of uh its ray owns
         const long srow = row0 + s < S ? row0 + s : S - 1;
