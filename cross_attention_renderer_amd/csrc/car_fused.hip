@@ -97,7 +97,8 @@ __device__ __forceinline__ NextChunk next_chunk_w2(const float* __restrict__ blo
 // 1 no tap loads, 2 no gather work, 3 = 2 + no weight DMA / barriers, 5 no e-path MFMAs, weight DMA or barriers in the two source
 // passes (the gather + the key / query layers); 11 the full kernel without the barrier of the weight stream (racy);
 // 12 = 3 + no A-operand reads from LDS (matrix pipe + VALU only); 13 the full kernel without the A-operand reads;
-// 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val)
+// 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val);
+// 20: the full kernel with shader-clock sums per piece of the chunk loop (where a wave waits inside a chunk)
 template <int ABL>
 __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f), tanhf(py / 5.0f), tanhf(pz / 5.0f), 0.0f);
         }
         if (g_live) {
-            if constexpr (ABL != 4) { a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1]; }
+            if constexpr (ABL != 4 && ABL != 20) { a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1]; }
             a.pt[3 * gi + 0] = smp.pt[0]; a.pt[3 * gi + 1] = smp.pt[1]; a.pt[3 * gi + 2] = smp.pt[2];
         }
         float* gl = lds + kLdsG + sg * 16;
@@ -276,6 +277,10 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     issue_row(bufA, 0, 1, 0);                                          // pipeline prologue: chunk (0, 1), both row groups
     issue_row(bufB, 0, 1, 1);
 
+    // ABL 20 (development build): shader-clock time the wave spends, per piece of the chunk loop, summed over the source passes and
+    // written over pixel_val (tools/bench_fused.py 20); in every other variant tick() is 0 and all of this folds away
+    long long t_blend = 0, t_dma = 0, t_bar = 0, t_chunks = 0, t_issue = 0, t_piece = 0, t_aff = 0, t_mfma = 0;
+    auto tick = [&]() -> long long { if constexpr (ABL == 20) return (long long)__builtin_amdgcn_s_memtime(); else return 0; };
     f32x4 acc[kTE];
     float m0 = 0.0f;                                                   // largest |e_0| of this lane's sample
     half8 bhi, blo;
@@ -296,20 +301,27 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             // 9 slots of (4 ds_read_b128 + 6 MFMAs of 16 cycles); between them one piece of the gather / DMA issue: slots 0-2 carry the
             // DMA pieces, slot 0 the affine start values, slots 3 and 6 one row group each — blend, store the h rows, re-issue.
             auto piece = [&](int qs) {
-                if (qs < kPieces) stream_issue_piece<ABL>(nx, qs, lane, wave);
-                if (qs == 0) { affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); }
-                else if (qs == 3) { blend_row(bufA, nsv, 0); finish_row(0); issue_row(bufA, n2sv, n2c, 0); }
-                else if (qs == 6) { blend_row(bufB, nsv, 1); finish_row(1); issue_row(bufB, n2sv, n2c, 1); }
+                if (qs < kPieces) { const long long t0 = tick(); stream_issue_piece<ABL>(nx, qs, lane, wave); t_piece += tick() - t0; }
+                if (qs == 0) { const long long t0 = tick(); affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); t_aff += tick() - t0; }
+                else if (qs == 3) { const long long t0 = tick(); blend_row(bufA, nsv, 0); const long long t1 = tick(); finish_row(0); issue_row(bufA, n2sv, n2c, 0); t_blend += t1 - t0; t_issue += tick() - t1; }
+                else if (qs == 6) { const long long t0 = tick(); blend_row(bufB, nsv, 1); const long long t1 = tick(); finish_row(1); issue_row(bufB, n2sv, n2c, 1); t_blend += t1 - t0; t_issue += tick() - t1; }
             };
 #pragma unroll
             for (int qs = 0; qs < kTE / 2; ++qs) {
                 const float* w0 = wl + (2 * qs * 2) * 256;
-                if constexpr (ABL != 5) mfma_pair<ABL>(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
+                { const long long t0 = tick(); if constexpr (ABL != 5) mfma_pair<ABL>(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo); t_mfma += tick() - t0; }
                 piece(qs);
                 __builtin_amdgcn_sched_barrier(0);
             }
             read_b(bhi, blo);                                          // next chunk's B operand (own LDS tile, in-order LDS)
             // the 8 tap loads issued in slots 3 and 6 stay in flight over the barrier (they are younger than every DMA piece)
+            if constexpr (ABL == 20) {
+                const long long t0 = tick();
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                const long long t1 = tick();
+                __syncthreads();
+                t_dma += t1 - t0; t_bar += tick() - t1; t_chunks += 1;
+            } else
             stream_sync<ABL, kTapsLive ? 8 : 0>();
             ++g;
         }
@@ -391,6 +403,12 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         if (q4 == 0) a.logit[i] = dot / 16.0f;
     }
     mark(6);
+    if constexpr (ABL == 20) {
+        if (lane == 0) {
+            long long* out = reinterpret_cast<long long*>(a.pixel_val) + ((long)blk * kWaves + wave) * 8;
+            out[0] = t_blend; out[1] = t_dma; out[2] = t_bar; out[3] = t_chunks; out[4] = t_issue; out[5] = t_piece; out[6] = t_aff; out[7] = t_mfma;
+        }
+    }
     if constexpr (ABL == 4) {
         if (tid == 0) {
             long long* out = reinterpret_cast<long long*>(a.pixel_val) + (long)blk * 16;
@@ -426,7 +444,7 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     switch (abl) {
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 4: kern = fused_kernel<4>; break;   case 5: kern = fused_kernel<5>; break;   case 11: kern = fused_kernel<11>; break;
-        case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;
+        case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;   case 20: kern = fused_kernel<20>; break;
         default: break;
     }
 #else

@@ -1,10 +1,9 @@
 """Times the fused per-sample kernel (csrc/car_fused.hip) alone on one 8192-ray chunk of the bench frame (256x256x64), for the
 product kernel (variant 0) and the timing-only ablation variants of the development build (tools/build_dev.py; results of
 variants > 0 are wrong by construction):
-  1 no tap loads | 2 no gather work | 3 = 2 + no weight DMA / barriers | 5 the gather alone
-  14 four taps per sample and source from a full three-level lattice (521 x 521 nodes, random contents)
-  texture-address probes on top of 5:  6 odd rows masked off | 7 odd channel quads masked off | 8 lanes in the MFMA's B-operand
-  order | 9 no level-0 taps | 10 level-2 taps only in the first two chunks
+  1 no tap loads | 2 no gather work | 3 = 2 + no weight DMA / barriers | 5 the source passes without their matrix work | 4 phase stamps | 20 where a wave waits inside a chunk
+  11 no chunk barrier (racy) | 12 = 3 + no A-operand reads | 13 no A-operand reads | 100 the PRODUCT library's kernel, timed the same way
+(earlier rounds' probes — masked lanes, tap orders, deep tap rings, the full-lattice timing probe — are recorded in profiles/)
 Usage (GPU box): python tools/bench_fused.py [variants...]"""
 import ctypes
 import os
@@ -106,6 +105,13 @@ def main():
                 x = (st8[:, seq[j + 1]] - st8[:, seq[j]]).mean().item()
                 print(f"   {n_:38s} {x:10.0f}  {100 * x / tot:5.1f} %")
             print(f"   total {tot:.0f} ticks")
+        if v == 20:
+            w8 = pixel_val.view(torch.int64)[: (2 * R * bench.P // 192) * 12 * 8].view(-1, 8).cpu().double()
+            n = w8[:, 3].mean().item()
+            m = lambda k: w8[:, k].mean().item() / n
+            print(f"source passes, per wave and chunk (mean over {w8.shape[0]} waves, {n:.0f} chunks each; s_memtime ticks): "
+                  f"9 x (A-operand reads + 6 MFMAs issued) {m(7):.0f}, DMA pieces {m(5):.0f}, affine {m(6):.0f}, blends incl. the wait for their taps {m(0):.0f}, "
+                  f"h rows stored + tap loads issued {m(4):.0f}, chunk-end wait for the weight DMA {m(1):.0f}, barrier {m(2):.0f}")
         if v in (0, 100):                                  # keep the results: the development kernel must equal the product's bit for bit
             outs[v] = [torch.empty(cnt_, device=dev).copy_(eng._work[o_:o_ + cnt_]) for o_, cnt_ in
                        [(lambda n_: (lib.car_workspace_find(ctypes.byref(d), n_.encode(), ctypes.byref(off), ctypes.byref(cnt)), (off.value, cnt.value))[1])(n_)
