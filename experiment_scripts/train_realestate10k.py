@@ -1,0 +1,97 @@
+"""Training entry point (mirrors reference experiment_scripts/train_realestate10k.py + training.py:46-246).
+
+    python experiment_scripts/train_realestate10k.py --experiment_name demo --views 2 --batch_size 12 --synthetic [--gpus N] [--max_steps K]
+
+The reference's loop, with ``training.render_train`` (HIP forward + HIP backward, csrc/car_backward.hip) in the place of
+``model(model_input)``: Adam(lr, betas=(0.99, 0.999)) (train_realestate10k.py:93), 192 random query rays per scene (query_sparsity,
+train_realestate10k.py:78), L1 image loss (loss_functions.image_loss; --depth adds the depth-variance term, loss_functions.py:112-127),
+gradient clipping at norm 1 (training.py:130-134), parameters broadcast from rank 0 and gradients all-reduced when --gpus > 1
+(train_realestate10k.py:60-62, training.py:21-28: one process per GPU over RCCL), checkpoints ``{'model', 'optimizer'}`` as
+``checkpoints/model_current.pth`` / ``model_final.pth`` (training.py:82-84, 244-246) that the eval / render scripts load.
+
+Data: the RealEstate10K training set and its augmenting reader are not available offline, so scenes are synthetic (--synthetic, the
+default here: seeded stereo pairs with a smooth random target image per scene; every step draws new rays).  The encoder trains when the
+model is built with it (--with_encoder: the pyramid then comes from ``get_z`` under autograd); otherwise the pyramid itself is a leaf
+that receives gradients, standing in for the encoder's output.  LPIPS (--lpips) needs the lpips package, which is not installed."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import common  # noqa: E402
+
+
+def _parser():
+    p = common.parser(__doc__)
+    p.add_argument("--lr", type=float, default=5e-5)
+    p.add_argument("--l2_coeff", type=float, default=0.05)
+    p.add_argument("--depth", action="store_true", default=False)
+    p.add_argument("--lpips", action="store_true", default=False)
+    p.add_argument("--max_steps", type=int, default=20)
+    p.add_argument("--steps_til_summary", type=int, default=10)
+    p.add_argument("--query_sparsity", type=int, default=192)
+    p.set_defaults(batch_size=12, synthetic=True)
+    return p
+
+
+def train(rank, opt):
+    import torch
+    import torch.distributed as dist
+    from cross_attention_renderer_amd import harness, synthetic
+    from cross_attention_renderer_amd.training import average_gradients, render_train
+    if opt.lpips:
+        raise SystemExit("--lpips needs the lpips package (not installed here)")
+    dev = common.init_rank(rank, opt)
+    H, b, R = opt.img_sidelength, opt.batch_size, opt.query_sparsity
+    model = common.build_model(opt, dev).train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    if opt.gpus > 1:                                              # sync_model (train_realestate10k.py:60-62)
+        for p in params:
+            dist.broadcast(p.data, 0)
+    g = torch.Generator().manual_seed(1234 + rank)                 # every rank shuffles on its own (train_realestate10k.py:80-81)
+    base = synthetic.stereo_scene(H, b=b, seed=5 + rank, n_view=opt.views)
+    z = None
+    leaves = list(params)
+    if model.encoder.__class__.__name__ == "EncoderNotBuilt":
+        z = [t.to(dev).requires_grad_(True) for t in synthetic.feature_maps(b, opt.views, H, seed=1 + rank)]
+        leaves += z
+    optimizer = torch.optim.Adam(lr=opt.lr, params=leaves, betas=(0.99, 0.999))
+    # a smooth random target image per scene: low-frequency colours of the pixel coordinates
+    coef = (torch.rand(b, 3, 4, generator=g) * 2 - 1).to(dev)
+    ckpt_dir = os.path.join(opt.logging_root, opt.experiment_name, "checkpoints")
+    if rank == 0:
+        os.makedirs(ckpt_dir, exist_ok=True)
+    grid = synthetic.pixel_grid(H, H)
+    t0, losses = time.time(), []
+    for step in range(opt.max_steps):
+        uv = torch.stack([grid[torch.randperm(H * H, generator=g)[:R]] for _ in range(b)])[:, None]       # (b, 1, R, 2)
+        inp = {"context": base["context"], "query": dict(base["query"], uv=uv)}
+        inp = harness.to_device(inp, dev, opt.cameras)
+        u = inp["query"]["uv"][:, 0] / (H - 1) * 3.14159
+        feats = torch.stack([torch.sin(u[..., 0]), torch.cos(u[..., 1]), torch.sin(u[..., 0] + u[..., 1]), torch.ones_like(u[..., 0])], dim=-1)
+        gt_rgb = torch.tanh(torch.einsum("brk,bck->brc", feats, coef))[:, None]                             # (b, 1, R, 3)
+        out = render_train(model, inp, z=z)
+        loss = (gt_rgb - out["rgb"]).abs().mean()                                                           # loss_functions.image_loss
+        if opt.depth:                                                                                       # loss_functions.py:112-127
+            d = out["depth_ray"][..., 0]
+            loss = loss + (opt.l2_coeff * (d - d.mean(dim=-1, keepdim=True)) ** 2).mean()
+        optimizer.zero_grad()
+        loss.backward()
+        if opt.gpus > 1:
+            average_gradients(model)                              # the stand-in pyramid, if any, is per rank: not reduced
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+        optimizer.step()
+        losses.append(loss.item())
+        if rank == 0 and (step % opt.steps_til_summary == 0 or step == opt.max_steps - 1):
+            print(f"step {step}: loss {losses[-1]:.5f}  ({(time.time() - t0) / (step + 1) * 1e3:.1f} ms/step, {b} scenes x {R} rays)", flush=True)
+            torch.save({"model": model.state_dict(), "optimizer": optimizer.state_dict()}, os.path.join(ckpt_dir, "model_current.pth"))
+    if rank == 0:
+        torch.save({"model": model.state_dict(), "optimizer": optimizer.state_dict()}, os.path.join(ckpt_dir, "model_final.pth"))
+        print(f"trained {opt.max_steps} steps: loss {losses[0]:.5f} -> {losses[-1]:.5f}; wrote {os.path.join(ckpt_dir, 'model_final.pth')}")
+    if opt.gpus > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    opt = _parser().parse_args()
+    common.spawn(train, opt)
