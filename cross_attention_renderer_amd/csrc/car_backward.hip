@@ -21,72 +21,135 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// dW[n][k] += sum_m dY[m][n] X[m][k]  (k == K: the bias column, X = 1).  A wave owns a 64 x 128 tile of dW (2 x 4 MFMA tiles of
-// 32 x 32) over a slab of rows: D += A B with A = dY^T (32 outputs x 2 rows), B = X (2 rows x 32 inputs), so lane l feeds
-// dY[m + l / 32][n0 + l % 32] and X[m + l / 32][k0 + l % 32]: both reads are 128 contiguous bytes per half wave.  Eight row
-// pairs are loaded ahead of their 64 MFMAs.  The tile is added to dW with fp32 atomics (slabs of different workgroups meet there).
+// dW[n][k] += sum_m dY[m][n] X[m][k]  (k == K: the bias column, X = 1) on the fp32 matrix pipe: D += A B with A = dY^T (32 outputs x 2
+// rows), B = X (2 rows x 32 inputs), lane l feeding dY[m + l / 32][n + l % 32] and X[m + l / 32][k + l % 32].  A workgroup tile is
+// staged through LDS: 4 waves as 2 x 2 over a (2 TN 32) x (2 TK 32) tile of dW, every operand element of a 16-row block loaded ONCE
+// per workgroup (float4 loads, coalesced) and read by two waves from LDS (one float per lane and MFMA operand: consecutive lanes,
+// consecutive addresses).  The next block's loads are in flight under this block's MFMAs (registers -> the other LDS buffer).  The
+// tile is added to dW with fp32 atomics (the row slabs of different workgroups meet there).  <3, 5>: a 192 x 320 tile, 240 accumulator
+// registers per wave, for the wide layers (a 64 x 128 tile per wave, the first version, re-read the first point-MLP layer's operands
+// 8352 floats per row = 19.7 GB per launch; 2320 here); <2, 2>: 128 x 128 for the 128-wide layers.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kWgTN = 2, kWgTK = 4, kWgUnroll = 8;
+constexpr int kWtRows = 16;           // rows per staged block (8 MFMA row pairs)
 
-__global__ void __launch_bounds__(256) wgrad_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, long M, int N,
-                                                    int K, int relu_x, int slab_rows, float* __restrict__ dW, int lddw, float* __restrict__ db) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n0 = blockIdx.x * (32 * kWgTN), k0 = blockIdx.y * (32 * kWgTK);
-    const int Kb = db ? K + 1 : K;                                    // the bias rides as column K
-    const long m_begin = ((long)blockIdx.z * 4 + wave) * slab_rows;
+template <int TN, int TK>
+__global__ void __launch_bounds__(256) wgrad_tile_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, long M, int N,
+                                                         int K, int relu_x, long slab_rows, float* __restrict__ dW, int lddw, float* __restrict__ db) {
+    constexpr int WN = 2 * TN * 32, WK = 2 * TK * 32;                 // workgroup tile
+    constexpr int kA4 = kWtRows * WN / 4, kB4 = kWtRows * WK / 4;     // float4s per block
+    constexpr int kPer = (kA4 + kB4 + 255) / 256;                     // float4s per thread and block
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [2][rows][WN] then [2][rows][WK]
+    float* la = lds;
+    float* lb = lds + 2 * kWtRows * WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int n0 = blockIdx.x * WN, k0 = blockIdx.y * WK;
+    const int Kb = db ? K + 1 : K;
+    const long m_begin = (long)blockIdx.z * slab_rows;
     const long m_end = m_begin + slab_rows < M ? m_begin + slab_rows : M;
-    f32x16 acc[kWgTN][kWgTK];
+    f32x16 acc[TN][TK];
 #pragma unroll
-    for (int i = 0; i < kWgTN; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < kWgTK; ++j)
+        for (int j = 0; j < TK; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    const int half = lane >> 5, col = lane & 31;
-    for (long m = m_begin; m < m_end; m += 2 * kWgUnroll) {
-        float a[kWgUnroll][kWgTN], bq[kWgUnroll][kWgTK];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 stage[kPer];
+    // float4 f of a block: the first kA4 belong to dY (row f / (WN / 4), columns 4 (f % (WN / 4)) ...), the rest to X
+    auto fetch = [&](long m) {
 #pragma unroll
-        for (int u = 0; u < kWgUnroll; ++u) {
-            const long row = m + 2 * u + half;
-            const bool on = row < m_end;
-            const long rr = on ? row : m_begin;
-#pragma unroll
-            for (int i = 0; i < kWgTN; ++i) {
-                const int n = n0 + 32 * i + col;
-                a[u][i] = (on && n < N) ? dY[rr * ldy + n] : 0.0f;
+        for (int p = 0; p < kPer; ++p) {
+            const int f = tid + 256 * p;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (f < kA4) {
+                const int r = f / (WN / 4), c = 4 * (f % (WN / 4));
+                const long row = m + r;
+                if (row < m_end && n0 + c < ldy) v = *reinterpret_cast<const f32x4*>(dY + row * ldy + n0 + c);
+                for (int e = 0; e < 4; ++e) if (n0 + c + e >= N) v[e] = 0.0f;
+            } else if (f < kA4 + kB4) {
+                const int g = f - kA4, r = g / (WK / 4), c = 4 * (g % (WK / 4));
+                const long row = m + r;
+                if (row < m_end && k0 + c < ldx) v = *reinterpret_cast<const f32x4*>(X + row * ldx + k0 + c);
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + c + e;
+                    if (k >= K) v[e] = (k == K && db && row < m_end) ? 1.0f : 0.0f;        // the bias column, then nothing
+                    else if (relu_x) v[e] = fmaxf(v[e], 0.0f);
+                }
             }
-#pragma unroll
-            for (int j = 0; j < kWgTK; ++j) {
-                const int k = k0 + 32 * j + col;
-                float x = 0.0f;
-                if (on && k < K) { x = X[rr * ldx + k]; if (relu_x) x = fmaxf(x, 0.0f); }
-                else if (on && k == K && db) x = 1.0f;
-                bq[u][j] = x;
-            }
+            stage[p] = v;
         }
+    };
+    auto commit = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < kWgUnroll; ++u)
+        for (int p = 0; p < kPer; ++p) {
+            const int f = tid + 256 * p;
+            if (f < kA4) *reinterpret_cast<f32x4*>(la + buf * kWtRows * WN + 4 * f) = stage[p];
+            else if (f < kA4 + kB4) *reinterpret_cast<f32x4*>(lb + buf * kWtRows * WK + 4 * (f - kA4)) = stage[p];
+        }
+    };
+    const int half = lane >> 5, col = lane & 31;
+    if (m_begin < m_end) { fetch(m_begin); commit(0); }
+    __syncthreads();
+    int buf = 0;
+    for (long m = m_begin; m < m_end; m += kWtRows) {
+        const bool more = m + kWtRows < m_end;
+        if (more) fetch(m + kWtRows);
+        const float* pa = la + buf * kWtRows * WN + wn * (TN * 32) + col;
+        const float* pb = lb + buf * kWtRows * WK + wk * (TK * 32) + col;
 #pragma unroll
-            for (int i = 0; i < kWgTN; ++i)
+        for (int u = 0; u < kWtRows / 2; ++u) {
+            float a[TN], bq[TK];
 #pragma unroll
-                for (int j = 0; j < kWgTK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], bq[u][j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TN; ++i) a[i] = pa[(2 * u + half) * WN + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TK; ++j) bq[j] = pb[(2 * u + half) * WK + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
-    // accumulator register r of lane l holds D[8 (r / 4) + 4 (l / 32) + r % 4][l % 32]
 #pragma unroll
-    for (int i = 0; i < kWgTN; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < kWgTK; ++j) {
-            const int k = k0 + 32 * j + col;
+        for (int j = 0; j < TK; ++j) {
+            const int k = k0 + wk * (TK * 32) + 32 * j + col;
             if (k >= Kb) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
+                const int n = n0 + wn * (TN * 32) + 32 * i + 8 * (r >> 2) + 4 * half + (r & 3);
                 if (n >= N) continue;
                 const float v = acc[i][j][r];
                 if (k < K) atomicAdd(dW + (long)n * lddw + k, v);
                 else atomicAdd(db + n, v);
             }
         }
+}
+
+template <int TN, int TK>
+int launch_wgrad_tile(const float* dY, int ldy, const float* X, int ldx, long M, int N, int K, int flags, float* dW, int lddw, float* db, void* stream) {
+    constexpr int WN = 2 * TN * 32, WK = 2 * TK * 32;
+    const int Kb = db ? K + 1 : K;
+    const unsigned gx = car_div_up(N, WN), gy = car_div_up(Kb, WK);
+    long want = 512 / ((long)gx * gy);                                 // ~2 workgroups per CU
+    if (want < 1) want = 1;
+    long slab = (M + want - 1) / want;
+    slab = (slab + kWtRows - 1) / kWtRows * kWtRows;
+    const unsigned gz = car_div_up(M, slab);
+    CAR_REQUIRE(gz <= 65535, "car_linear_wgrad: too many row slabs");
+    const size_t lds_bytes = (size_t)2 * kWtRows * (WN + WK) * sizeof(float);
+    auto kern = wgrad_tile_kernel<TN, TK>;
+    hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e1 != hipSuccess) { car_set_error("car_linear_wgrad: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), lds_bytes, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K, (flags & CAR_LIN_RELU_IN) ? 1 : 0, slab,
+                       dW, lddw, db);
+    CAR_CHECK_LAUNCH("car_linear_wgrad");
+    return CAR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -271,20 +334,10 @@ extern "C" int car_linear_wgrad(const float* dY, int ldy, const float* X, int ld
                                 float* db, void* stream) {
     CAR_REQUIRE(dY && X && dW, "car_linear_wgrad: null pointer");
     CAR_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && lddw >= K, "car_linear_wgrad: bad sizes M=%ld N=%d K=%d", M, N, K);
-    const int Kb = db ? K + 1 : K;
-    const unsigned gx = car_div_up(N, 32 * kWgTN), gy = car_div_up(Kb, 32 * kWgTK);
-    // slabs: enough workgroups to fill the chip (>= ~2048 waves), rows per wave a multiple of the unrolled step
-    long want = 2048 / ((long)gx * gy * 4);
-    if (want < 1) want = 1;
-    long slab = (M + want * 4 - 1) / (want * 4);
-    slab = (slab + 2 * kWgUnroll - 1) / (2 * kWgUnroll) * (2 * kWgUnroll);
-    const unsigned gz = car_div_up(M, slab * 4);
-    CAR_REQUIRE(gz <= 65535, "car_linear_wgrad: too many row slabs");
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(wgrad_kernel, dim3(gx, gy, gz), dim3(256), 0, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K, (flags & CAR_LIN_RELU_IN) ? 1 : 0,
-                       (int)slab, dW, lddw, db);
-    CAR_CHECK_LAUNCH("car_linear_wgrad");
-    return CAR_OK;
+    CAR_REQUIRE(ldy % 4 == 0 && ldx % 4 == 0, "car_linear_wgrad: row strides must be multiples of 4 floats (got %d, %d)", ldy, ldx);
+    // wide layers: the 192 x 320 workgroup tile; everything else the 128 x 128 one
+    if (N > 128 || K + (db ? 1 : 0) > 128) return launch_wgrad_tile<3, 5>(dY, ldy, X, ldx, M, N, K, flags, dW, lddw, db, stream);
+    return launch_wgrad_tile<2, 2>(dY, ldy, X, ldx, M, N, K, flags, dW, lddw, db, stream);
 }
 
 extern "C" int car_attend_backward(const float* w, const float* val, int D, int b, int V, int R, int P, const float* dz, int ld_dz,
