@@ -13,7 +13,7 @@
 //   * two tap batches (one row group each: 4 float4) in flight, each issued a whole chunk before it is blended;
 //   * no read-ahead of the weight operands (the third wave hides the LDS latency instead).
 // One workgroup = 12 waves = 192 samples = 48 consecutive rays x 4 consecutive steps (wave = (16-ray bundle, step)); the weight
-// stream is shared by 192 samples.  The tap tables are stored compactly (byte offset + two flags, four weights).
+// stream is shared by 192 samples.  The tap tables are stored compactly (byte offset of the north-west node, four weights).
 // The geometric query g (16 floats per sample) is written out for the second attention round (car_round2.hip recomputes the
 // 16 -> 128 half of query_repeat_embed from it instead of reading a 128-wide row back).
 #include "car_common.h"
@@ -26,13 +26,13 @@ constexpr int kStepsPerGroup = 4, kBundles = kWaves / kStepsPerGroup;  // 3 bund
 constexpr int kThreads = 64 * kWaves;
 
 constexpr int kPieces = 3;                         // LDS-DMA pieces per chunk: 12 waves x 1 KB each
-constexpr unsigned kDeadTap = 0xfffffe00u;         // tap-table entry of a sample that reads exact zeros: beyond any map, no wrap with the column offset
-constexpr long kMaxMapBytes = 0xfffff000L;         // the lattice of one (view, padding mode) stays below it
+constexpr unsigned kDeadTap = 0xc0000000u;         // tap-table entry of a sample that reads exact zeros: beyond any map, and no wrap with + row + node + column
+constexpr long kMaxMapBytes = 0x80000000L;         // the lattice of one (view, padding mode) stays below it
 
 #include "car_fused_mma.h"
 
 constexpr int kLdsStage = kLdsW + 2 * kChunkTiles * kTile;      // [12][16][36]           h tiles, wave private     27 KB
-constexpr int kLdsTapB = kLdsStage + kGroup * kStageLd;         // [192][2] uint          byte offset of the nw node | 1: x1 != x0 | 2: y1 != y0   1.5 KB
+constexpr int kLdsTapB = kLdsStage + kGroup * kStageLd;         // [192][2] uint          byte offset of the nw node (or kDeadTap)   1.5 KB
 constexpr int kLdsTapW = kLdsTapB + kGroup * 2;                 // [192][2][4]            tap weights (nw, ne, sw, se)    6 KB
 constexpr int kLdsPe = kLdsTapW + kGroup * 8;                   // [192][2][4]            tanh(pt_s/5)                6 KB
 constexpr int kLdsWpt = kLdsPe + kGroup * 8;                    // [576][4]               (W1[:,C:C+3], b1)           9 KB
@@ -102,7 +102,8 @@ __device__ __forceinline__ NextChunk next_chunk_w2(const float* __restrict__ blo
 template <int ABL>
 __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: everything derived from it stays out of the vector ALU
     const int s = lane & 15, q4 = lane >> 4;
     const int nblk = gridDim.x;
     int blk = blockIdx.x;
@@ -151,8 +152,8 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             int mode;
             if (sv == v) { gx = smp.grid[0]; gy = smp.grid[1]; mode = 0; }
             else { gx = sv == 0 ? smp.grid_in[0][0] : smp.grid_in[1][0]; gy = sv == 0 ? smp.grid_in[0][1] : smp.grid_in[1][1]; mode = 1; }
-            // the four taps are nw + {0, 1 node} + {0, 1 row}; a node's row is kC*4 = 2304 B, a multiple of 256, so the two flags ride in
-            // the low bits of the nw node's byte offset inside the lattice of this (source view, padding mode)
+            // the four taps are nw + {0, 1 node} + {0, 1 row} (car_lattice_taps never returns a node of the last column / row): the
+            // table holds the nw node's byte offset inside the lattice of this (source view, padding mode)
             int node, flags;
             float w[4];
             car_lattice_taps(gx, gy, a.lw, a.lh, a.pad, a.sx, a.sy, &node, &flags, w);
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             // loads of its lanes return zeros without touching memory — an instruction whose lanes are all out of range costs the
             // texture path nothing (profiles/round3_fused_experiments.md) — and weight zero makes the contribution exactly +-0
             const bool dead = mode == 1 && (flags & 4);
-            reinterpret_cast<unsigned*>(lds + kLdsTapB)[sg * 2 + sv] = dead ? kDeadTap : (unsigned)node * (unsigned)(kC * 4) | (unsigned)(flags & 3);
+            reinterpret_cast<unsigned*>(lds + kLdsTapB)[sg * 2 + sv] = dead ? kDeadTap : (unsigned)node * (unsigned)(kC * 4);
             *reinterpret_cast<float4*>(lds + kLdsTapW + (sg * 2 + sv) * 4) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w[0], w[1], w[2], w[3]);
             const float px = sv == 0 ? smp.pt_in[0][0] : smp.pt_in[1][0], py = sv == 0 ? smp.pt_in[0][1] : smp.pt_in[1][1],
                         pz = sv == 0 ? smp.pt_in[0][2] : smp.pt_in[1][2];
@@ -206,12 +207,12 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         if constexpr (ABL == 1 || ABL == 2 || ABL == 3 || ABL == 12) return;
         const int chunk_off = 128 * c;                                 // the chunk's 32 channels: scalar offset, not range-checked
         const unsigned tbv = reinterpret_cast<const unsigned*>(lds + kLdsTapB)[(wave * kRows + r0 + 8 * it) * 2 + sv];
-        const unsigned o00 = (tbv & ~3u) + qd16, dx = (tbv & 1u) ? (unsigned)(kC * 4) : 0u, dy = (tbv & 2u) ? row_step : 0u;
+        const unsigned o00 = tbv + qd16, o10 = o00 + row_step;          // east taps: the instruction's immediate offset (one node = 2304 B)
         auto ld = [&](unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc[sv], (int)off, chunk_off, 0)); };
         tap[0] = ld(o00);
-        tap[1] = ld(o00 + dx);
-        tap[2] = ld(o00 + dy);
-        tap[3] = ld(o00 + dx + dy);
+        tap[1] = ld(o00 + (unsigned)(kC * 4));
+        tap[2] = ld(o10);
+        tap[3] = ld(o10 + (unsigned)(kC * 4));
     };
     auto blend_row = [&](const f32x4 (&tap)[4], int sv, int it) {
         if constexpr (ABL == 2 || ABL == 3 || ABL == 12) return;

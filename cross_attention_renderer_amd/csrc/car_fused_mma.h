@@ -45,11 +45,13 @@ __device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, in
     int kb = kWaves * p + wave;
     kb = kb < n.nkb ? kb : kb - n.nkb;
     kb = kb < n.nkb ? kb : kb - n.nkb;
+    // `wave` is scalar, so both addresses are: scalar base + the lane's 16 bytes (no 64-bit vector address arithmetic per piece)
     const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(n.dst + kb * 256));
-    const float* gsrc = n.src + kb * 256 + 4 * lane;
+    const float* gsrc = n.src + kb * 256;
+    const unsigned voff = 16u * (unsigned)lane;
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(gsrc) : "memory");
 }
 template <int ABL = 0>
 __device__ __forceinline__ void stream_issue_all(const float* __restrict__ blob, float* lds, int g, int lane, int wave) {

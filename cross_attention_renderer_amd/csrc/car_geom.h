@@ -353,8 +353,11 @@ CAR_HD void car_bilinear_taps(float gx, float gy, int W, int H, int mode, int* i
 // texel beyond the edge; border: the clamp at the outer centres).  The SUM over the levels is therefore bilinear inside
 // every cell of the integer lattice u in [-pad, 2 W_max - 1 + pad], pad = r_max + 1, and four taps of one map — built once
 // per stereo pair and padding mode — give what twelve taps of three levels give.  Outside the lattice both sums are constant
-// (zero / the border value), so the lookup clamps.  Returns the node index y0 * lw + x0 of the north-west tap, flags
-// (1: the east taps are one node over, 2: the south taps one row down, 4: on / beyond the outer ring) and the weights (nw, ne, sw, se).
+// (zero / the border value), so the lookup clamps.  Returns the node index y0 * lw + x0 of the north-west tap, flags and the weights
+// (nw, ne, sw, se).  The north-west node is never in the last column / row: a point clamped onto the far edge takes the node before
+// it with weights (0, 1), so the east taps are ALWAYS one node over and the south taps one row down (flag bits 1 and 2, always set;
+// kept for the callers that still read them) — the fused kernel's tap addresses are "node, +1 node, +1 row, +both" without a decode.
+// Flag 4: on / beyond the outer ring.
 // ----------------------------------------------------------------------------------------------------
 CAR_HD void car_lattice_taps(float gx, float gy, int lw, int lh, int pad, float sx, float sy, int* node, int* flags, float* w) {
     float ux = (gx + 1.0f) * sx - 1.0f, uy = (gy + 1.0f) * sy - 1.0f;
@@ -363,12 +366,14 @@ CAR_HD void car_lattice_taps(float gx, float gy, int lw, int lh, int pad, float 
     if (!(uy > loy)) uy = loy;
     if (ux > hix) ux = hix;
     if (uy > hiy) uy = hiy;
-    const float x0f = floorf(ux), y0f = floorf(uy);
+    float x0f = floorf(ux), y0f = floorf(uy);
+    if (x0f > hix - 1.0f) x0f = hix - 1.0f;                            // on the far edge: the cell before it, weights (0, 1)
+    if (y0f > hiy - 1.0f) y0f = hiy - 1.0f;
     const float wx0 = (x0f + 1.0f) - ux, wx1 = ux - x0f, wy0 = (y0f + 1.0f) - uy, wy1 = uy - y0f;
     const int x0 = (int)x0f + pad, y0 = (int)y0f + pad;
     *node = y0 * lw + x0;
     // 4: the point sits on or beyond the lattice's outer ring: with zeros padding every level's function — and so every node the
     // four taps touch — is exactly zero there (with border padding the ring carries the edge values: the caller ignores the bit)
-    *flags = (x0 < lw - 1 ? 1 : 0) | (y0 < lh - 1 ? 2 : 0) | ((ux <= lox || ux >= hix || uy <= loy || uy >= hiy) ? 4 : 0);
-    w[0] = wx0 * wy0; w[1] = wx1 * wy0; w[2] = wx0 * wy1; w[3] = wx1 * wy1;     // on the last node the far weight is exactly 0
+    *flags = 3 | ((ux <= lox || ux >= hix || uy <= loy || uy >= hiy) ? 4 : 0);
+    w[0] = wx0 * wy0; w[1] = wx1 * wy0; w[2] = wx0 * wy1; w[3] = wx1 * wy1;
 }

@@ -3,6 +3,7 @@ product kernel (variant 0) and the timing-only ablation variants of the developm
 variants > 0 are wrong by construction):
   1 no tap loads | 2 no gather work | 3 = 2 + no weight DMA / barriers | 5 the source passes without their matrix work | 4 phase stamps | 20 where a wave waits inside a chunk
   11 no chunk barrier (racy) | 12 = 3 + no A-operand reads | 13 no A-operand reads | 100 the PRODUCT library's kernel, timed the same way
+  200 the wave-specialised kernel under evaluation (csrc/car_fused_ws.hip, development build only), compared bit for bit with 100
 (earlier rounds' probes — masked lanes, tap orders, deep tap rings, the full-lattice timing probe — are recorded in profiles/)
 Usage (GPU box): python tools/bench_fused.py [variants...]"""
 import ctypes
@@ -27,6 +28,16 @@ def main():
     fn = dev_lib.car_fused_samples_ablate
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_int] + _lib.SIGNATURES["car_fused_samples"][1]
+    fn_ws = getattr(dev_lib, "car_fused_samples_ws", None)
+    if fn_ws is not None:
+        fn_ws.restype = ctypes.c_int
+        fn_ws.argtypes = _lib.SIGNATURES["car_fused_samples"][1]
+    base_path = os.path.join(ROOT, "tools", "_dev", "libcar_base.so")          # variant 300: a saved earlier build of the product library
+    fn_base = None
+    if os.path.exists(base_path):
+        fn_base = ctypes.CDLL(base_path).car_fused_samples
+        fn_base.restype = ctypes.c_int
+        fn_base.argtypes = _lib.SIGNATURES["car_fused_samples"][1]
     lib = _lib.load()
     dev = torch.device("cuda:0")
     model = bench.build_model(dev)
@@ -88,7 +99,7 @@ def main():
                     gmeta, wpt.data_ptr(), blob.data_ptr(),
                     bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
                     pixel_val.data_ptr(), st)
-            rc = prod(*args) if v == 100 else fn(v, *args)
+            rc = prod(*args) if v == 100 else fn_ws(*args) if v == 200 else fn_base(*args) if v == 300 else fn(v, *args)
             b_.record()
             assert rc == 0, dev_lib.car_last_error()
             lat.append((a, b_))
@@ -112,13 +123,22 @@ def main():
             print(f"source passes, per wave and chunk (mean over {w8.shape[0]} waves, {n:.0f} chunks each; s_memtime ticks): "
                   f"9 x (A-operand reads + 6 MFMAs issued) {m(7):.0f}, DMA pieces {m(5):.0f}, affine {m(6):.0f}, blends incl. the wait for their taps {m(0):.0f}, "
                   f"h rows stored + tap loads issued {m(4):.0f}, chunk-end wait for the weight DMA {m(1):.0f}, barrier {m(2):.0f}")
-        if v in (0, 100):                                  # keep the results: the development kernel must equal the product's bit for bit
+        if v == 200 and "CAR_WS_STAMP" in os.environ:      # development build with -DCAR_WS_STAMP: per-wave tick sums of the source passes
+            w4 = pixel_val.view(torch.int64)[: (2 * R * bench.P // 192) * 16 * 8].view(-1, 16, 8).cpu().double()
+            mw, gw_ = w4[:, :12, :3].mean(dim=(0, 1)) / 36, w4[:, 12:, :3].mean(dim=(0, 1)) / 36
+            phm = w4[:, :12, 3:].mean(dim=(0, 1))
+            print("   matrix wave phases (ticks): tables + geometry %.0f, source passes %.0f, key layer 1 (both halves) %.0f, rest %.0f, total %.0f" % (
+                phm[1] - phm[0], phm[2] - phm[1], phm[3] - phm[2], phm[4] - phm[3], phm[4] - phm[0]))
+            print(f"   matrix wave per chunk: MFMA groups + DMA issue {mw[0]:.0f}, wait for own DMA {mw[2]:.0f}, barrier {mw[1]:.0f};  "
+                  f"gather wave per period: 6 row groups {gw_[0]:.0f}, barrier {gw_[1]:.0f}  (s_memtime ticks)")
+        if v in (0, 100, 200, 300):                        # keep the results: the development kernels must equal the product's bit for bit
             outs[v] = [torch.empty(cnt_, device=dev).copy_(eng._work[o_:o_ + cnt_]) for o_, cnt_ in
                        [(lambda n_: (lib.car_workspace_find(ctypes.byref(d), n_.encode(), ctypes.byref(off), ctypes.byref(cnt)), (off.value, cnt.value))[1])(n_)
                         for n_ in ("e", "qry", "logit", "pt", "g")]]
-            if len(outs) == 2:
-                for n_, x, y in zip(("e", "qry", "logit", "pt", "g"), outs[0], outs[100]):
-                    print(f"   dev(0) vs product(100) {n_:6s} max |diff| {(x - y).abs().max().item():.3e}  equal {torch.equal(x, y)}")
+            ref = 300 if 300 in outs else 100
+            if v != ref and ref in outs:
+                for n_, x, y in zip(("e", "qry", "logit", "pt", "g"), outs[v], outs[ref]):
+                    print(f"   ({v}) vs ({ref}) {n_:6s} max |diff| {(x - y).abs().max().item():.3e}  max |ref| {y.abs().max().item():.3e}  equal {torch.equal(x, y)}")
         print(f"ABL={v}: fused kernel median {ms[len(ms) // 2]:.3f} ms  min {ms[0]:.3f} ms  -> {flop / ms[len(ms) // 2] / 1e9:.1f} TFLOP/s (nominal flops)", flush=True)
 
 
