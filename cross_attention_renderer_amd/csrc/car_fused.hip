@@ -35,7 +35,7 @@ constexpr int kLdsStage = kLdsW + 2 * kChunkTiles * kTile;      // [12][16][36] 
 constexpr int kLdsTapB = kLdsStage + kGroup * kStageLd;         // [192][2] uint          byte offset of the nw node (or kDeadTap)   1.5 KB
 constexpr int kLdsTapW = kLdsTapB + kGroup * 2;                 // [192][2][4]            tap weights (nw, ne, sw, se)    6 KB
 constexpr int kLdsPe = kLdsTapW + kGroup * 8;                   // [192][2][4]            tanh(pt_s/5)                6 KB
-constexpr int kLdsWpt = kLdsPe + kGroup * 8;                    // [576][4]               (W1[:,C:C+3], b1)           9 KB
+constexpr int kLdsWpt = kLdsPe + kGroup * 8;                    // [144][4][4]            (W1[:,C:C+3], b1 hp) per channel quad: x | y | z | b   9 KB
 constexpr int kLdsBias = kLdsWpt + kC * 4;                      // [672]
 constexpr int kLdsG = kLdsBias + kBiasFloats;                   // [192][16]              geometric query g per sample 12 KB
 constexpr int kLdsFloats = kLdsG + kGroup * 16;
@@ -124,7 +124,18 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     long long stamp[12];
     auto mark = [&](int k) { if constexpr (ABL == 4) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); };
     mark(0);
-    for (int k = tid; k < kC; k += kThreads) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
+    // Scale of the first layer's output h (split-fp16 arithmetic, car_fused_mma.h): h is bounded by the largest lattice value plus the
+    // point / bias term (the tap weights are non-negative and sum to at most one, |tanh| <= 1): one power of two hp per launch.
+    // Everything that is added up into h — tap weights, point terms, the bias — is multiplied by hp ONCE, where it is made (exact:
+    // a power of two), so the chunk loop never scales: h comes out of the gather as h * hp.
+    float hp, hinv;
+    pow2_scale(fmaxf(a.gmeta[0] + a.bias[kBiasScale + 5], 1e-30f), hp, hinv);
+    // point-term table, per quad of channels: [x0..x3 | y0..y3 | z0..z3 | b0 hp..b3 hp] (operand pairs of the packed FMAs)
+    for (int k = tid; k < kC; k += kThreads) {
+        const float4 v = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
+        float* q = lds + kLdsWpt + 16 * (k >> 2) + (k & 3);
+        q[0] = v.x; q[4] = v.y; q[8] = v.z; q[12] = v.w * hp;
+    }
     for (int k = tid; k < kBiasFloats; k += kThreads) lds[kLdsBias + k] = a.bias[k];
     int g = 0;
     stream_issue_all<ABL>(a.blob, lds, 0, lane, wave);
@@ -163,10 +174,11 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             // texture path nothing (profiles/round3_fused_experiments.md) — and weight zero makes the contribution exactly +-0
             const bool dead = mode == 1 && (flags & 4);
             reinterpret_cast<unsigned*>(lds + kLdsTapB)[sg * 2 + sv] = dead ? kDeadTap : (unsigned)node * (unsigned)(kC * 4);
-            *reinterpret_cast<float4*>(lds + kLdsTapW + (sg * 2 + sv) * 4) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<float4*>(lds + kLdsTapW + (sg * 2 + sv) * 4) =
+                dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w[0] * hp, w[1] * hp, w[2] * hp, w[3] * hp);
             const float px = sv == 0 ? smp.pt_in[0][0] : smp.pt_in[1][0], py = sv == 0 ? smp.pt_in[0][1] : smp.pt_in[1][1],
                         pz = sv == 0 ? smp.pt_in[0][2] : smp.pt_in[1][2];
-            *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f), tanhf(py / 5.0f), tanhf(pz / 5.0f), 0.0f);
+            *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f) * hp, tanhf(py / 5.0f) * hp, tanhf(pz / 5.0f) * hp, 0.0f);
         }
         if (g_live) {
             if constexpr (ABL != 4 && ABL != 20) { a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1]; }
@@ -232,12 +244,14 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         if constexpr (ABL == 2 || ABL == 3 || ABL == 12) return;
         const int rr = r0 + 8 * it;
         const float4 pe = *reinterpret_cast<const float4*>(lds + kLdsPe + ((wave * kRows + rr) * 2 + sv) * 4);
-        const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 4 * (32 * c + 4 * qd));
-        const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
-        hacc[it] = make_float4(fmaf(w0.z, pe.z, fmaf(w0.y, pe.y, w0.x * pe.x)) + w0.w,
-                               fmaf(w1.z, pe.z, fmaf(w1.y, pe.y, w1.x * pe.x)) + w1.w,
-                               fmaf(w2.z, pe.z, fmaf(w2.y, pe.y, w2.x * pe.x)) + w2.w,
-                               fmaf(w3.z, pe.z, fmaf(w3.y, pe.y, w3.x * pe.x)) + w3.w);
+        const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 16 * (8 * c + qd));
+        const float4 wx = wp[0], wy = wp[1], wz = wp[2], wb = wp[3];
+        // twelve FMAs: b + wz pz + wy py + wx px per channel (the bias rides in the innermost FMA: no separate multiply / add).
+        // Deliberately scalar: the same sum written as six v_pk_fma_f32 with broadcast point terms produced e off by 1e-2 in this
+        // kernel (cause not found — the instruction itself is fine with a destination that overlaps its broadcast source,
+        // checked in isolation); this form differs from the round-2 arithmetic by rounding only (2.4e-7 on e).
+        hacc[it] = make_float4(fmaf(wx.x, pe.x, fmaf(wy.x, pe.y, fmaf(wz.x, pe.z, wb.x))), fmaf(wx.y, pe.x, fmaf(wy.y, pe.y, fmaf(wz.y, pe.z, wb.y))),
+                               fmaf(wx.z, pe.x, fmaf(wy.z, pe.y, fmaf(wz.z, pe.z, wb.z))), fmaf(wx.w, pe.x, fmaf(wy.w, pe.y, fmaf(wz.w, pe.z, wb.w))));
     };
     auto finish_row = [&](int it) {
         if constexpr (ABL == 2 || ABL == 3 || ABL == 12) return;
@@ -246,22 +260,19 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
     };
     // Scales of the split-fp16 arithmetic (car_fused_mma.h).  Packed weights carry 2^shift per layer (dW.. = 2^-shift, from the
-    // bias table).  h is bounded by the largest lattice value plus the point / bias term, because the tap weights are non-negative
-    // and sum to at most one and |tanh| <= 1: one power of two hp per launch.
+    // bias table); hp: see the top of the kernel.
     const float* lsc = lds + kLdsBias + kBiasScale;
     auto uniform = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };   // keep it in an SGPR
-    float hp, e_up, e_down;
+    float e_up, e_down;
     {
-        float hinv;
-        pow2_scale(fmaxf(a.gmeta[0] + lsc[5], 1e-30f), hp, hinv);
         const float dW2 = lsc[kLayerW2];
-        e_up = uniform(hp / dW2); e_down = uniform(dW2 * hinv); hp = uniform(hp);
+        e_up = uniform(hp / dW2); e_down = uniform(dW2 * hinv);
     }
-    auto read_b = [&](half8& bhi, half8& blo) {                        // this lane's 8 channels of the wave's h tile, split
+    auto read_b = [&](half8& bhi, half8& blo) {                        // this lane's 8 channels of the wave's h tile (already h * hp), split
         const float4 x0 = *reinterpret_cast<const float4*>(stage + s * kStageLd + 8 * q4);
         const float4 x1 = *reinterpret_cast<const float4*>(stage + s * kStageLd + 8 * q4 + 4);
         const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-        split8(x, hp, bhi, blo);
+        split8_scaled(x, bhi, blo);
     };
 
     // first chunk of source 0: nothing to hide it under
