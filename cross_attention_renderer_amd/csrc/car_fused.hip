@@ -56,6 +56,7 @@ struct FusedArgs {
     const float* bias;
     int b, V, R, P, H, W;
     long S;
+    int blk0;                  // first sample group of this launch (0 except in the development build's partial launches)
     float* e;
     float* qry;
     float* g;
@@ -99,6 +100,7 @@ __device__ __forceinline__ NextChunk next_chunk_w2(const float* __restrict__ blo
 // 12 = 3 + no A-operand reads from LDS (matrix pipe + VALU only); 13 the full kernel without the A-operand reads;
 // 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val);
 // 20: the full kernel with shader-clock sums per piece of the chunk loop (where a wave waits inside a chunk)
+// 21: the full kernel, writing each sample's north-west lattice node per source (-1: no fetch) over pixel_val (tap statistics)
 template <int ABL>
 __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -110,7 +112,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     {   // workgroup b runs on XCD b % 8 (observed, speed only): give every XCD a contiguous band of sample groups so that the
         // lattice rows its workgroups share stay in one L2
         const int q8 = nblk / 8, r8 = nblk % 8, xcd = blk % 8, idx = blk / 8;
-        blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx + a.blk0;
     }
     // 192 samples = 48 consecutive rays x 4 consecutive steps: wave = (bundle of 16 rays, step), lane & 15 = ray of the bundle, so the
     // 16 rows a wave gathers together are the same step of neighbouring rays (shared lattice rows)
@@ -173,6 +175,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             // loads of its lanes return zeros without touching memory — an instruction whose lanes are all out of range costs the
             // texture path nothing (profiles/round3_fused_experiments.md) — and weight zero makes the contribution exactly +-0
             const bool dead = mode == 1 && (flags & 4);
+            if constexpr (ABL == 21) { if (g_live) reinterpret_cast<int*>(a.pixel_val)[2 * gi + sv] = dead ? -1 : node; }      // tools/bench_fused.py 21: tap statistics
             reinterpret_cast<unsigned*>(lds + kLdsTapB)[sg * 2 + sv] = dead ? kDeadTap : (unsigned)node * (unsigned)(kC * 4);
             *reinterpret_cast<float4*>(lds + kLdsTapW + (sg * 2 + sv) * 4) =
                 dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w[0] * hp, w[1] * hp, w[2] * hp, w[3] * hp);
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f) * hp, tanhf(py / 5.0f) * hp, tanhf(pz / 5.0f) * hp, 0.0f);
         }
         if (g_live) {
-            if constexpr (ABL != 4 && ABL != 20) { a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1]; }
+            if constexpr (ABL != 4 && ABL != 20 && ABL != 21) { a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1]; }
             a.pt[3 * gi + 0] = smp.pt[0]; a.pt[3 * gi + 1] = smp.pt[1]; a.pt[3 * gi + 2] = smp.pt[2];
         }
         float* gl = lds + kLdsG + sg * 16;
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
 }
 
 
-int launch_fused(int abl, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w, int lat_pad,
+int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w, int lat_pad,
                  const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W, float* e,
                  float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
     CAR_REQUIRE(poses && rays && steps && lattice && gmeta && wpt && blob && bias, "car_fused_samples: null input");
@@ -449,14 +452,17 @@ int launch_fused(int abl, const float* poses, const float* rays, const float* st
     a.gmeta = gmeta; a.wpt = wpt; a.blob = blob; a.bias = bias;
     a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
     a.S = (long)b * V * R * P;
+    a.blk0 = blk0;
     a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
-    const long groups = (long)b * V * car_div_up(R, kBundles * kRows) * car_div_up(P, kStepsPerGroup);
+    long groups = (long)b * V * car_div_up(R, kBundles * kRows) * car_div_up(P, kStepsPerGroup);
+    if (nblk > 0) groups = (groups - blk0 < nblk) ? groups - blk0 : nblk;     // development build: a slice of the sample groups
     void (*kern)(const FusedArgs) = fused_kernel<0>;
 #ifdef CAR_ABLATION
     switch (abl) {
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 4: kern = fused_kernel<4>; break;   case 5: kern = fused_kernel<5>; break;   case 11: kern = fused_kernel<11>; break;
         case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;   case 20: kern = fused_kernel<20>; break;
+        case 21: kern = fused_kernel<21>; break;
         default: break;
     }
 #else
@@ -478,7 +484,7 @@ extern "C" size_t car_fused_bias_floats(void) { return (size_t)kBiasFloats; }
 extern "C" int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
                                  int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P,
                                  int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
-    return launch_fused(0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt, pixel_val,
+    return launch_fused(0, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt, pixel_val,
                         stream);
 }
 
@@ -488,7 +494,20 @@ extern "C" int car_fused_samples_ablate(int abl, const float* poses, const float
                                         int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b,
                                         int V, int R, int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt,
                                         float* pixel_val, void* stream) {
-    return launch_fused(abl, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt,
+    return launch_fused(abl, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt,
                         pixel_val, stream);
+}
+// the same launch cut into slices of `nblk` sample groups (one kernel launch each): every slice starts its workgroups in phase
+extern "C" int car_fused_samples_sliced(int nblk, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h,
+                                        int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b,
+                                        int V, int R, int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt,
+                                        float* pixel_val, void* stream) {
+    const long groups = (long)b * V * car_div_up(R, kBundles * kRows) * car_div_up(P, kStepsPerGroup);
+    for (long b0 = 0; b0 < groups; b0 += nblk) {
+        const int rc = launch_fused(0, (int)b0, nblk, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
+                                    logit, pt, pixel_val, stream);
+        if (rc != CAR_OK) return rc;
+    }
+    return CAR_OK;
 }
 #endif

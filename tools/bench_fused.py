@@ -3,7 +3,7 @@ product kernel (variant 0) and the timing-only ablation variants of the developm
 variants > 0 are wrong by construction):
   1 no tap loads | 2 no gather work | 3 = 2 + no weight DMA / barriers | 5 the source passes without their matrix work | 4 phase stamps | 20 where a wave waits inside a chunk
   11 no chunk barrier (racy) | 12 = 3 + no A-operand reads | 13 no A-operand reads | 100 the PRODUCT library's kernel, timed the same way
-  200 the wave-specialised kernel under evaluation (csrc/car_fused_ws.hip, development build only), compared bit for bit with 100
+  200 the wave-specialised kernel under evaluation (tools/probes/car_fused_ws.hip, development build only), compared bit for bit with 100
 (earlier rounds' probes — masked lanes, tap orders, deep tap rings, the full-lattice timing probe — are recorded in profiles/)
 Usage (GPU box): python tools/bench_fused.py [variants...]"""
 import ctypes
@@ -28,6 +28,9 @@ def main():
     fn = dev_lib.car_fused_samples_ablate
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.c_int] + _lib.SIGNATURES["car_fused_samples"][1]
+    fn_sliced = dev_lib.car_fused_samples_sliced         # variant 1000 + n: the launch cut into kernel launches of n sample groups each
+    fn_sliced.restype = ctypes.c_int
+    fn_sliced.argtypes = [ctypes.c_int] + _lib.SIGNATURES["car_fused_samples"][1]
     fn_ws = getattr(dev_lib, "car_fused_samples_ws", None)
     if fn_ws is not None:
         fn_ws.restype = ctypes.c_int
@@ -99,7 +102,7 @@ def main():
                     gmeta, wpt.data_ptr(), blob.data_ptr(),
                     bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
                     pixel_val.data_ptr(), st)
-            rc = prod(*args) if v == 100 else fn_ws(*args) if v == 200 else fn_base(*args) if v == 300 else fn(v, *args)
+            rc = fn_sliced(v - 1000, *args) if v >= 1000 else prod(*args) if v == 100 else fn_ws(*args) if v == 200 else fn_base(*args) if v == 300 else fn(v, *args)
             b_.record()
             assert rc == 0, dev_lib.car_last_error()
             lat.append((a, b_))
@@ -116,6 +119,33 @@ def main():
                 x = (st8[:, seq[j + 1]] - st8[:, seq[j]]).mean().item()
                 print(f"   {n_:38s} {x:10.0f}  {100 * x / tot:5.1f} %")
             print(f"   total {tot:.0f} ticks")
+        if v == 21:                                         # where the taps go: unique lattice nodes per instruction / workgroup / launch
+            nd = pixel_val.view(torch.int32)[: 2 * R * bench.P * 2].view(2, R, bench.P, 2).cpu().long()      # [context view n][ray][step][source]
+            lw_ = lw.value
+            for sv in (0, 1):
+                for n in (0, 1):
+                    x = nd[n, :, :, sv]                                    # [ray][step]
+                    livef = (x >= 0).float().mean().item()
+                    # one tap instruction = 8 consecutive rays at one step (rows r0 .. r0+7 of a wave): unique 128-byte lines among its 8 rows
+                    g8 = x.view(R // 8, 8, bench.P).permute(0, 2, 1).reshape(-1, 8)
+                    uniq8 = torch.tensor([len(set(r.tolist()) - {-1}) for r in g8[:4096]]).float().mean().item()
+                    # a workgroup = 48 consecutive rays x 4 consecutive steps; nodes touched by its 4 taps (nw, +1, +row, +row+1)
+                    wg = x[: (R // 48) * 48].view(R // 48, 48, bench.P // 4, 4).permute(0, 2, 1, 3).reshape(-1, 192)
+                    def touched(t):
+                        t = t[t >= 0]
+                        return torch.unique(torch.cat([t, t + 1, t + lw_, t + lw_ + 1]))
+                    uw = sum(len(touched(r)) for r in wg[:512]) / 512
+                    # the 32 workgroups an XCD runs at a time: 96 consecutive rays x all steps (two bundles x 16 step groups)
+                    rnd = x[:96].view(2, 48, bench.P // 4, 4).permute(0, 2, 1, 3).reshape(32, 192)
+                    per_wg = sum(len(touched(r)) for r in rnd)
+                    union = len(touched(rnd.reshape(-1)))
+                    same_pg = x[:96, :4].reshape(-1)                       # the two bundles at one step group
+                    print(f"      one XCD round (96 rays x 64 steps): sum of the 32 workgroups' nodes {per_wg}, union {union} ({union * 2304 / 1e6:.1f} MB, {union * 128 / 1e3:.0f} KB per chunk phase); "
+                          f"two neighbouring bundles at one step group: {len(touched(x[:48, :4].reshape(-1)))} + {len(touched(x[48:96, :4].reshape(-1)))} nodes, union {len(touched(same_pg))}")
+                    tot = touched(x.reshape(-1))
+                    print(f"   view {n} source {sv} ({'own, border' if n == sv else 'other, zeros'}): fetching samples {100 * livef:.1f} %, unique nw nodes per 8-row instruction "
+                          f"{uniq8:.2f}, nodes touched per workgroup {uw:.0f} of {192 * 4} tap reads, nodes touched by the launch {len(tot)} "
+                          f"({len(tot) * 2304 / 1e6:.0f} MB) for {int((x >= 0).sum()) * 4} tap reads: {int((x >= 0).sum()) * 4 / max(len(tot), 1):.1f} reads per node")
         if v == 20:
             w8 = pixel_val.view(torch.int64)[: (2 * R * bench.P // 192) * 12 * 8].view(-1, 8).cpu().double()
             n = w8[:, 3].mean().item()
@@ -129,9 +159,11 @@ def main():
             phm = w4[:, :12, 3:].mean(dim=(0, 1))
             print("   matrix wave phases (ticks): tables + geometry %.0f, source passes %.0f, key layer 1 (both halves) %.0f, rest %.0f, total %.0f" % (
                 phm[1] - phm[0], phm[2] - phm[1], phm[3] - phm[2], phm[4] - phm[3], phm[4] - phm[0]))
+            gx = w4[:, 12:, :].mean(dim=(0, 1)) / 36
+            print(f"   gather wave per period: finish (wait taps, blend, split, write) {gx[2]:.0f}, issue of 4 x 6 tap loads {gx[5]:.0f}")
             print(f"   matrix wave per chunk: MFMA groups + DMA issue {mw[0]:.0f}, wait for own DMA {mw[2]:.0f}, barrier {mw[1]:.0f};  "
                   f"gather wave per period: 6 row groups {gw_[0]:.0f}, barrier {gw_[1]:.0f}  (s_memtime ticks)")
-        if v in (0, 100, 200, 300):                        # keep the results: the development kernels must equal the product's bit for bit
+        if v in (0, 100, 200, 300) or v >= 1000:                     # keep the results: the development kernels must equal the product's bit for bit
             outs[v] = [torch.empty(cnt_, device=dev).copy_(eng._work[o_:o_ + cnt_]) for o_, cnt_ in
                        [(lambda n_: (lib.car_workspace_find(ctypes.byref(d), n_.encode(), ctypes.byref(off), ctypes.byref(cnt)), (off.value, cnt.value))[1])(n_)
                         for n_ in ("e", "qry", "logit", "pt", "g")]]

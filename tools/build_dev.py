@@ -29,8 +29,8 @@ def build_dev() -> str:
             subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCAR_ABLATION", *extra, "-c", src, "-o", obj,
                                    "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS[unit]])
         objs.append(obj)
-    for unit in ("car_fused_ws.hip",):                          # development-only units (kernels under evaluation), if present
-        src = os.path.join(ge.CSRC, unit)
+    for unit in ("car_fused_ws.hip",):                          # development-only units (kernels under evaluation): tools/probes/
+        src = os.path.join(ROOT, "tools", "probes", unit)
         if not os.path.exists(src):
             continue
         obj = os.path.join(DEV_DIR, unit.replace(".hip", "_dev.o"))

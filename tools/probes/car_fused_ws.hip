@@ -1,4 +1,6 @@
-// car_fused_ws.hip — the fused per-sample kernel with SPECIALISED waves (same arithmetic, same outputs as car_fused.hip, bit for bit).
+// car_fused_ws.hip — EXPERIMENT, not product (built only by tools/build_dev.py, timed by tools/bench_fused.py 200): the fused per-sample
+// kernel with SPECIALISED waves (same arithmetic, same outputs as csrc/car_fused.hip, bit for bit).  Measured slower than the product
+// kernel (3.59 vs 3.32 ms per 8192 rays): profiles/round3_fused_experiments.md section 11 has the numbers and the reason.
 //
 // Why: in car_fused.hip every wave gathers its own 16 samples AND runs their matrix work.  Its waves stall in the ISSUE of their
 // vector-memory instructions (the texture path takes a 1 KB instruction every ~20 clocks per CU; twelve waves offer their tap loads
@@ -10,6 +12,7 @@
 //   * 4 GATHER waves (one per SIMD), 48 samples each: all tap loads (three row groups = 12 x 16 B per lane in flight, half a chunk
 //     ahead), the blend, the affine start values, ReLU and the fp16 hi/lo split of h, written to a double-buffered B-operand stage
 //     in LDS.  They issue nothing but tap loads, so the compiler's own vmcnt waits are exact, and they end after the source passes.
+// -DCAR_WS_STAMP / _NOTAPS / _NOGATHER / _L2TEST / _RING=n: timing variants of the experiment.
 // 16 waves = four per SIMD, so every wave has 128 registers: the key layer therefore takes BOTH halves of its input ([e_0 ; e_1])
 // back from the output tensor (stored by the same lane moments earlier: L2) instead of chaining e_1 from the accumulators.
 // One barrier per chunk as before; a chunk's h tile and weights are produced during the previous chunk's period.
@@ -28,8 +31,8 @@ constexpr int kRowGroups = kGroup / kGather / 8;   // 6 row groups of 8 rows per
 #define CAR_WS_RING 6
 #endif
 constexpr int kRing = CAR_WS_RING;                 // row groups of tap loads in flight per gather wave (divides 6: ring slots are static)
-constexpr unsigned kDeadTap = 0xfffffe00u;
-constexpr long kMaxMapBytes = 0xfffff000L;
+constexpr unsigned kDeadTap = 0xc0000000u;
+constexpr long kMaxMapBytes = 0x80000000L;
 
 #include "car_fused_mma.h"
 
@@ -154,7 +157,14 @@ __global__ void __launch_bounds__(kThreads) fused_ws_kernel(const FusedArgs a) {
     const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + kBundles * kRows - 1) / (kBundles * kRows);
     const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
 
-    for (int k = tid; k < kC; k += kThreads) *reinterpret_cast<float4*>(lds + kLdsWpt + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
+    // hp: the power of two of the first layer's output; folded into the tap weights, the point terms and the bias where they are made
+    float hp, hinv;
+    pow2_scale(fmaxf(a.gmeta[0] + a.bias[kBiasScale + 5], 1e-30f), hp, hinv);
+    for (int k = tid; k < kC; k += kThreads) {                        // per quad of channels: [x0..x3 | y0..y3 | z0..z3 | b0 hp..b3 hp]
+        const float4 v = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
+        float* q = lds + kLdsWpt + 16 * (k >> 2) + (k & 3);
+        q[0] = v.x; q[4] = v.y; q[8] = v.z; q[12] = v.w * hp;
+    }
     for (int k = tid; k < kBiasFloats; k += kThreads) lds[kLdsBias + k] = a.bias[k];
     if (wave < kMatrix) stream_issue_all(a.blob, lds, 0, lane, wave);                   // weight chunk 0: nothing else touches the buffers yet
 
@@ -184,11 +194,11 @@ __global__ void __launch_bounds__(kThreads) fused_ws_kernel(const FusedArgs a) {
             float w[4];
             car_lattice_taps(gx, gy, a.lw, a.lh, a.pad, a.sx, a.sy, &node, &flags, w);
             const bool dead = mode == 1 && (flags & 4);                // zeros padding, beyond the outer ring: exact zeros, no memory touched
-            reinterpret_cast<unsigned*>(lds + kLdsTapB)[sg * 2 + sv] = dead ? kDeadTap : (unsigned)node * (unsigned)(kC * 4) | (unsigned)(flags & 3);
-            *reinterpret_cast<float4*>(lds + kLdsTapW + (sg * 2 + sv) * 4) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w[0], w[1], w[2], w[3]);
+            reinterpret_cast<unsigned*>(lds + kLdsTapB)[sg * 2 + sv] = dead ? kDeadTap : (unsigned)node * (unsigned)(kC * 4);
+            *reinterpret_cast<float4*>(lds + kLdsTapW + (sg * 2 + sv) * 4) = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w[0] * hp, w[1] * hp, w[2] * hp, w[3] * hp);
             const float px = sv == 0 ? smp.pt_in[0][0] : smp.pt_in[1][0], py = sv == 0 ? smp.pt_in[0][1] : smp.pt_in[1][1],
                         pz = sv == 0 ? smp.pt_in[0][2] : smp.pt_in[1][2];
-            *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f), tanhf(py / 5.0f), tanhf(pz / 5.0f), 0.0f);
+            *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f) * hp, tanhf(py / 5.0f) * hp, tanhf(pz / 5.0f) * hp, 0.0f);
         }
         if (g_live) {
 #ifndef CAR_WS_STAMP
@@ -208,14 +218,11 @@ __global__ void __launch_bounds__(kThreads) fused_ws_kernel(const FusedArgs a) {
 
     const float* lsc = lds + kLdsBias + kBiasScale;
     auto uniform = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
-    float hp, e_up, e_down;
+    float e_up, e_down;
     {
-        float hinv;
-        pow2_scale(fmaxf(a.gmeta[0] + lsc[5], 1e-30f), hp, hinv);
         const float dW2 = lsc[kLayerW2];
-        e_up = uniform(hp / dW2); e_down = uniform(dW2 * hinv); hp = uniform(hp);
+        e_up = uniform(hp / dW2); e_down = uniform(dW2 * hinv);
     }
-
 #ifdef CAR_WS_STAMP
     long long t_work = 0, t_bar = 0, t_aux = 0, ph[5] = {0, 0, 0, 0, 0};
     auto tick = [&]() -> long long { return (long long)__builtin_amdgcn_s_memtime(); };
@@ -273,8 +280,8 @@ __global__ void __launch_bounds__(kThreads) fused_ws_kernel(const FusedArgs a) {
         auto fetch_offsets = [&](int slot, int m, int rg) { tbq[slot] = tapb[rg * 16 + src_of(m)]; };
         auto fetch_weights = [&](int m) {
             const int c = m < kG_K1b ? m - src_of(m) * kKS : 0;
-            const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 4 * (32 * c + 4 * qd));
-            wq[0] = wp[0]; wq[1] = wp[1]; wq[2] = wp[2]; wq[3] = wp[3];
+            const float4* wp = reinterpret_cast<const float4*>(lds + kLdsWpt + 16 * (8 * c + qd));
+            wq[0] = wp[0]; wq[1] = wp[1]; wq[2] = wp[2]; wq[3] = wp[3];      // x | y | z | b of the lane's four channels
         };
         auto issue = [&](int slot, unsigned tbv, int m) {
 #if defined(CAR_WS_NOTAPS) || defined(CAR_WS_NOGATHER)   // timing only (wrong results)
@@ -283,9 +290,9 @@ __global__ void __launch_bounds__(kThreads) fused_ws_kernel(const FusedArgs a) {
 #endif
             const int sv = src_of(m), chunk_off = 128 * (m - sv * kKS);
 #ifdef CAR_WS_L2TEST   // timing only (wrong results): every tap inside a 1 MB window of its lattice, i.e. resident in the XCD's L2
-            const unsigned o00 = (tbv & 0xfff00u) + qd16, dx = (tbv & 1u) ? (unsigned)(kC * 4) : 0u, dy = (tbv & 2u) ? 4u * (kC * 4) : 0u;
+            const unsigned o00 = (tbv & 0xfff00u) + qd16, dx = (unsigned)(kC * 4), dy = 4u * (kC * 4);
 #else
-            const unsigned o00 = (tbv & ~3u) + qd16, dx = (tbv & 1u) ? (unsigned)(kC * 4) : 0u, dy = (tbv & 2u) ? row_step : 0u;
+            const unsigned o00 = tbv + qd16, dx = (unsigned)(kC * 4), dy = row_step;
 #endif
             auto ld = [&](unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc[sv], (int)off, chunk_off, 0)); };
             ring[slot][0] = ld(o00);
@@ -299,10 +306,9 @@ __global__ void __launch_bounds__(kThreads) fused_ws_kernel(const FusedArgs a) {
             return;
 #endif
             const float4 pe = peq[rslot];
-            const float4 h0 = make_float4(fmaf(wq[0].z, pe.z, fmaf(wq[0].y, pe.y, wq[0].x * pe.x)) + wq[0].w,
-                                          fmaf(wq[1].z, pe.z, fmaf(wq[1].y, pe.y, wq[1].x * pe.x)) + wq[1].w,
-                                          fmaf(wq[2].z, pe.z, fmaf(wq[2].y, pe.y, wq[2].x * pe.x)) + wq[2].w,
-                                          fmaf(wq[3].z, pe.z, fmaf(wq[3].y, pe.y, wq[3].x * pe.x)) + wq[3].w);
+            const float4 wx = wq[0], wy = wq[1], wz = wq[2], wb = wq[3];
+            const float4 h0 = make_float4(fmaf(wx.x, pe.x, fmaf(wy.x, pe.y, fmaf(wz.x, pe.z, wb.x))), fmaf(wx.y, pe.x, fmaf(wy.y, pe.y, fmaf(wz.y, pe.z, wb.y))),
+                                          fmaf(wx.z, pe.x, fmaf(wy.z, pe.y, fmaf(wz.z, pe.z, wb.z))), fmaf(wx.w, pe.x, fmaf(wy.w, pe.y, fmaf(wz.w, pe.z, wb.w))));
             const float ww[4] = {twq[rslot].x, twq[rslot].y, twq[rslot].z, twq[rslot].w};
             f32x2 lo2 = {h0.x, h0.y}, hi2 = {h0.z, h0.w};
 #pragma unroll
@@ -312,16 +318,15 @@ __global__ void __launch_bounds__(kThreads) fused_ws_kernel(const FusedArgs a) {
                 lo2 = __builtin_elementwise_fma(w2_, f32x2{gq[0], gq[1]}, lo2);
                 hi2 = __builtin_elementwise_fma(w2_, f32x2{gq[2], gq[3]}, hi2);
             }
-            const float x0 = fmaxf(lo2[0], 0.f) * hp, x1 = fmaxf(lo2[1], 0.f) * hp, x2 = fmaxf(hi2[0], 0.f) * hp, x3 = fmaxf(hi2[1], 0.f) * hp;
-            const fp16x2 ha = __builtin_amdgcn_cvt_pkrtz(x0, x1), hb = __builtin_amdgcn_cvt_pkrtz(x2, x3);
-            const fp16x2 la = __builtin_amdgcn_cvt_pkrtz(x0 - (float)ha[0], x1 - (float)ha[1]),
-                         lb = __builtin_amdgcn_cvt_pkrtz(x2 - (float)hb[0], x3 - (float)hb[1]);
+            unsigned ha, la, hb, lb;                                     // already h * hp: ReLU, then the fp16 halves
+            split_pair(fmaxf(lo2[0], 0.f), fmaxf(lo2[1], 0.f), ha, la);
+            split_pair(fmaxf(hi2[0], 0.f), fmaxf(hi2[1], 0.f), hb, lb);
             // matrix wave 3 gw + (rg >> 1), row rr = r0 + 8 (rg & 1), channels 4 qd .. 4 qd + 3: four halves = 8 bytes of the row's 64;
             // the row's four 16-byte slots are rotated by rr >> 2 so that the matrix wave's ds_read_b128 (16 rows per pass) is conflict-free
             const int rr = r0 + 8 * (rg & 1);
             float* st = lds + kLdsStage + ((m & 1) * kMatrix + 3 * gw + (rg >> 1)) * kStageWave + rr * 16 + 4 * ((qd >> 1) ^ ((rr >> 2) & 3)) + 2 * (qd & 1);
-            *reinterpret_cast<float2*>(st) = make_float2(__builtin_bit_cast(float, ha), __builtin_bit_cast(float, hb));
-            *reinterpret_cast<float2*>(st + 256) = make_float2(__builtin_bit_cast(float, la), __builtin_bit_cast(float, lb));
+            *reinterpret_cast<uint2*>(st) = make_uint2(ha, hb);
+            *reinterpret_cast<uint2*>(st + 256) = make_uint2(la, lb);
         };
         static_assert(kRowGroups % 3 == 0 && kRowGroups % kRing == 0, "record / ring slots are static");
         // prologue: the first kRing positions' taps, the records of positions 0 and 1, the offsets of the first two positions to issue
@@ -339,9 +344,18 @@ __global__ void __launch_bounds__(kThreads) fused_ws_kernel(const FusedArgs a) {
             for (int rg = 0; rg < kRowGroups; ++rg) {
                 fetch_records((rg + 2) % 3, pos_m(m, rg, 2), pos_rg(rg, 2));
                 fetch_offsets((rg + 2) % 3, pos_m(m, rg, 2 + kRing), pos_rg(rg, 2 + kRing));
+#ifdef CAR_WS_STAMP
+                const long long ta = tick();
+                finish(rg % kRing, rg % 3, m, rg);
+                const long long tb = tick();
+                const int m2 = pos_m(m, rg, kRing);
+                if (m2 < kG_K1b) issue(rg % kRing, tbq[rg % 3], m2);
+                t_aux += tb - ta; ph[2] += tick() - tb;
+#else
                 finish(rg % kRing, rg % 3, m, rg);
                 const int m2 = pos_m(m, rg, kRing);
                 if (m2 < kG_K1b) issue(rg % kRing, tbq[rg % 3], m2);
+#endif
                 if (rg == kRowGroups - 1) fetch_weights(m + 1);
             }
             const long long t1 = tick();
