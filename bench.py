@@ -292,17 +292,18 @@ def main():
                     pmc[k] = pmc[k] * part
             if part != 1.0 and pmc.get("source"):
                 pmc["source"] += f", scaled by {part:g} to this launch's share of the frame"
-            roof = {"bound": pmc.get("bound", "ta/l1"), "kernel": f"fused_kernel on {int(samples)} samples (geometry, 4-tap gather of the per-texel-projected pyramid on its lattice, e, key, qry, logits; "
+            roof = {"bound": "mfma", "limiter": pmc.get("limiter"), "kernel": f"fused_kernel on {int(samples)} samples (geometry, 4-tap gather of the per-texel-projected pyramid on its lattice, e, key, qry, logits; "
                                                                   "f16 matrix pipe, fp16 hi/lo split x3)",
                     "achieved": flop / mean / 1e12, "peak": F16_MFMA_PEAK / 3 / 1e12, "unit": "TFLOP/s", "frac": flop / mean / (F16_MFMA_PEAK / 3),
-                    "peak_note": "dense f16 MFMA peak 2500 / 3 products per fp32 term; the kernel is bound by the texture-address / L1 path "
-                                 "(see ta_busy, mfma_busy), this fraction is what the matrix pipe delivers under that bound",
+                    "peak_note": "dense f16 MFMA peak 2500 / 3 products per fp32 term.  What keeps the kernel from it (limiter): MFMAs and ordinary "
+                                 "vector instructions share a SIMD's issue, the A operands wait on LDS, and the tap loads stall in the texture "
+                                 "path's issue (see ta_busy, mfma_busy, valu_share; DESIGN.md section 4.6)",
                     "frac_of_fp32_pipe_peak": flop / mean / FP32_MFMA_PEAK,
-                    "ta_busy": pmc.get("ta_busy"), "mfma_busy": pmc.get("mfma_busy"), "l1_bytes": pmc.get("l1_bytes_per_launch"),
+                    "ta_busy": pmc.get("ta_busy"), "mfma_busy": pmc.get("mfma_busy"), "valu_share": pmc.get("valu_share"), "l1_bytes": pmc.get("l1_bytes_per_launch"),
                     "traffic": pmc.get("bytes_per_launch"), "traffic_source": pmc.get("source"),
                     # which of these fields this run measured and which it copied from the committed counter passes
                     "live_fields": ["achieved", "frac", "frac_of_fp32_pipe_peak", "launches", "ms_per_launch", "flop_per_launch"],
-                    "static_fields": ["bound", "ta_busy", "mfma_busy", "l1_bytes", "traffic"],
+                    "static_fields": ["limiter", "ta_busy", "mfma_busy", "valu_share", "l1_bytes", "traffic"],
                     "static": "profiles/traffic.json: rocprofv3 --pmc passes of an earlier run of this kernel (separate passes, not collected here)",
                     "launches": len(lat), "ms_per_launch": mean * 1e3, "flop_per_launch": flop}
         fr = prof.get("frame")

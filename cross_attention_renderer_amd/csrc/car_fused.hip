@@ -12,7 +12,7 @@
 //     sources, chained from the accumulators for e_1 and from e_0 read back from the output tensor it was just stored to (L2);
 //   * two tap batches (one row group each: 4 float4) in flight, each issued a whole chunk before it is blended;
 //   * no read-ahead of the weight operands (the third wave hides the LDS latency instead).
-// One workgroup = 12 waves = 192 samples = 48 consecutive rays x 4 consecutive steps (wave = (16-ray bundle, step)); the weight
+// One workgroup = 12 waves = 192 samples = 24 consecutive rays x 8 consecutive steps (wave = 8 rays x 2 steps); the weight
 // stream is shared by 192 samples.  The tap tables are stored compactly (byte offset of the north-west node, four weights).
 // The geometric query g (16 floats per sample) is written out for the second attention round (car_round2.hip recomputes the
 // 16 -> 128 half of query_repeat_embed from it instead of reading a 128-wide row back).
@@ -22,7 +22,19 @@
 namespace {
 
 constexpr int kWaves = 12, kRows = 16, kGroup = kWaves * kRows;      // 192 samples per workgroup
-constexpr int kStepsPerGroup = 4, kBundles = kWaves / kStepsPerGroup;  // 3 bundles of 16 rays x 4 steps
+// A workgroup's 192 samples = kTileRays consecutive rays x kTileSteps consecutive steps; a wave = 8 rays x 2 steps (rows 0-7: the
+// first step, rows 8-15: the second), so the 8 rows of a tap instruction are one step of neighbouring rays.  24 x 8 touches 22 % fewer
+// lattice nodes per workgroup than 48 x 4 (751 vs 964 over the four (view, source) maps of the bench frame; 12 x 16: 804, 96 x 2:
+// 1374 — profiles/round3_fused_experiments.md section 15), i.e. more of a workgroup's tap lines come from its own L1.
+#ifndef CAR_TILE_STEPS
+#define CAR_TILE_STEPS 8
+#endif
+constexpr int kWaveRays = 8, kWaveSteps = kRows / kWaveRays;          // a wave's 16 rows
+constexpr int kTileSteps = CAR_TILE_STEPS, kStepWaves = kTileSteps / kWaveSteps, kRayWaves = kWaves / kStepWaves, kTileRays = kRayWaves * kWaveRays;
+static_assert(kStepWaves * kRayWaves == kWaves && kTileSteps % kWaveSteps == 0, "tile shape");
+// row s of wave w: ray (w / kStepWaves) * 8 + (s & 7), step (w % kStepWaves) * 2 + (s >> 3) of the tile
+__device__ __forceinline__ int tile_ray(int w, int s) { return (w / kStepWaves) * kWaveRays + (s & (kWaveRays - 1)); }
+__device__ __forceinline__ int tile_step(int w, int s) { return (w % kStepWaves) * kWaveSteps + s / kWaveRays; }
 constexpr int kThreads = 64 * kWaves;
 
 constexpr int kPieces = 3;                         // LDS-DMA pieces per chunk: 12 waves x 1 KB each
@@ -114,11 +126,11 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         const int q8 = nblk / 8, r8 = nblk % 8, xcd = blk % 8, idx = blk / 8;
         blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx + a.blk0;
     }
-    // 192 samples = 48 consecutive rays x 4 consecutive steps: wave = (bundle of 16 rays, step), lane & 15 = ray of the bundle, so the
-    // 16 rows a wave gathers together are the same step of neighbouring rays (shared lattice rows)
-    const int pgs = (a.P + kStepsPerGroup - 1) / kStepsPerGroup, bundles = (a.R + kBundles * kRows - 1) / (kBundles * kRows);
+    // the tile's sample of (wave, row lane & 15): tile_ray / tile_step above; the 8 rows a tap instruction gathers are one step of
+    // neighbouring rays (shared lattice rows)
+    const int pgs = (a.P + kTileSteps - 1) / kTileSteps, bundles = (a.R + kTileRays - 1) / kTileRays;
     const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
-    const int ray_i = bun * (kBundles * kRows) + (wave / kStepsPerGroup) * kRows + s, pp = pg * kStepsPerGroup + wave % kStepsPerGroup;
+    const int ray_i = bun * kTileRays + tile_ray(wave, s), pp = pg * kTileSteps + tile_step(wave, s);
     const bool live = ray_i < a.R && pp < a.P;
     const long i = ((long)nn * a.R + (ray_i < a.R ? ray_i : a.R - 1)) * a.P + (pp < a.P ? pp : a.P - 1);
 
@@ -147,7 +159,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     const int P = a.P, V = a.V;
     if (wave < kGroup / 64) {
         const int sg = wave * 64 + lane, gwv = sg >> 4, gs = sg & 15;     // sample sg belongs to row gs of matrix wave gwv
-        const int g_ray = bun * (kBundles * kRows) + (gwv / kStepsPerGroup) * kRows + gs, g_pp = pg * kStepsPerGroup + gwv % kStepsPerGroup;
+        const int g_ray = bun * kTileRays + tile_ray(gwv, gs), g_pp = pg * kTileSteps + tile_step(gwv, gs);
         const bool g_live = g_ray < a.R && g_pp < a.P;
         const long gi = ((long)nn * a.R + (g_ray < a.R ? g_ray : a.R - 1)) * a.P + (g_pp < a.P ? g_pp : a.P - 1);
         const int p = (int)(gi % P);
@@ -454,7 +466,7 @@ int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* r
     a.S = (long)b * V * R * P;
     a.blk0 = blk0;
     a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
-    long groups = (long)b * V * car_div_up(R, kBundles * kRows) * car_div_up(P, kStepsPerGroup);
+    long groups = (long)b * V * car_div_up(R, kTileRays) * car_div_up(P, kTileSteps);
     if (nblk > 0) groups = (groups - blk0 < nblk) ? groups - blk0 : nblk;     // development build: a slice of the sample groups
     void (*kern)(const FusedArgs) = fused_kernel<0>;
 #ifdef CAR_ABLATION
@@ -502,7 +514,7 @@ extern "C" int car_fused_samples_sliced(int nblk, const float* poses, const floa
                                         int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b,
                                         int V, int R, int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt,
                                         float* pixel_val, void* stream) {
-    const long groups = (long)b * V * car_div_up(R, kBundles * kRows) * car_div_up(P, kStepsPerGroup);
+    const long groups = (long)b * V * car_div_up(R, kTileRays) * car_div_up(P, kTileSteps);
     for (long b0 = 0; b0 < groups; b0 += nblk) {
         const int rc = launch_fused(0, (int)b0, nblk, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
                                     logit, pt, pixel_val, stream);

@@ -142,6 +142,22 @@ def main():
                     same_pg = x[:96, :4].reshape(-1)                       # the two bundles at one step group
                     print(f"      one XCD round (96 rays x 64 steps): sum of the 32 workgroups' nodes {per_wg}, union {union} ({union * 2304 / 1e6:.1f} MB, {union * 128 / 1e3:.0f} KB per chunk phase); "
                           f"two neighbouring bundles at one step group: {len(touched(x[:48, :4].reshape(-1)))} + {len(touched(x[48:96, :4].reshape(-1)))} nodes, union {len(touched(same_pg))}")
+                    shapes = []
+                    for rt, st_ in ((192, 1), (96, 2), (48, 4), (24, 8), (12, 16), (6, 32), (3, 64)):     # workgroup tile: rays x steps
+                        t = x[: (R // rt) * rt].view(R // rt, rt, bench.P // st_, st_).permute(0, 2, 1, 3).reshape(-1, 192)
+                        sel = t[torch.linspace(0, t.shape[0] - 1, 256).long()]
+                        shapes.append(f"{rt}x{st_}: {sum(len(touched(r)) for r in sel) / 256:.0f}")
+                    print("      nodes touched per workgroup by tile shape (rays x steps): " + ", ".join(shapes))
+                    comp = []
+                    for nb, np_ in ((4, 8), (8, 4), (16, 2), (32, 1)):         # an XCD round = nb bundles of 24 rays x np_ groups of 8 steps
+                        u = [len(touched(x[24 * nb * k: 24 * nb * (k + 1), 8 * j * np_: 8 * (j + 1) * np_].reshape(-1))) for k in (0, 3) for j in (0, 8 // np_ - 1)]
+                        comp.append(f"{24 * nb} rays x {8 * np_} steps: {sum(u) / len(u):.0f}")
+                    xr = x.view(32, 256, bench.P)                               # [image row][column][step]
+                    for rows_, cols_, np_ in ((4, 24, 8), (8, 12, 8), (4, 48, 4), (8, 24, 4), (16, 12, 4), (8, 96, 1), (32, 24, 1)):   # 2-D pixel blocks
+                        u = [len(touched(xr[r0_: r0_ + rows_, c0_: c0_ + cols_, 8 * j * np_: 8 * (j + 1) * np_].reshape(-1)))
+                             for r0_, c0_ in ((0, 0), (32 - rows_, 120)) for j in (0, 8 // np_ - 1)]
+                        comp.append(f"{rows_} rows x {cols_} cols x {8 * np_} steps: {sum(u) / len(u):.0f}")
+                    print("      nodes touched by one XCD round of 6144 samples, by composition: " + "; ".join(comp))
                     tot = touched(x.reshape(-1))
                     print(f"   view {n} source {sv} ({'own, border' if n == sv else 'other, zeros'}): fetching samples {100 * livef:.1f} %, unique nw nodes per 8-row instruction "
                           f"{uniq8:.2f}, nodes touched per workgroup {uw:.0f} of {192 * 4} tap reads, nodes touched by the launch {len(tot)} "
