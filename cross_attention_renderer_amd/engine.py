@@ -330,7 +330,7 @@ class RenderEngine:
         rc = R
         if ws_bytes(gs, R) > budget:
             per_ray = ws_bytes(gs, 4800) / 4800.0
-            rc = int(budget / per_ray) // 48 * 48            # whole sample groups of the fused kernel (48 rays)
+            rc = int(budget / per_ray) // 48 * 48            # whole sample tiles of the fused kernel (24 rays each)
             if rc < 48:
                 raise RuntimeError(f"forward: {budget / 2**20:.0f} MiB of workspace cannot hold even 48 rays "
                                    f"({ws_bytes(gs, 48) / 2**20:.0f} MiB needed): free device memory")

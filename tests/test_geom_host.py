@@ -149,6 +149,11 @@ def test_merged_lattice_equals_the_sum_of_the_levels(shim, sizes):
     shim.host_lattice_taps(_ptr(gnp), n, lw, lh, pad, float(wm), float(hm), _ptr(node), _ptr(flags), _ptr(w))
     east, south, ring = flags & 1, (flags >> 1) & 1, (flags >> 2) & 1
     assert node.min() >= 0 and (node + east + south * lw).max() < lh * lw
+    # the fused kernel addresses the taps as "node, +1 node, +1 row, +both" without a decode: the north-west node is never in the last
+    # column / row (a point clamped onto the far edge takes the cell before it with weights (0, 1))
+    assert (east == 1).all() and (south == 1).all() and (node % lw).max() <= lw - 2 and (node // lw).max() <= lh - 2
+    far = (gnp[:, 0] > 1.2) & (np.abs(gnp[:, 1]) < 1.0)
+    assert far.any() and np.all(w[far][:, 0] + w[far][:, 2] == 0.0)          # clamped in x: everything on the east taps
     assert np.all(np.abs(w.sum(1) - 1.0) < 1e-6) and w.min() >= 0.0
     idx = np.stack([node, node + east, node + south * lw, node + east + south * lw], 1)
     # bit 2: on or beyond the outer ring, where the zeros-padding lattice is exactly zero (the fused kernel does not fetch those taps)

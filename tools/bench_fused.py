@@ -129,7 +129,7 @@ def main():
                     # one tap instruction = 8 consecutive rays at one step (rows r0 .. r0+7 of a wave): unique 128-byte lines among its 8 rows
                     g8 = x.view(R // 8, 8, bench.P).permute(0, 2, 1).reshape(-1, 8)
                     uniq8 = torch.tensor([len(set(r.tolist()) - {-1}) for r in g8[:4096]]).float().mean().item()
-                    # a workgroup = 48 consecutive rays x 4 consecutive steps; nodes touched by its 4 taps (nw, +1, +row, +row+1)
+                    # the round-3 start tile: 48 consecutive rays x 4 consecutive steps (now 24 x 8, see `shapes` below); nodes touched by its 4 taps (nw, +1, +row, +row+1)
                     wg = x[: (R // 48) * 48].view(R // 48, 48, bench.P // 4, 4).permute(0, 2, 1, 3).reshape(-1, 192)
                     def touched(t):
                         t = t[t >= 0]
