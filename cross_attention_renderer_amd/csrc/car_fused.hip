@@ -18,6 +18,7 @@
 // 16 -> 128 half of query_repeat_embed from it instead of reading a 128-wide row back).
 #include "car_common.h"
 #include "car_geom.h"
+#include <type_traits>
 
 namespace {
 
@@ -44,13 +45,15 @@ constexpr long kMaxMapBytes = 0x80000000L;         // the lattice of one (view, 
 #include "car_fused_mma.h"
 
 constexpr int kLdsStage = kLdsW + 2 * kChunkTiles * kTile;      // [12][16][36]           h tiles, wave private     27 KB
-constexpr int kLdsTapB = kLdsStage + kGroup * kStageLd;         // [192][2] uint          byte offset of the nw node (or kDeadTap)   1.5 KB
-constexpr int kLdsTapW = kLdsTapB + kGroup * 2;                 // [192][2][4]            tap weights (nw, ne, sw, se)    6 KB
-constexpr int kLdsPe = kLdsTapW + kGroup * 8;                   // [192][2][4]            tanh(pt_s/5)                6 KB
-constexpr int kLdsWpt = kLdsPe + kGroup * 8;                    // [144][4][4]            (W1[:,C:C+3], b1 hp) per channel quad: x | y | z | b   9 KB
-constexpr int kLdsBias = kLdsWpt + kC * 4;                      // [672]
+constexpr int kLdsBias = kLdsStage + kGroup * kStageLd;         // [672]
 constexpr int kLdsG = kLdsBias + kBiasFloats;                   // [192][16]              geometric query g per sample 12 KB
-constexpr int kLdsFloats = kLdsG + kGroup * 16;
+// the gather's tables: dead once the two source passes are over — the key layer's second e_0 buffer (kLdsE0) lies over them
+constexpr int kLdsTapB = kLdsG + kGroup * 16;                   // [192][2] uint          byte offset of the nw node (or kDeadTap)   1.5 KB
+constexpr int kLdsTapW = kLdsTapB + kGroup * 2;                 // [192][2][4]            tap weights (nw, ne, sw, se) x hp    6 KB
+constexpr int kLdsPe = kLdsTapW + kGroup * 8;                   // [192][2][4]            tanh(pt_s/5) x hp            6 KB
+constexpr int kLdsWpt = kLdsPe + kGroup * 8;                    // [144][4][4]            (W1[:,C:C+3], b1 hp) per channel quad: x | y | z | b   9 KB
+constexpr int kLdsE0 = kLdsTapB;                                // [12][512]              e_0 rows of a K step, LDS-DMA target (the other buffer: the wave's h tile)
+constexpr int kLdsFloats = (kLdsWpt + kC * 4 > kLdsE0 + kWaves * 512) ? kLdsWpt + kC * 4 : kLdsE0 + kWaves * 512;
 constexpr size_t kLdsBytes = (size_t)kLdsFloats * sizeof(float);
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
@@ -359,30 +362,100 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             if (live) store_rows<kTE>(acc, a.e + i * (2 * kE), q4);
         }
     }
-    // ---- k1 = Wk1 [e_0 ; e_1] + bk1: first the e_1 half, chained from the accumulators; then e_1 is stored and its registers take
-    //      e_0 back from the output tensor (written by this wave one source pass ago: L2), same layout, for the other half ----
+    // ---- k1 = Wk1 [e_0 ; e_1] + bk1: first the e_1 half, chained from the accumulators (each K step's two tiles are stored as soon
+    //      as they are consumed); then the e_0 half, whose B operands come back from the output tensor (written by this wave one source
+    //      pass ago: L2) by LDS-DMA — whole 128-byte lines, no registers, two K steps ahead — instead of 16 half lines per load into
+    //      the accumulator registers (the e traffic made this layer texture-path bound: profiles/round3_fused_experiments.md §16).
     //      Both halves accumulate into the same registers, so they share one per-sample power of two (from max |e_0|, |e_1|).
     float p, pinv;
     pow2_scale(fmaxf(fmaxf(m0, sample_max<kTE, false>(acc)), 1e-30f), p, pinv);
     f32x4 k1[kTD];
     init_bias<kTD>(k1, lds + kLdsBias + kBiasK1, q4, p / lsc[kLayerK1]);
-    // As soon as a K step has taken its two tiles of e_1 they are stored and e_0's tiles are fetched into the same registers: the
-    // 221 KB of e traffic per workgroup trickle through the texture-address path under the layer's MFMAs instead of standing
-    // between the two halves of the layer (and in front of the weight stream of the second half).
     float* erow = a.e + i * (2 * kE) + 4 * q4;
-    auto swap_tiles = [&](int m) {
+    auto store_tiles = [&](int m) {
 #pragma unroll
-        for (int t = 2 * m; t < 2 * m + 2; ++t) {
+        for (int t = 2 * m; t < 2 * m + 2; ++t)
             // unconditional: a lane past the end of the rays / steps works on a clamped duplicate of a live sample and writes that
-            // sample's own values again — and the chunk barrier counts on exactly four memory instructions per call
+            // sample's own values again — and the chunk barrier counts on exactly two memory instructions per call
             *reinterpret_cast<float4*>(erow + kE + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-            acc[t] = *reinterpret_cast<const f32x4*>(erow + 16 * t);
-        }
     };
-    chained_layer<kTE, false, ABL, kG_K1b, 4>(k1, acc, p, a.blob, lds, lane, wave, swap_tiles);
+    chained_layer<kTE, false, ABL, kG_K1b, 2>(k1, acc, p, a.blob, lds, lane, wave, store_tiles);
     mark(7);
-    if constexpr (ABL == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mark(9); }
-    chained_layer<kTE, false, ABL, kG_K1a>(k1, acc, p, a.blob, lds, lane, wave);
+    {
+        constexpr bool kStream = !(ABL == 3 || ABL == 12 || ABL == 5);
+        // lane (r0, qd) fetches 16 bytes of row rr = r0 + 8 it of the wave's tile; a row's eight 16-byte segments are stored rotated
+        // by f(rr) = (rr >> 1) & 7 (the lane asks for segment qd ^ f(rr)), so that the B-operand reads below — 16 rows per pass,
+        // 128 bytes apart — spread over the banks
+        const float* esrc[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int rr = r0 + 8 * it;
+            const int ray_r = bun * kTileRays + tile_ray(wave, rr), pp_r = pg * kTileSteps + tile_step(wave, rr);
+            const long i_r = ((long)nn * a.R + (ray_r < a.R ? ray_r : a.R - 1)) * a.P + (pp_r < a.P ? pp_r : a.P - 1);
+            esrc[it] = a.e + i_r * (2 * kE) + 4 * (qd ^ ((rr >> 1) & 7));
+        }
+        float* const ebuf[2] = {stage, lds + kLdsE0 + wave * 512};
+        auto issue_e0 = [&](int m) {                                   // K step m (channels 32 m .. 32 m + 31) -> buffer m & 1
+            if constexpr (!kStream) return;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(ebuf[m & 1] + it * 256));
+                const float* gsrc = esrc[it] + 32 * m;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+            }
+        };
+        auto wait_vm = [&](auto n) {                                   // at most n of this wave's vector memory operations outstanding
+            if constexpr (!kStream) return;
+            constexpr int N = decltype(n)::value;
+            if constexpr (N >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        constexpr int kSteps = kTE / 2;                                // 9 K steps, two per weight chunk
+        issue_e0(0);
+        issue_e0(1);
+#pragma unroll
+        for (int c = 0; c < kChK1; ++c) {
+            const int g = kG_K1a + c;
+            const float* wl = lds + kLdsW + (g & 1) * kChunkTiles * kTile + 4 * lane;
+            const NextChunk nx = next_chunk(a.blob, lds, g + 1);
+#pragma unroll
+            for (int kl = 0; kl < 2; ++kl) {
+                const int m = 2 * c + kl;
+                if (m < kSteps) {
+                    // vector memory operations issued after e_0(m)'s two: e_0(m + 1)'s, and for the second K step of a chunk the
+                    // chunk's three weight pieces in between
+                    if (kl == 0) { if (m + 1 < kSteps) wait_vm(std::integral_constant<int, 2>()); else wait_vm(std::integral_constant<int, 0>()); }
+                    else { if (m + 1 < kSteps) wait_vm(std::integral_constant<int, 5>()); else wait_vm(std::integral_constant<int, 3>()); }
+                    const float* eb = ebuf[m & 1] + s * 32;
+                    const int rot = (s >> 1) & 7;
+                    const float4 x0 = *reinterpret_cast<const float4*>(eb + 4 * (q4 ^ rot));
+                    const float4 x1 = *reinterpret_cast<const float4*>(eb + 4 * ((4 + q4) ^ rot));
+                    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    half8 bhi, blo;
+                    split8(x, p, bhi, blo);
+#pragma unroll
+                    for (int q = 0; q < kTD / 2; ++q) {
+                        const float* w0 = wl + ((kl * kTD + 2 * q) * 2) * 256;
+                        mfma_pair<ABL>(k1[2 * q], k1[2 * q + 1], w0, w0 + 512, bhi, blo);
+                        if (kl == 0 && q < kPieces) stream_issue_piece<ABL>(nx, q, lane, wave);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (m + 2 < kSteps) issue_e0(m + 2);              // into the buffer just read
+                }
+            }
+            // the weight pieces of the next chunk have landed: behind them only the e_0 rows issued after the K steps of this chunk
+            constexpr int kBehind = 0;
+            if (2 * c + 2 < kSteps && 2 * c + 3 < kSteps) wait_vm(std::integral_constant<int, 4>());
+            else if (2 * c + 2 < kSteps) wait_vm(std::integral_constant<int, 2>());
+            else wait_vm(std::integral_constant<int, 0>());
+            (void)kBehind;
+            if constexpr (kStream && ABL != 11) __syncthreads();
+        }
+    }
     mark(8);
     scale_acc<kTD>(k1, lsc[kLayerK1] * pinv);
     f32x4 key[kTD];

@@ -110,8 +110,8 @@ def main():
         ms = sorted(a.elapsed_time(b_) for a, b_ in lat[2:])
         if v == 4:
             st8 = pixel_val.view(torch.int64)[: (2 * R * bench.P // 192) * 16].view(-1, 16).cpu().double()
-            seq = [0, 1, 2, 3, 4, 7, 9, 8, 5, 6]                  # stamp indices in program order
-            names = ["tables+geometry", "first gather + weights 0", "source pass 0", "source pass 1", "K1 over e_1", "store e_1, reload e_0 (waited)", "K1 over e_0",
+            seq = [0, 1, 2, 3, 4, 7, 8, 5, 6]                     # stamp indices in program order
+            names = ["tables+geometry", "first gather + weights 0", "source pass 0", "source pass 1", "K1 over e_1 (+ its stores)", "K1 over e_0 (LDS-DMA rows)",
                      "K2", "query layers + stores"]
             tot = (st8[:, 6] - st8[:, 0]).mean().item()
             print("phase clock ticks per workgroup (mean over %d groups; s_memtime):" % st8.shape[0])
