@@ -371,13 +371,28 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     pow2_scale(fmaxf(fmaxf(m0, sample_max<kTE, false>(acc)), 1e-30f), p, pinv);
     f32x4 k1[kTD];
     init_bias<kTD>(k1, lds + kLdsBias + kBiasK1, q4, p / lsc[kLayerK1]);
-    float* erow = a.e + i * (2 * kE) + 4 * q4;
+    // row side of the wave's tile: lane (r0, qd) owns 16 bytes (channel quad qd of a 32-channel pair) of rows r0 and r0 + 8 — eight
+    // lanes per 128-byte line of e.  Clamped like i above: a row past the end of the rays / steps is a duplicate of a live sample.
+    long i_row[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int rr = r0 + 8 * it;
+        const int ray_r = bun * kTileRays + tile_ray(wave, rr), pp_r = pg * kTileSteps + tile_step(wave, rr);
+        i_row[it] = ((long)nn * a.R + (ray_r < a.R ? ray_r : a.R - 1)) * a.P + (pp_r < a.P ? pp_r : a.P - 1);
+    }
+    // A K step's two tiles of e_1 are stored as soon as they are consumed — turned through the wave's (idle) h tile, so that the two
+    // store instructions write 8 whole lines each instead of 16 half lines (accumulator layout: four lanes x 16 bytes per row).
     auto store_tiles = [&](int m) {
 #pragma unroll
-        for (int t = 2 * m; t < 2 * m + 2; ++t)
-            // unconditional: a lane past the end of the rays / steps works on a clamped duplicate of a live sample and writes that
-            // sample's own values again — and the chunk barrier counts on exactly two memory instructions per call
-            *reinterpret_cast<float4*>(erow + kE + 16 * t) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<float4*>(stage + s * kStageLd + 16 * j + 4 * q4) = make_float4(acc[2 * m + j][0], acc[2 * m + j][1], acc[2 * m + j][2], acc[2 * m + j][3]);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            // unconditional (duplicates write their sample's own values again) — the chunk barrier counts on exactly two memory
+            // instructions per call
+            const float4 v = *reinterpret_cast<const float4*>(stage + (r0 + 8 * it) * kStageLd + 4 * qd);
+            *reinterpret_cast<float4*>(a.e + i_row[it] * (2 * kE) + kE + 32 * m + 4 * qd) = v;
+        }
     };
     chained_layer<kTE, false, ABL, kG_K1b, 2>(k1, acc, p, a.blob, lds, lane, wave, store_tiles);
     mark(7);
@@ -388,12 +403,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         // 128 bytes apart — spread over the banks
         const float* esrc[2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int rr = r0 + 8 * it;
-            const int ray_r = bun * kTileRays + tile_ray(wave, rr), pp_r = pg * kTileSteps + tile_step(wave, rr);
-            const long i_r = ((long)nn * a.R + (ray_r < a.R ? ray_r : a.R - 1)) * a.P + (pp_r < a.P ? pp_r : a.P - 1);
-            esrc[it] = a.e + i_r * (2 * kE) + 4 * (qd ^ ((rr >> 1) & 7));
-        }
+        for (int it = 0; it < 2; ++it) esrc[it] = a.e + i_row[it] * (2 * kE) + 4 * (qd ^ (((r0 + 8 * it) >> 1) & 7));
         float* const ebuf[2] = {stage, lds + kLdsE0 + wave * 512};
         auto issue_e0 = [&](int m) {                                   // K step m (channels 32 m .. 32 m + 31) -> buffer m & 1
             if constexpr (!kStream) return;
