@@ -359,7 +359,23 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         mark(3 + sv);
         if (sv == 0) {
             m0 = sample_max<kTE, false>(acc);
-            if (live) store_rows<kTE>(acc, a.e + i * (2 * kE), q4);
+            // e_0 out, as whole lines: the wave's h tile is free between the B-operand read that closed the pass and the next chunk's
+            // first h rows, so each pair of tiles is turned through it (accumulator layout: four lanes x 16 bytes per row; row layout:
+            // eight lanes per 128-byte line).  The 18 half-line stores this replaces stood in front of the next pass's first barrier.
+#pragma unroll
+            for (int m = 0; m < kTE / 2; ++m) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    *reinterpret_cast<float4*>(stage + s * kStageLd + 16 * j + 4 * q4) = make_float4(acc[2 * m + j][0], acc[2 * m + j][1], acc[2 * m + j][2], acc[2 * m + j][3]);
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int rr = r0 + 8 * it;
+                    const int ray_r = bun * kTileRays + tile_ray(wave, rr), pp_r = pg * kTileSteps + tile_step(wave, rr);
+                    const long i_r = ((long)nn * a.R + (ray_r < a.R ? ray_r : a.R - 1)) * a.P + (pp_r < a.P ? pp_r : a.P - 1);
+                    const float4 v = *reinterpret_cast<const float4*>(stage + rr * kStageLd + 4 * qd);
+                    *reinterpret_cast<float4*>(a.e + i_r * (2 * kE) + 32 * m + 4 * qd) = v;      // rows past the end: duplicates, same values
+                }
+            }
         }
     }
     // ---- k1 = Wk1 [e_0 ; e_1] + bk1: first the e_1 half, chained from the accumulators (each K step's two tiles are stored as soon
