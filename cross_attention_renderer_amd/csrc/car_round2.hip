@@ -26,24 +26,7 @@ constexpr int kLdsBias = kLdsW1 + kNT * 512;                        // br1 [128]
 constexpr int kLdsStage = kLdsBias + 2 * kD + 4;                    // [8 waves][32 rows][36]
 constexpr size_t kLdsBytes = (size_t)(kLdsStage + kWaves * 32 * kStageLd) * sizeof(float);
 
-// x[8] * p -> fp16 hi/lo halves (round toward zero; x*p - hi is exact in fp32)
-__device__ __forceinline__ void split8(const float (&x)[8], float p, half8& hi, half8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        const float a = x[e] * p, b = x[e + 1] * p;
-        const fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(a, b);
-        const fp16x2 l2 = __builtin_amdgcn_cvt_pkrtz(a - (float)h2[0], b - (float)h2[1]);
-        hi[e] = (_Float16)h2[0]; hi[e + 1] = (_Float16)h2[1];
-        lo[e] = (_Float16)l2[0]; lo[e + 1] = (_Float16)l2[1];
-    }
-}
-// power of two p with m * p in [2^13, 2^14) (m > 0, clamped for tiny / huge m), and 1/p
-__device__ __forceinline__ void pow2_scale(float m, float& p, float& inv) {
-    int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
-    e = e < 97 ? 97 : (e > 230 ? 230 : e);          // p in [2^-90, 2^43]: an all-zero vector or matrix must not push p_x * p_W past fp32
-    p = __uint_as_float((unsigned)(267 - e) << 23);
-    inv = __uint_as_float((unsigned)(e - 13) << 23);
-}
+#include "car_split.h"
 
 __global__ void __launch_bounds__(512) round2_kernel(const float* __restrict__ g, const float* __restrict__ uh,
                                                      const float* __restrict__ qry, const float* __restrict__ wpacked,
