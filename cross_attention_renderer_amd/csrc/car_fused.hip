@@ -9,11 +9,15 @@
 //
 // Three waves per SIMD (<= 168 registers per wave), which needs
 //   * the key layer's accumulators (k1, 32 registers) out of the e path: k1 = Wk1 [e_0 ; e_1] is computed after both
-//     sources, chained from the accumulators for e_1 and from e_0 read back from the output tensor it was just stored to (L2);
+//     sources, chained from the accumulators for e_1; e_0 comes back from the output tensor it was just stored to (L2) by
+//     LDS-DMA, straight into B-operand tiles in LDS;
 //   * two tap batches (one row group each: 4 float4) in flight, each issued a whole chunk before it is blended;
 //   * no read-ahead of the weight operands (the third wave hides the LDS latency instead).
 // One workgroup = 12 waves = 192 samples = 24 consecutive rays x 8 consecutive steps (wave = 8 rays x 2 steps); the weight
 // stream is shared by 192 samples.  The tap tables are stored compactly (byte offset of the north-west node, four weights).
+// Every vector instruction in the chunk loop costs matrix-pipe time (a SIMD issues either), and every memory instruction ahead of a
+// chunk barrier is waited for (in-order vmcnt): tap addresses need no decode, the first layer's scale is folded into its operands,
+// e leaves as whole 128-byte lines (turned through the wave's LDS tile).  profiles/round3_fused_experiments.md has the measurements.
 // The geometric query g (16 floats per sample) is written out for the second attention round (car_round2.hip recomputes the
 // 16 -> 128 half of query_repeat_embed from it instead of reading a 128-wide row back).
 #include "car_common.h"
