@@ -109,3 +109,31 @@ def test_training_entry_point_runs_and_writes_reference_style_checkpoints(tmp_pa
     assert set(ck) == {"model", "optimizer"} and "query_encode_latent.weight" in ck["model"] and ck["optimizer"]["state"]
     first, last = [float(x) for x in out.stdout.split("loss ")[-1].split(";")[0].split(" -> ")]
     assert first == first and last == last                      # finite
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_line_with_the_contract_fields():
+    """`python bench.py` (small K / W, a 256-ray CPU sample): the last stdout line is ONE JSON object with the fields the driver reads —
+    metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config —
+    plus the `roofline` (bound in {hbm, mfma}, achieved / peak / unit / frac / traffic) and `cpu_baseline` objects."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-rays", "256"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "rendered_rays_per_sec" and d["unit"] == "rays/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0.0 < r["frac"] < 1.0 and r["traffic"] is not None and set(r["live_fields"]).isdisjoint(r["static_fields"])
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
