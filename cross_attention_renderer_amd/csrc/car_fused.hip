@@ -478,11 +478,9 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
                 }
             }
             // the weight pieces of the next chunk have landed: behind them only the e_0 rows issued after the K steps of this chunk
-            constexpr int kBehind = 0;
             if (2 * c + 2 < kSteps && 2 * c + 3 < kSteps) wait_vm(std::integral_constant<int, 4>());
             else if (2 * c + 2 < kSteps) wait_vm(std::integral_constant<int, 2>());
             else wait_vm(std::integral_constant<int, 0>());
-            (void)kBehind;
             if constexpr (kStream && ABL != 11) __syncthreads();
         }
     }
