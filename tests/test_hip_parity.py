@@ -331,8 +331,9 @@ def test_forward_split_into_several_calls_is_bit_identical(name, ws_mib, level_m
 
 @pytest.mark.parametrize("R,P,b", [(37, 13, 1), (16, 8, 2), (131, 70, 1), (96, 32, 5)])
 def test_fused_path_ragged_sizes_against_the_oracle(R, P, b):
-    """Ray counts that are no multiple of 16 and sample counts that are no multiple of 8 (the fused kernel works on groups of
-    16 rays x 8 steps, the round-2 kernel on blocks of 32 samples): real widths, H = 64, rays picked across the frame."""
+    """Ray counts that are no multiple of 24 and sample counts that are no multiple of 8 (the fused kernel works on tiles of
+    24 rays x 8 steps — rows past the end are clamped duplicates that write their sample's values again — the round-2 kernel on blocks
+    of 32 samples): real widths, H = 64, rays picked across the frame."""
     from cross_attention_renderer_amd import synthetic as S
     from cross_attention_renderer_amd.models import CrossAttentionRenderer
     dev = torch.device("cuda:0")
