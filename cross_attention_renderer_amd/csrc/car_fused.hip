@@ -120,6 +120,8 @@ __device__ __forceinline__ NextChunk next_chunk_w2(const float* __restrict__ blo
 // 4: the full kernel with shader-clock stamps at its phase boundaries (written over pixel_val);
 // 20: the full kernel with shader-clock sums per piece of the chunk loop (where a wave waits inside a chunk)
 // 21: the full kernel, writing each sample's north-west lattice node per source (-1: no fetch) over pixel_val (tap statistics)
+// 22: every tap inside a 1 MB window of its lattice (L2 hits); 28: inside 32 nodes (L1 hits); 23: no weight DMA (barriers kept); 24 = 22 + 23;
+// 30-33: the weight DMA with cache-policy bits nt / sc1 / sc0 sc1 / sc0
 template <int ABL>
 __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -143,7 +145,12 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
 
     // ABL 4 (development build): the full kernel, plus shader-clock stamps of wave 0 at the phase boundaries, written over pixel_val
     long long stamp[12];
-    auto mark = [&](int k) { if constexpr (ABL == 4) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); };
+#ifdef CAR_STAMP_ALL
+    constexpr bool kStamp = true;
+#else
+    constexpr bool kStamp = (ABL == 4);
+#endif
+    auto mark = [&](int k) { if constexpr (kStamp) stamp[k] = (long long)__builtin_amdgcn_s_memtime(); };
     mark(0);
     // Scale of the first layer's output h (split-fp16 arithmetic, car_fused_mma.h): h is bounded by the largest lattice value plus the
     // point / bias term (the tap weights are non-negative and sum to at most one, |tanh| <= 1): one power of two hp per launch.
@@ -195,7 +202,10 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             // texture path nothing (profiles/round3_fused_experiments.md) — and weight zero makes the contribution exactly +-0
             const bool dead = mode == 1 && (flags & 4);
             if constexpr (ABL == 21) { if (g_live) reinterpret_cast<int*>(a.pixel_val)[2 * gi + sv] = dead ? -1 : node; }      // tools/bench_fused.py 21: tap statistics
-            reinterpret_cast<unsigned*>(lds + kLdsTapB)[sg * 2 + sv] = dead ? kDeadTap : (unsigned)node * (unsigned)(kC * 4);
+            unsigned tap_off = (unsigned)node * (unsigned)(kC * 4);
+            if constexpr (ABL == 22 || ABL == 24) tap_off = (unsigned)(node % 448) * (unsigned)(kC * 4);       // timing probe: every tap inside a 1 MB window (L2 hits)
+            if constexpr (ABL == 28) tap_off = (unsigned)(gs & 7) * (unsigned)(kC * 4);                        // timing probe: 32 nodes in all (L1 hits)
+            reinterpret_cast<unsigned*>(lds + kLdsTapB)[sg * 2 + sv] = dead ? kDeadTap : tap_off;
             *reinterpret_cast<float4*>(lds + kLdsTapW + (sg * 2 + sv) * 4) =
                 dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w[0] * hp, w[1] * hp, w[2] * hp, w[3] * hp);
             const float px = sv == 0 ? smp.pt_in[0][0] : smp.pt_in[1][0], py = sv == 0 ? smp.pt_in[0][1] : smp.pt_in[1][1],
@@ -203,7 +213,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + sv) * 4) = make_float4(tanhf(px / 5.0f) * hp, tanhf(py / 5.0f) * hp, tanhf(pz / 5.0f) * hp, 0.0f);
         }
         if (g_live) {
-            if constexpr (ABL != 4 && ABL != 20 && ABL != 21) { a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1]; }
+            if constexpr (!kStamp && ABL != 20 && ABL != 21) { a.pixel_val[2 * gi] = smp.grid[0]; a.pixel_val[2 * gi + 1] = smp.grid[1]; }
             a.pt[3 * gi + 0] = smp.pt[0]; a.pt[3 * gi + 1] = smp.pt[1]; a.pt[3 * gi + 2] = smp.pt[2];
         }
         float* gl = lds + kLdsG + sg * 16;
@@ -225,7 +235,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     float4 hacc[2];
     f32x4 bufA[4], bufB[4];
     const unsigned qd16 = 16u * qd;
-    const unsigned row_step = (unsigned)a.lw * (kC * 4);
+    const unsigned row_step = (ABL == 22 || ABL == 24 || ABL == 28) ? 16u * (kC * 4) : (unsigned)a.lw * (kC * 4);
 
     // Buffer loads, range-checked against ONE (view, padding mode) lattice: the workgroup's samples all lie on the epipolar lines of
     // context view nn % V, so source view sv reads the border-padded lattice of that view when sv is the view itself and the
@@ -247,6 +257,12 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         tap[1] = ld(o00 + (unsigned)(kC * 4));
         tap[2] = ld(o10);
         tap[3] = ld(o10 + (unsigned)(kC * 4));
+    };
+    auto issue_tap = [&](f32x4 (&tap)[4], int sv, int c, int it, int t) {          // development build (ABL 43): one tap of a batch
+        const int chunk_off = 128 * c;
+        const unsigned tbv = reinterpret_cast<const unsigned*>(lds + kLdsTapB)[(wave * kRows + r0 + 8 * it) * 2 + sv];
+        const unsigned o = tbv + qd16 + ((t & 2) ? row_step : 0u) + ((t & 1) ? (unsigned)(kC * 4) : 0u);
+        tap[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc[sv], (int)o, chunk_off, 0));
     };
     auto blend_row = [&](const f32x4 (&tap)[4], int sv, int it) {
         if constexpr (ABL == 2 || ABL == 3 || ABL == 12) return;
@@ -336,6 +352,16 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             // DMA pieces, slot 0 the affine start values, slots 3 and 6 one row group each — blend, store the h rows, re-issue.
             auto piece = [&](int qs) {
                 if (qs < kPieces) { const long long t0 = tick(); stream_issue_piece<ABL>(nx, qs, lane, wave); t_piece += tick() - t0; }
+                if constexpr (ABL == 43) {                             // the eight tap loads spread over slots 3-8, one or two per slot
+                    if (qs == 0) { affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); }
+                    else if (qs == 3) { blend_row(bufA, nsv, 0); finish_row(0); issue_tap(bufA, n2sv, n2c, 0, 0); }
+                    else if (qs == 4) issue_tap(bufA, n2sv, n2c, 0, 1);
+                    else if (qs == 5) issue_tap(bufA, n2sv, n2c, 0, 2);
+                    else if (qs == 6) { issue_tap(bufA, n2sv, n2c, 0, 3); blend_row(bufB, nsv, 1); finish_row(1); issue_tap(bufB, n2sv, n2c, 1, 0); }
+                    else if (qs == 7) issue_tap(bufB, n2sv, n2c, 1, 1);
+                    else if (qs == 8) { issue_tap(bufB, n2sv, n2c, 1, 2); issue_tap(bufB, n2sv, n2c, 1, 3); }
+                    return;
+                }
                 if (qs == 0) { const long long t0 = tick(); affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); t_aff += tick() - t0; }
                 else if (qs == 3) { const long long t0 = tick(); blend_row(bufA, nsv, 0); const long long t1 = tick(); finish_row(0); issue_row(bufA, n2sv, n2c, 0); t_blend += t1 - t0; t_issue += tick() - t1; }
                 else if (qs == 6) { const long long t0 = tick(); blend_row(bufB, nsv, 1); const long long t1 = tick(); finish_row(1); issue_row(bufB, n2sv, n2c, 1); t_blend += t1 - t0; t_issue += tick() - t1; }
@@ -357,6 +383,11 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
                 t_dma += t1 - t0; t_bar += tick() - t1; t_chunks += 1;
             } else
             stream_sync<ABL, kTapsLive ? 8 : 0>();
+            if constexpr (ABL == 40 || ABL == 41 || ABL == 42) {       // development build: the three waves of a SIMD (w, w + 4, w + 8) leave the barrier apart
+                constexpr int kS = ABL == 40 ? 4 : ABL == 41 ? 8 : 2;
+                if (wave >= 4) __builtin_amdgcn_s_sleep(kS);
+                if (wave >= 8) __builtin_amdgcn_s_sleep(kS);
+            }
             ++g;
         }
         scale_acc<kTE>(acc, e_down);
@@ -537,7 +568,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             out[0] = t_blend; out[1] = t_dma; out[2] = t_bar; out[3] = t_chunks; out[4] = t_issue; out[5] = t_piece; out[6] = t_aff; out[7] = t_mfma;
         }
     }
-    if constexpr (ABL == 4) {
+    if constexpr (kStamp) {
         if (tid == 0) {
             long long* out = reinterpret_cast<long long*>(a.pixel_val) + (long)blk * 16;
             for (int k = 0; k < 10; ++k) out[k] = stamp[k];
@@ -556,7 +587,7 @@ int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* r
     CAR_REQUIRE(lat_pad >= 2 && lat_h > 2 * lat_pad + 1 && lat_w > 2 * lat_pad + 1 && ((lat_h - 2 * lat_pad) & 1) && ((lat_w - 2 * lat_pad) & 1),
                 "car_fused_samples: bad lattice %d x %d, pad %d (car_lattice_shape)", lat_h, lat_w, lat_pad);
     // nodes are addressed by 32-bit byte offsets inside the lattice of one (view, padding mode)
-    CAR_REQUIRE((long)lat_h * lat_w * (kC * 4) < kMaxMapBytes, "car_fused_samples: a lattice of %d x %d nodes exceeds 4 GiB per view", lat_h, lat_w);
+    CAR_REQUIRE((long)lat_h * lat_w * (kC * 4) < kMaxMapBytes, "car_fused_samples: a lattice of %d x %d nodes exceeds 2 GiB per view and padding mode (finest level wider than ~470 pixels): use the stage entries", lat_h, lat_w);
     FusedArgs a;
     a.poses = (const CarPose*)poses; a.rays = (const CarRay*)rays; a.steps = steps;
     a.lattice = lattice; a.lh = lat_h; a.lw = lat_w; a.pad = lat_pad;
@@ -575,7 +606,11 @@ int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* r
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 4: kern = fused_kernel<4>; break;   case 5: kern = fused_kernel<5>; break;   case 11: kern = fused_kernel<11>; break;
         case 12: kern = fused_kernel<12>; break;   case 13: kern = fused_kernel<13>; break;   case 20: kern = fused_kernel<20>; break;
-        case 21: kern = fused_kernel<21>; break;
+        case 21: kern = fused_kernel<21>; break;   case 22: kern = fused_kernel<22>; break;   case 23: kern = fused_kernel<23>; break;
+        case 24: kern = fused_kernel<24>; break;   case 28: kern = fused_kernel<28>; break;   case 30: kern = fused_kernel<30>; break;
+        case 31: kern = fused_kernel<31>; break;   case 32: kern = fused_kernel<32>; break;   case 33: kern = fused_kernel<33>; break;
+        case 40: kern = fused_kernel<40>; break;   case 41: kern = fused_kernel<41>; break;   case 42: kern = fused_kernel<42>; break;
+        case 43: kern = fused_kernel<43>; break;
         default: break;
     }
 #else

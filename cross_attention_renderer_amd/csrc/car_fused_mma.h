@@ -41,7 +41,7 @@ __device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, 
 // LDS-DMA in inline asm, see car_linear.hip.  Must only run after the barrier that retired the buffer's previous chunk.
 template <int ABL = 0>
 __device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, int lane, int wave) {
-    if constexpr (ABL == 3 || ABL == 12 || ABL == 5) return;
+    if constexpr (ABL == 3 || ABL == 12 || ABL == 5 || ABL == 23 || ABL == 24) return;      // 23 / 24: no weight DMA, barriers kept
     int kb = kWaves * p + wave;
     kb = kb < n.nkb ? kb : kb - n.nkb;
     kb = kb < n.nkb ? kb : kb - n.nkb;
@@ -50,8 +50,14 @@ __device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, in
     const float* gsrc = n.src + kb * 256;
     const unsigned voff = 16u * (unsigned)lane;
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(gsrc) : "memory");
+#define CAR_DMA_PIECE(POLICY) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" POLICY "\n\ts_mov_b32 m0, %0" \
+                                           : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(gsrc) : "memory")
+    if constexpr (ABL == 30) CAR_DMA_PIECE(" nt");                    // development build: cache-policy probes of the weight stream
+    else if constexpr (ABL == 31) CAR_DMA_PIECE(" sc1");
+    else if constexpr (ABL == 32) CAR_DMA_PIECE(" sc0 sc1");
+    else if constexpr (ABL == 33) CAR_DMA_PIECE(" sc0");
+    else CAR_DMA_PIECE("");
+#undef CAR_DMA_PIECE
 }
 template <int ABL = 0>
 __device__ __forceinline__ void stream_issue_all(const float* __restrict__ blob, float* lds, int g, int lane, int wave) {

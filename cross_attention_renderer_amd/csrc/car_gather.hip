@@ -273,6 +273,7 @@ int launch_gather(int cfg, const GatherLevels& L, int n_maps, const float* grid,
             ok = ok && quads > 0 && (quads & (quads - 1)) == 0 && (quads <= 64 || quads % 64 == 0);
             WL.lpr[l] = quads < 64 ? quads : 64;
             WL.rpt[l] = 64 / WL.lpr[l];
+            ok = ok && WL.rpt[l] <= kWRows;                            // a 4-channel level (64 rows per task > the group's 32) takes the per-float4 kernel
             const int segs = quads / WL.lpr[l];
             WL.lpr_shift[l] = WL.seg_shift[l] = 0;
             while ((1 << WL.lpr_shift[l]) < WL.lpr[l]) ++WL.lpr_shift[l];

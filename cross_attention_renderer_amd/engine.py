@@ -76,6 +76,10 @@ class RenderEngine:
         self._steps: Dict[tuple, Tensor] = {}
         self.linear_flags = 0          # tests may set NO_GLDS for A/B
         self.pose_records = None       # tests: (b*V, 96) CarPose records to use instead of the host pose algebra
+        # "host": the reference's torch.inverse on the CPU wherever the cameras live (strict parity; cameras on the GPU cost one small
+        # download per new pose); "device": car_pose_setup when the cameras are on the GPU (no host round trip, budgeted parity)
+        # -> the module's ``pose_route`` attribute (scripts set it before the first forward creates the engine)
+        self.last_pose_sync_ms = 0.0
         # first point-MLP layer as a gather over per-texel pre-projected maps (csrc/car_encode.hip) instead of a
         # K=579 GEMM per sample; False selects the literal gather -> GEMM pipeline (A/B and stage tests)
         self.project_maps = True
@@ -86,6 +90,8 @@ class RenderEngine:
         # sizing of the one-call route (tests shrink them to force several calls)
         self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
         self.max_level_bytes: Optional[int] = None         # tests: lattice bytes of one call (forces scene groups); None = no limit
+        self.max_pair_bytes: Optional[int] = None          # tests: bytes of one lattice buffer (forces lattice groups, each projected on its own)
+        self.last_pair_groups = 1      # number of lattice buffers (car_project_maps calls' scene groups) of the last forward
         self.last_calls = 0            # number of car_render_forward calls the last forward was split into
         self._round2_key = None
         self._round2 = None
@@ -101,6 +107,16 @@ class RenderEngine:
         self._pair_key = None
         self._pair: Optional[Tensor] = None
         self._work: Optional[Tensor] = None
+
+    @property
+    def pose_route(self) -> str:
+        return getattr(self.m, "pose_route", "host")
+
+    @pose_route.setter
+    def pose_route(self, route: str) -> None:
+        if route not in ("host", "device"):
+            raise ValueError("pose_route must be 'host' or 'device'")
+        self.m.pose_route = route
 
     # ------------------------------------------------------------------ weights
     def _weights(self, device) -> Dict[str, PackedLinear]:
@@ -179,34 +195,65 @@ class RenderEngine:
                                               _stream()), "car_gather_encode")
 
     def _poses(self, inp, H: int, n: int, dev) -> Tensor:
-        """Device pose records (``struct CarPose``) for this input (models.py:207-211, 285-286).  The 4x4 algebra runs where the
-        camera matrices live, as ``torch.inverse`` / ``matmul`` would in the reference:
-          * cameras on the GPU (the reference's scripts move the whole input dict there, render_realestate10k_traj.py:85):
-            ``car_pose_setup`` on the device — no host round trip, nothing to wait for between frames;
-          * cameras on the CPU: the reference's own calls on the host (poses.pack_poses) and one small upload, cached on the
-            identity/version of the four camera tensors (a frame rendered in chunks uploads once).
-        The two differ in the last ulp of the matrices (fp64 Gauss-Jordan vs LAPACK in fp32), which the fp64 Pluecker intersection
-        amplifies on the few samples whose pixel ray is nearly parallel to the query ray — as it does between two LAPACK builds."""
+        """Device pose records (``struct CarPose``) for this input (models.py:207-211, 285-286).
+
+        ``pose_route == "host"`` (the default, the strict-parity route): the reference's own ``torch.inverse`` / ``matmul`` calls on
+        the host CPU (poses.pack_poses) wherever the four camera tensors live.  Cameras that arrive on the GPU — the reference's
+        scripts move the whole input dict there (render_realestate10k_traj.py:85) — are copied to the host first: ONE pinned
+        download of the 4x4 matrices (a few hundred bytes; the stream is synchronised once, which the reference does on every
+        call anyway, models.py:570), then one pinned upload of the records.  Cached on the identity/version of the four tensors, so a
+        frame rendered in chunks pays once.  ``last_pose_sync_ms`` holds the host time of the last such round trip.
+        ``pose_route == "device"`` (opt-in; ``--cameras device`` of the scripts): ``car_pose_setup`` on the device when the cameras
+        are there — no host round trip, but fp64 Gauss-Jordan instead of LAPACK's fp32: the matrices differ in the last ulp, which
+        the fp64 Pluecker intersection amplifies on the few samples whose pixel ray is nearly parallel to the query ray
+         — as it does between two LAPACK builds."""
         if self.pose_records is not None:
             poses = self.pose_records.float().contiguous()
             if tuple(poses.shape) != (n, 96):
                 raise ValueError(f"pose records must have shape ({n}, 96)")
             return poses.to(dev, non_blocking=True)
+        if self.pose_route not in ("host", "device"):
+            raise ValueError("RenderEngine.pose_route must be 'host' or 'device'")
         ts = (inp["context"]["cam2world"], inp["context"]["intrinsics"], inp["query"]["cam2world"], inp["query"]["intrinsics"])
-        if all(t.is_cuda for t in ts):
+        on_gpu = all(t.is_cuda for t in ts)
+        if self.pose_route == "device" and on_gpu:
             b, V = ts[0].shape[:2]
             c2w, Kc, c2w_q, Kq = [t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in ts]
             poses = torch.empty(n, 96, device=dev, dtype=torch.float32)
             _lib.check(self.lib.car_pose_setup(_ptr(c2w), _ptr(c2w_q), _ptr(Kc), _ptr(Kq), b, V, H, _ptr(poses), _stream()),
                        "car_pose_setup")
             return poses
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts) + (H, str(dev))
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in ts) + (H, str(dev))
         if key != self._pose_key:
+            src = inp
+            if any(t.is_cuda for t in ts):
+                import time
+                t0 = time.perf_counter()
+                src = self._cameras_to_host(ts)
+                self.last_pose_sync_ms = (time.perf_counter() - t0) * 1e3
             # pinned staging: the 768-byte upload is queued behind the previous frame's kernels instead of waiting for them
-            self._pose_dev = pack_poses(inp, H).pin_memory().to(dev, non_blocking=True)
+            self._pose_dev = pack_poses(src, H).pin_memory().to(dev, non_blocking=True)
             self._pose_key = key
             self._pose_src = ts                      # keep the tensors alive so data_ptr cannot be recycled
         return self._pose_dev
+
+    @staticmethod
+    def _cameras_to_host(ts):
+        """The four camera tensors as CPU tensors in the input dict's shape, through ONE device-to-host copy (tensors already on the
+        host are passed through)."""
+        gpu = [t for t in ts if t.is_cuda]
+        flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in gpu])
+        host = torch.empty(flat.numel(), dtype=torch.float32, pin_memory=True)
+        host.copy_(flat, non_blocking=True)
+        torch.cuda.current_stream(flat.device).synchronize()
+        out, off = [], 0
+        for t in ts:
+            if t.is_cuda:
+                out.append(host[off:off + t.numel()].view(t.shape).clone())
+                off += t.numel()
+            else:
+                out.append(t)
+        return {"context": {"cam2world": out[0], "intrinsics": out[1]}, "query": {"cam2world": out[2], "intrinsics": out[3]}}
 
     def _linspace(self, a: float, b_: float, P: int, device) -> Tensor:
         k = (a, b_, P, str(device))
@@ -274,18 +321,22 @@ class RenderEngine:
         self._pair_key = None
         return plan
 
-    def _pair_for(self, d, plan: Tensor, z: List[Tensor], device) -> Tensor:
-        """car_project_maps: the first point-MLP layer applied per texel of the pyramid, once per stereo pair (and weights)."""
+    def _pair_for(self, plan: Tensor, z: List[Tensor], device, s0: int, s1: int, R: int):
+        """car_project_maps for scenes [s0, s1): the first point-MLP layer applied per texel of the pyramid and every level summed on the
+        common lattice, once per stereo pair (and weights).  Returns (buffer, its car_dims).  One buffer is cached: the whole batch
+        normally; when the lattices of all scenes do not fit the device memory (_render_one_call) the last group's."""
         maps = self._channel_last(z)
-        key = (self._maps_key, self._plan_key)
+        V = self.m.n_view
+        d = self._dims(s1 - s0, R, z)
+        key = (self._maps_key, self._plan_key, s0, s1)
         if key != self._pair_key or self._pair is None:
             lib = self.lib
             self._pair = None                                # release the previous pair's maps before allocating
             pair = torch.empty(lib.car_gmaps_floats(ctypes.byref(d)), device=device, dtype=torch.float32)
-            ptrs = (ctypes.c_void_p * len(maps))(*[t.data_ptr() for t in maps])
+            ptrs = (ctypes.c_void_p * len(maps))(*[t[s0 * V:s1 * V].data_ptr() for t in maps])
             _lib.check(lib.car_project_maps(ctypes.byref(d), _ptr(plan), ptrs, _ptr(pair), _stream()), "car_project_maps")
             self._pair, self._pair_key = pair, key
-        return self._pair
+        return self._pair, d
 
     @staticmethod
     def _common_lattice(z: List[Tensor]) -> bool:
@@ -295,13 +346,22 @@ class RenderEngine:
         hm, wm = max(h for h, _ in sizes), max(w for _, w in sizes)
         return all(hm % h == 0 and wm % w == 0 and hm // h == wm // w for h, w in sizes)
 
-    def _workspace_budget(self, device) -> int:
-        if self.max_workspace_bytes is not None:
-            return int(self.max_workspace_bytes)
+    def _lattice_fits(self, b: int, R: int, z: List[Tensor]) -> bool:
+        """car_fused_samples addresses the lattice of one (view, padding mode) with 32-bit byte offsets below 2 GiB (a finest level
+        up to ~470 pixels wide at 576 channels); wider pyramids take the stage route, which has no such limit."""
+        lh, lw, lpad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.lib.car_lattice_shape(ctypes.byref(self._dims(b, R, z)), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(lpad)), "car_lattice_shape")
+        return lh.value * lw.value * 576 * 4 < 2**31
+
+    def _free_budget(self, device) -> int:
+        """85 % of what this engine could allocate now: free device memory, the caching allocator's idle blocks, its own workspace."""
         free, _ = torch.cuda.mem_get_info(device)
         cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
         mine = self._work.numel() * 4 if self._work is not None else 0
         return int(0.85 * (free + cached + mine))
+
+    def _workspace_budget(self, device) -> int:
+        return int(self.max_workspace_bytes) if self.max_workspace_bytes is not None else self._free_budget(device)
 
     def _render_one_call(self, inp, z, poses, uv, steps, b, V, R, P, H, W, debug) -> Dict[str, Tensor]:
         m, lib = self.m, self.lib
@@ -310,35 +370,33 @@ class RenderEngine:
         n = b * V
         d_all = self._dims(b, R, z)
         plan = self._plan_for(d_all, dev)
-        pair = self._pair_for(d_all, plan, z, dev)
         lh, lw, lpad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _lib.check(lib.car_lattice_shape(ctypes.byref(d_all), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(lpad)), "car_lattice_shape")
         lattice_scene = V * 2 * lh.value * lw.value * 576                                        # floats per scene
-        gmeta_ptr = pair.data_ptr() + 4 * lib.car_gmeta_offset(ctypes.byref(d_all))
-
-        # scenes per call: any number (the fused kernel addresses the lattice of ONE view and padding mode with 32-bit offsets);
-        # max_level_bytes lets tests force scene groups.  Rays per call: the workspace (~0.44 MB per ray at 64 samples) must fit the
-        # free memory.  Rays and scenes are independent, so the split is exact.
-        gs = b if self.max_level_bytes is None else max(1, min(b, self.max_level_bytes // (4 * lattice_scene)))
-        budget = self._workspace_budget(dev)
 
         def ws_bytes(nb, nr):
             return lib.car_workspace_bytes(ctypes.byref(self._dims(nb, nr, z)))
 
-        while gs > 1 and ws_bytes(gs, R) > budget:
-            gs = (gs + 1) // 2
-        rc = R
-        if ws_bytes(gs, R) > budget:
-            per_ray = ws_bytes(gs, 4800) / 4800.0
-            rc = int(budget / per_ray) // 48 * 48            # whole sample tiles of the fused kernel (24 rays each)
-            if rc < 48:
-                raise RuntimeError(f"forward: {budget / 2**20:.0f} MiB of workspace cannot hold even 48 rays "
-                                   f"({ws_bytes(gs, 48) / 2**20:.0f} MiB needed): free device memory")
-        need = ws_bytes(gs, min(rc, R))
-        if self._work is None or self._work.numel() * 4 < need:
-            self._work = None
-            self._work = torch.empty(need // 4, **f32)
-        work = self._work
+        def pair_bytes(nb):
+            return 4 * lib.car_gmaps_floats(ctypes.byref(self._dims(nb, R, z)))
+
+        # Scenes per lattice buffer: all of them (2.5 GB per scene at 256 x 256, 5.6 GB at 384 x 384) unless that would leave less than
+        # half of the usable device memory for the workspace; then the scenes are rendered in groups, each with its own
+        # car_project_maps (re-done on every forward: the one cached buffer holds the last group — a fallback, not a fast path).
+        self._channel_last(z)
+        whole_cached = self._pair is not None and self._pair_key == (self._maps_key, self._plan_key, 0, b)
+        pg = b
+        if not whole_cached:
+            usable = self._free_budget(dev) + (self._pair.numel() * 4 if self._pair is not None else 0)
+            if self.max_pair_bytes is not None:
+                usable = min(usable, 2 * int(self.max_pair_bytes))
+            while pg > 1 and pair_bytes(pg) > usable // 2:
+                pg = (pg + 1) // 2
+
+        # inside a lattice group — scenes per call: any number (the fused kernel addresses the lattice of ONE view and padding mode with
+        # 32-bit offsets); max_level_bytes lets tests force smaller calls.  Rays per call: the workspace (~0.44 MB per ray at 64 samples)
+        # must fit the free memory.  Rays and scenes are independent, so every split is exact.
+        gs_cap = pg if self.max_level_bytes is None else max(1, min(pg, self.max_level_bytes // (4 * lattice_scene)))
 
         out = {"rgb": torch.empty(b, 1, R, 3, **f32), "valid_mask": torch.empty(b, R, 1, **f32), "depth_ray": torch.empty(b, R, 1, **f32),
                "at_wt": torch.empty(n, R, P, **f32), "at_wt_max": torch.empty(n, R, 1, device=dev, dtype=torch.int32),
@@ -348,34 +406,55 @@ class RenderEngine:
         st = _stream()
         calls = 0
         d_last = None
-        for s0 in range(0, b, gs):
-            s1 = min(b, s0 + gs)
-            for r0 in range(0, R, rc):
-                r1 = min(R, r0 + rc)
-                d = self._dims(s1 - s0, r1 - r0, z)
-                whole = (r0 == 0 and r1 == R)
-                if whole:
-                    tgt = {k: out[k][s0 * lead[k]:s1 * lead[k]] for k in order}            # contiguous scene slices: written in place
-                    uv_c = uv[s0:s1]
-                else:
-                    tgt = {k: torch.empty((s1 - s0) * lead[k], r1 - r0, *out[k].shape[2 if k != "rgb" else 3:],
-                                          device=dev, dtype=out[k].dtype) for k in order}
-                    uv_c = uv[s0:s1, r0:r1].contiguous()
-                ci = _lib.CarInputs()
-                ci.poses = poses.data_ptr() + 4 * 96 * s0 * V
-                ci.uv = uv_c.data_ptr()
-                ci.lattice = pair.data_ptr() + 4 * s0 * lattice_scene
-                ci.gmeta = gmeta_ptr
-                ci.steps = steps.data_ptr()
-                co = _lib.CarOutputs(*[tgt[k].data_ptr() for k in order])
-                _lib.check(lib.car_render_forward(ctypes.byref(d), _ptr(plan), ctypes.byref(ci), ctypes.byref(co),
-                                                  _ptr(work), work.numel() * 4, st), "car_render_forward")
-                if not whole:
-                    for k in order:
-                        dst = out[k][:, 0] if k == "rgb" else out[k]
-                        dst[s0 * lead[k]:s1 * lead[k], r0:r1] = tgt[k]
-                calls += 1
-                d_last = d
+        self.last_pair_groups = -(-b // pg)
+        for p0 in range(0, b, pg):
+            p1 = min(b, p0 + pg)
+            pair, d_pair = self._pair_for(plan, z, dev, p0, p1, R)
+            gmeta_ptr = pair.data_ptr() + 4 * lib.car_gmeta_offset(ctypes.byref(d_pair))
+            budget = self._workspace_budget(dev)
+            gs = min(gs_cap, p1 - p0)
+            while gs > 1 and ws_bytes(gs, R) > budget:
+                gs = (gs + 1) // 2
+            rc = R
+            if ws_bytes(gs, R) > budget:
+                per_ray = ws_bytes(gs, 4800) / 4800.0
+                rc = int(budget / per_ray) // 48 * 48            # whole sample tiles of the fused kernel (24 rays each)
+                if rc < 48:
+                    raise RuntimeError(f"forward: {budget / 2**20:.0f} MiB of workspace cannot hold even 48 rays "
+                                       f"({ws_bytes(gs, 48) / 2**20:.0f} MiB needed): free device memory")
+            need = ws_bytes(gs, min(rc, R))
+            if self._work is None or self._work.numel() * 4 < need:
+                self._work = None
+                self._work = torch.empty(need // 4, **f32)
+            work = self._work
+            for s0 in range(p0, p1, gs):
+                s1 = min(p1, s0 + gs)
+                for r0 in range(0, R, rc):
+                    r1 = min(R, r0 + rc)
+                    d = self._dims(s1 - s0, r1 - r0, z)
+                    whole = (r0 == 0 and r1 == R)
+                    if whole:
+                        tgt = {k: out[k][s0 * lead[k]:s1 * lead[k]] for k in order}            # contiguous scene slices: written in place
+                        uv_c = uv[s0:s1]
+                    else:
+                        tgt = {k: torch.empty((s1 - s0) * lead[k], r1 - r0, *out[k].shape[2 if k != "rgb" else 3:],
+                                              device=dev, dtype=out[k].dtype) for k in order}
+                        uv_c = uv[s0:s1, r0:r1].contiguous()
+                    ci = _lib.CarInputs()
+                    ci.poses = poses.data_ptr() + 4 * 96 * s0 * V
+                    ci.uv = uv_c.data_ptr()
+                    ci.lattice = pair.data_ptr() + 4 * (s0 - p0) * lattice_scene
+                    ci.gmeta = gmeta_ptr
+                    ci.steps = steps.data_ptr()
+                    co = _lib.CarOutputs(*[tgt[k].data_ptr() for k in order])
+                    _lib.check(lib.car_render_forward(ctypes.byref(d), _ptr(plan), ctypes.byref(ci), ctypes.byref(co),
+                                                      _ptr(work), work.numel() * 4, st), "car_render_forward")
+                    if not whole:
+                        for k in order:
+                            dst = out[k][:, 0] if k == "rgb" else out[k]
+                            dst[s0 * lead[k]:s1 * lead[k], r0:r1] = tgt[k]
+                    calls += 1
+                    d_last = d
         self.last_calls = calls
         res = {
             "rgb": out["rgb"], "valid_mask": out["valid_mask"], "depth_ray": out["depth_ray"], "at_wt": out["at_wt"],
@@ -463,7 +542,7 @@ class RenderEngine:
         concat2 = (V == 2 and not m.no_latent_concat)
         if (self.fuse_samples and self.project_maps and concat2 and not m.no_sample and len(z) == 3
                 and sum(t.shape[1] for t in z) == 576 and m.hidden_dim == 128 and m.phi.n_blocks == 3 and m.phi.d_hidden == 128
-                and self._common_lattice(z)):
+                and self._common_lattice(z) and self._lattice_fits(b, R, z)):
             return self._render_one_call(inp, z, poses, uv, steps, b, V, R, P, H, W, debug)
 
         pk = self._weights(dev)

@@ -23,13 +23,17 @@ CAMERA_KEYS = ("cam2world", "intrinsics")
 
 
 def to_device(inp, device, cameras: str = "host"):
-    """Moves an input dict to the device.  ``cameras="host"`` (default) leaves the 4x4 camera matrices on the CPU: the engine then
-    runs the reference's own ``torch.inverse`` / ``matmul`` on them (poses.pack_poses) and uploads 768 bytes per frame — the
-    strict-parity route (the reference's fixtures reproduce to 1e-4).  ``cameras="device"`` moves them too, which selects
-    ``car_pose_setup`` (no host work per frame; equal to the host algebra to a few ulp, which the fp64 Pluecker intersection
-    amplifies on near-parallel samples: DESIGN.md section 2)."""
-    if cameras not in ("host", "device"):
-        raise ValueError("cameras must be 'host' or 'device'")
+    """Moves an input dict to the device.  All three choices but the last give the strict-parity pose algebra (the reference's own
+    ``torch.inverse`` / ``matmul`` on the host CPU, poses.pack_poses; the reference's fixtures reproduce to 1e-4):
+      ``"host"`` (default) leaves the 4x4 camera matrices on the CPU — the engine uploads 768 bytes of records per new pose and never
+                 waits for the device;
+      ``"gpu"``  moves them too, as the reference's ``dict_to_gpu`` does (render_realestate10k_traj.py:85): the engine copies them back
+                 for the host algebra, one small download + stream synchronisation per new pose (engine._poses);
+      ``"device"`` moves them and is meant for a module with ``pose_route = "device"``: ``car_pose_setup`` on the GPU, no host work per
+                 frame, equal to the host algebra to a few ulp — which the fp64 Pluecker intersection amplifies on near-parallel
+                 samples."""
+    if cameras not in ("host", "gpu", "device"):
+        raise ValueError("cameras must be 'host', 'gpu' or 'device'")
     keep = CAMERA_KEYS if cameras == "host" else ()
     return {k: {kk: (vv.to(device) if torch.is_tensor(vv) and kk not in keep else vv) for kk, vv in v.items()} for k, v in inp.items()}
 

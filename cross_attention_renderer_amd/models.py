@@ -137,6 +137,9 @@ class CrossAttentionRenderer(nn.Module):
         self.phi = ResnetFC(self.n_view * 9, n_blocks=3, d_out=3, d_latent=self.latent_dim * self.n_view,
                             d_hidden=self.num_hidden_units_phi)
         self._engine = None
+        # where forward's 4x4 pose algebra runs (engine._poses): "host" = the reference's torch.inverse on the CPU wherever the camera
+        # tensors live (strict parity, the default); "device" = car_pose_setup on the GPU when the cameras are there (opt-in)
+        self.pose_route = "host"
 
     # ------------------------------------------------------------------------------------------
     def get_z(self, input, val=False) -> List[Tensor]:

@@ -158,7 +158,9 @@ class _RenderTrain(torch.autograd.Function):
         zrep = torch.empty(b * R, V * Dl, **f32)
         saved = dict(x1=x1, h1=h1, e=e, k1=k1, key=key, q1=q1, q=q, at_wt=at_wt, ebar1=ebar1, g=g, pt=pt, poses=poses, rays=rays, phi_x=phi_x,
                      pixel_val=pixel_val, grid_other=grid_other)
-        ops = _Ops(eng)
+        ops = getattr(eng, "_train_ops", None)              # kept on the engine: its transposed-weight cache (keyed on data_ptr / _version)
+        if ops is None or ops.eng is not eng:               # then survives from step to step and re-packs only what the optimizer changed
+            ops = eng._train_ops = _Ops(eng)
         if m.repeat_attention:
             z1 = torch.empty(b * R, Dl, **f32)
             eng.linear(ebar1, Ce, pk["latent_value"], z1, Dl, b * R)
@@ -205,6 +207,10 @@ class _RenderTrain(torch.autograd.Function):
         ctx.dims = (b, V, R, P, C, Dl, Ce, hid, ld1, ld_phi)
         ctx.maps = maps
         ctx.params = {nme: t for nme, t in zip(_param_names(m), tensors[n_levels:])}
+        # the activations live as plain attributes (most are views into buffers autograd does not need to track), so autograd's own
+        # version check cannot see an in-place parameter update between forward and backward: check it by hand
+        ctx.param_versions = {nme: t._version for nme, t in ctx.params.items()}
+        ctx.need_dz = any(ctx.needs_input_grad[3:3 + n_levels])
         ctx.z_dtypes = [t.dtype for t in z]
         outs = (rgb.view(b, 1, R, 3), depth[..., None], valid[..., None], at_wt, amax.long()[..., None], coords9, pixel_val)
         ctx.mark_non_differentiable(*outs[2:])
@@ -219,6 +225,10 @@ class _RenderTrain(torch.autograd.Function):
         dev = sv["e"].device
         f32 = dict(device=dev, dtype=torch.float32)
         par = ctx.params
+        stale = [k for k, t in par.items() if t._version != ctx.param_versions[k]]
+        if stale:
+            raise RuntimeError(f"render_train: parameters were modified in place between forward and backward ({stale[:3]} ...): the saved "
+                               "activations no longer belong to them")
         with torch.cuda.device(dev):
             grads: Dict[str, Tensor] = {k: torch.zeros_like(v, dtype=torch.float32) for k, v in par.items()}
 
@@ -318,13 +328,16 @@ class _RenderTrain(torch.autograd.Function):
             dx("query_encode_latent_2", d_e, C // 2, d_h1, C, S * V)
             ops.relu_mask(d_h1, C, sv["h1"], C, S * V, C)
             wgrad("query_encode_latent", d_h1, C, sv["x1"], ld1, S * V)
-            d_x1 = torch.empty(S * V, ld1, **f32)
-            dx("query_encode_latent", d_h1, C, d_x1, ld1, S * V)
-            # ---- a7 / a10: scatter into the pyramid
-            dmaps = [torch.zeros_like(t) for t in ctx.maps]
-            ops.gather_backward(dmaps, sv["pixel_val"], R * P, 0, PLACE_OWN, V, d_x1, ld1, 0)
-            ops.gather_backward(dmaps, sv["grid_other"], R * P, 1, PLACE_OTHER2, V, d_x1, ld1, 0)
-            dz = [t.permute(0, 3, 1, 2).contiguous().to(dt) for t, dt in zip(dmaps, ctx.z_dtypes)]
+            dz = [None] * ctx.n_levels
+            if ctx.need_dz:                                  # the pyramid asked for a gradient (z from get_z under autograd, or a leaf)
+                d_x1 = torch.empty(S * V, ld1, **f32)
+                dx("query_encode_latent", d_h1, C, d_x1, ld1, S * V)
+                # ---- a7 / a10: scatter into the pyramid
+                dmaps = [torch.zeros_like(t) for t in ctx.maps]
+                ops.gather_backward(dmaps, sv["pixel_val"], R * P, 0, PLACE_OWN, V, d_x1, ld1, 0)
+                ops.gather_backward(dmaps, sv["grid_other"], R * P, 1, PLACE_OTHER2, V, d_x1, ld1, 0)
+                dz = [t.permute(0, 3, 1, 2).contiguous().to(dt) if need else None
+                      for t, dt, need in zip(dmaps, ctx.z_dtypes, ctx.needs_input_grad[3:3 + ctx.n_levels])]
         out = [None, None, None] + dz + [grads[k].view_as(par[k]).to(par[k].dtype) for k in _param_names(m)]
         return tuple(out)
 
@@ -359,20 +372,34 @@ def render_train(module, inp, z: Optional[List[Tensor]] = None) -> Dict[str, Ten
 def average_gradients(module, group=None) -> None:
     """The reference's gradient all-reduce (training.py:21-28): every parameter's gradient summed over the ranks and divided by the
     world size — here as ONE flat bucket per dtype over RCCL (xGMI is point-to-point: one large ring all-reduce instead of one
-    latency-bound collective per tensor), copied back in place."""
+    latency-bound collective per tensor), copied back in place.
+
+    The bucket is laid out over a rank-INVARIANT list — every parameter that requires a gradient, in ``module.parameters()`` order, zeros
+    standing in where this rank has none (an unused branch, an encoder-less rank) — so offsets agree on every rank whatever each one
+    back-propagated; one extra float per parameter carries "some rank had a gradient".  A parameter without a gradient on ANY rank keeps
+    ``grad = None`` (the optimizer skips it, as in the reference); one that had a gradient elsewhere receives the average here too, so
+    the replicas stay in step."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if world == 1:
         return
-    by_dtype: Dict[torch.dtype, List[Tensor]] = {}
+    by_dtype: Dict[torch.dtype, List[torch.nn.Parameter]] = {}
     for p in module.parameters():
-        if p.grad is not None:
-            by_dtype.setdefault(p.grad.dtype, []).append(p.grad)
-    for grads in by_dtype.values():
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        if p.requires_grad:
+            by_dtype.setdefault(p.dtype if p.grad is None else p.grad.dtype, []).append(p)
+    for dt, params in by_dtype.items():
+        dev = params[0].device
+        has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=dev, dtype=dt)
+        flat = torch.cat([(torch.zeros(p.numel(), device=dev, dtype=dt) if p.grad is None else p.grad.reshape(-1)) for p in params] + [has])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        n_flags = len(params)
+        any_rank = (flat[-n_flags:] > 0).tolist()
         flat /= world
         off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        for p, some in zip(params, any_rank):
+            g = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            if p.grad is not None:
+                p.grad.copy_(g)
+            elif some:
+                p.grad = g.clone()

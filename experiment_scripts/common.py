@@ -41,9 +41,11 @@ def parser(description: str) -> argparse.ArgumentParser:
                    help="build the DPT encoder and run get_z on the context images even without a checkpoint (random weights)")
     p.add_argument("--n_frames", type=int, default=8, help="frames of the rendered trajectory")
     p.add_argument("--out_dir", type=str, default=None)
-    p.add_argument("--cameras", choices=("host", "device"), default="host",
-                   help="where the 4x4 pose algebra runs: host = the reference's torch.inverse calls (strict parity, default); "
-                        "device = car_pose_setup (no host work per frame, last-ulp differences)")
+    p.add_argument("--cameras", choices=("host", "gpu", "device"), default="host",
+                   help="where the camera matrices live and the 4x4 pose algebra runs: host = matrices stay on the CPU, the reference's "
+                        "torch.inverse calls there (strict parity, no device sync; default); gpu = the whole input dict on the GPU as in the "
+                        "reference's scripts, the engine downloads the matrices for the same host algebra (strict parity, one small sync per "
+                        "new pose); device = car_pose_setup on the GPU (no host work per frame, last-ulp differences)")
     p.add_argument("--port", type=int, default=1492)          # the reference rendezvous port (eval_realestate10k.py:97)
     return p
 
@@ -75,6 +77,7 @@ def build_model(opt, device, with_encoder=None):
                 if not n_.startswith("encoder."):
                     p_.add_(0.02 * torch.randn(p_.shape, generator=g))
     model.H = model.W = opt.img_sidelength
+    model.pose_route = "device" if getattr(opt, "cameras", "host") == "device" else "host"
     return model.to(device)
 
 

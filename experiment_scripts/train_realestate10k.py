@@ -4,7 +4,8 @@
 
 The reference's loop, with ``training.render_train`` (HIP forward + HIP backward, csrc/car_backward.hip) in the place of
 ``model(model_input)``: Adam(lr, betas=(0.99, 0.999)) (train_realestate10k.py:93), 192 random query rays per scene (query_sparsity,
-train_realestate10k.py:78), L1 image loss (loss_functions.image_loss; --depth adds the depth-variance term, loss_functions.py:112-127),
+train_realestate10k.py:78), L1 image loss (loss_functions.image_loss; --depth adds the reference's per-patch depth-variance term on 32 x 32
+pixel patches, loss_functions.py:112-127, and samples the rays as such patches: --query_sparsity must then be a multiple of 1024),
 gradient clipping at norm 1 (training.py:130-134), parameters broadcast from rank 0 and gradients all-reduced when --gpus > 1
 (train_realestate10k.py:60-62, training.py:21-28: one process per GPU over RCCL), checkpoints ``{'model', 'optimizer'}`` as
 ``checkpoints/model_current.pth`` / ``model_final.pth`` (training.py:82-84, 244-246) that the eval / render scripts load.
@@ -51,11 +52,15 @@ def train(rank, opt):
     g = torch.Generator().manual_seed(1234 + rank)                 # every rank shuffles on its own (train_realestate10k.py:80-81)
     base = synthetic.stereo_scene(H, b=b, seed=5 + rank, n_view=opt.views)
     z = None
-    leaves = list(params)
     if model.encoder.__class__.__name__ == "EncoderNotBuilt":
         z = [t.to(dev).requires_grad_(True) for t in synthetic.feature_maps(b, opt.views, H, seed=1 + rank)]
-        leaves += z
-    optimizer = torch.optim.Adam(lr=opt.lr, params=leaves, betas=(0.99, 0.999))
+    optimizer = torch.optim.Adam(lr=opt.lr, params=params, betas=(0.99, 0.999))      # the reference's parameter group: what the checkpoint stores
+    # the stand-in pyramid (no encoder built) is a per-rank leaf with an optimizer of its own, so that the saved 'optimizer' state matches
+    # the reference's param groups
+    z_optimizer = torch.optim.Adam(lr=opt.lr, params=z, betas=(0.99, 0.999)) if z is not None else None
+    if opt.depth and R % 1024:
+        raise SystemExit("--depth: the reference's depth-variance term works on 32 x 32 pixel patches (loss_functions.py:112-127): "
+                         "--query_sparsity must be a multiple of 1024")
     # a smooth random target image per scene: low-frequency colours of the pixel coordinates
     coef = (torch.rand(b, 3, 4, generator=g) * 2 - 1).to(dev)
     ckpt_dir = os.path.join(opt.logging_root, opt.experiment_name, "checkpoints")
@@ -64,7 +69,12 @@ def train(rank, opt):
     grid = synthetic.pixel_grid(H, H)
     t0, losses = time.time(), []
     for step in range(opt.max_steps):
-        uv = torch.stack([grid[torch.randperm(H * H, generator=g)[:R]] for _ in range(b)])[:, None]       # (b, 1, R, 2)
+        if opt.depth:                                            # 32 x 32 pixel patches at random corners, row-major inside a patch
+            gi = grid.view(H, H, 2)
+            uv = torch.stack([torch.cat([gi[y0:y0 + 32, x0:x0 + 32].reshape(1024, 2)
+                                         for y0, x0 in torch.randint(0, H - 31, (R // 1024, 2), generator=g).tolist()]) for _ in range(b)])[:, None]
+        else:
+            uv = torch.stack([grid[torch.randperm(H * H, generator=g)[:R]] for _ in range(b)])[:, None]   # (b, 1, R, 2)
         inp = {"context": base["context"], "query": dict(base["query"], uv=uv)}
         inp = harness.to_device(inp, dev, opt.cameras)
         u = inp["query"]["uv"][:, 0] / (H - 1) * 3.14159
@@ -72,15 +82,22 @@ def train(rank, opt):
         gt_rgb = torch.tanh(torch.einsum("brk,bck->brc", feats, coef))[:, None]                             # (b, 1, R, 3)
         out = render_train(model, inp, z=z)
         loss = (gt_rgb - out["rgb"]).abs().mean()                                                           # loss_functions.image_loss
-        if opt.depth:                                                                                       # loss_functions.py:112-127
-            d = out["depth_ray"][..., 0]
-            loss = loss + (opt.l2_coeff * (d - d.mean(dim=-1, keepdim=True)) ** 2).mean()
+        if opt.depth:                                            # loss_functions.py:112-127: per-patch depth variance, masked per patch
+            d = out["depth_ray"][..., 0].reshape(-1, 1, 32, 32)
+            mean = d.mean(dim=-1).mean(dim=-1)[:, None, None]
+            dist_ = opt.l2_coeff * torch.pow(d - mean, 2).mean(dim=-1).mean(dim=-1).mean(dim=-1)
+            mask = torch.ones_like(dist_)                         # gt['mask']: every synthetic patch counts
+            loss = loss + (dist_ * mask).mean()
         optimizer.zero_grad()
+        if z_optimizer is not None:
+            z_optimizer.zero_grad()
         loss.backward()
         if opt.gpus > 1:
             average_gradients(model)                              # the stand-in pyramid, if any, is per rank: not reduced
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
         optimizer.step()
+        if z_optimizer is not None:
+            z_optimizer.step()
         losses.append(loss.item())
         if rank == 0 and (step % opt.steps_til_summary == 0 or step == opt.max_steps - 1):
             print(f"step {step}: loss {losses[-1]:.5f}  ({(time.time() - t0) / (step + 1) * 1e3:.1f} ms/step, {b} scenes x {R} rays)", flush=True)

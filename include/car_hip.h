@@ -133,7 +133,9 @@ int car_gather_encode(const float* const* gmaps, const int* level_h, const int* 
  * car_lattice_shape gives its size; csrc/car_geom.h car_lattice_taps).  `gmeta` [1]: max |lattice| (car_project_maps writes it),
  * from which the kernel derives the power of two that keeps the activations of the first layer inside fp16's range.
  * Outputs: e [S,576], qry [S,128], g [S,16] (the geometric query local_coords, models.py:528), logit [S], pt [S,3],
- * pixel_val [S,2] with S = b*V*R*P.  The lattice of one (view, padding mode) must stay below 4 GiB (images up to ~650 pixels). */
+ * pixel_val [S,2] with S = b*V*R*P.  The lattice of one (view, padding mode) must stay below 2 GiB (nodes are addressed by 32-bit
+ * byte offsets with the upper range reserved for samples that read zeros): a finest level up to ~470 pixels wide; wider pyramids take the
+ * stage entries (the Python engine falls back by itself). */
 size_t car_fused_blob_floats(void);
 size_t car_fused_bias_floats(void);
 int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,

@@ -6,7 +6,7 @@ detected instead of silently invalidating the vectors.
 
 Tiers:
   T0  tiny widths (latent 32 -> 16), every intermediate stored, plus the constructor variants (a19);
-  T1  real widths (C=576) at the C1 shape (64x64, 32 samples), 256 rays;
+  T1  real widths (C=576) at the C1 shape (64x64, 32 samples), 256 rays; the constructor variants (a19) at these widths, 128 rays;
   T2  real widths at the C2/C4/C5 shapes (256x256x64, x128, 384x384x64), 48-64 rays, outputs only.
 """
 from __future__ import annotations
@@ -40,6 +40,11 @@ CASES: Dict[str, dict] = {
     "t1_c1": dict(tier=1, H=64, P=32, b=1, rays=256, **REAL),
     "t1_nview3": dict(tier=1, H=64, P=16, b=1, rays=64, n_view=3, **REAL),
     "t1_c1_diverging": dict(tier=1, H=64, P=32, b=1, rays=128, yaw_deg=38.0, baseline=0.9, **REAL),
+    # the constructor variants at real widths, C1 shape, 128 rays
+    "t1_nview1": dict(tier=1, H=64, P=32, b=1, rays=128, n_view=1, **REAL),
+    "t1_no_sample": dict(tier=1, H=64, P=32, b=1, rays=128, no_sample=True, **REAL),
+    "t1_no_latent_concat": dict(tier=1, H=64, P=32, b=1, rays=128, no_latent_concat=True, **REAL),
+    "t1_no_repeat": dict(tier=1, H=64, P=32, b=1, rays=128, repeat_attention=False, **REAL),
     # ---- T2: real widths, bench shapes -------------------------------------------------------
     "t2_c2": dict(tier=2, H=256, P=64, b=1, rays=64, **REAL),
     "t2_c3": dict(tier=2, H=256, P=64, b=2, rays=48, alpha=0.3, **REAL),

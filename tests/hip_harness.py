@@ -33,19 +33,22 @@ CAMERA_KEYS = ("cam2world", "intrinsics")
 
 
 def to_device(inp, device, cameras_on_host=False):
-    """Moves the input dict to the device; with cameras_on_host the 4x4 camera matrices stay CPU tensors, which makes the engine
-    run the reference's own torch.inverse / matmul on the host (engine._poses) instead of car_pose_setup on the device."""
+    """Moves the input dict to the device; with cameras_on_host the 4x4 camera matrices stay CPU tensors.  Either way the engine runs
+    the reference's own torch.inverse / matmul on the host (engine._poses; cameras on the GPU are downloaded first) unless the module's
+    pose_route is "device" (car_pose_setup)."""
     return {k: {kk: (vv if (cameras_on_host and kk in CAMERA_KEYS) else vv.to(device)) for kk, vv in v.items()} for k, v in inp.items()}
 
 
 def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_poses=False, project_maps=True,
-             fuse_samples=True, fuse_round2=True, engine_setup=None, sd_edit=None, z_edit=None, poses=None, cameras_on_host=True):
+             fuse_samples=True, fuse_round2=True, engine_setup=None, sd_edit=None, z_edit=None, poses=None, cameras_on_host=True,
+             pose_route="host"):
     """Returns (config, fixture, oracle output dict (CPU), HIP output dict (tensors moved to CPU)).
 
     fixture_poses=True: both sides use the relative-pose matrices stored in the fixture (the ones the reference
     computed in the build container) instead of running torch.inverse on this host; ``poses`` (b*V, 96): explicit records for
-    both sides; otherwise cameras_on_host=True keeps the cameras on the CPU so that the engine computes them with the same
-    torch calls as the oracle (strict comparisons), False leaves them on the GPU (car_pose_setup: budgeted comparisons).
+    both sides; otherwise the engine computes them with the same torch calls as the oracle (strict comparisons) — from CPU camera
+    tensors (cameras_on_host=True) or, as the reference's scripts hand them over, from the whole input dict on the GPU (False: the
+    engine downloads the matrices).  pose_route="device" with the cameras on the GPU selects car_pose_setup (budgeted comparisons).
     sd_edit / z_edit: functions applied to the case's state_dict / feature pyramid before either side sees them;
     engine_setup(engine): last-minute engine knobs."""
     from cross_attention_renderer_amd.engine import RenderEngine
@@ -62,6 +65,7 @@ def run_case(name: str, device="cuda:0", debug=True, linear_flags=0, fixture_pos
     m._engine = RenderEngine(m)
     m._engine.linear_flags = linear_flags
     m._engine.pose_records = poses
+    m.pose_route = pose_route
     m._engine.project_maps = project_maps
     m._engine.fuse_samples = fuse_samples
     m._engine.fuse_round2 = fuse_round2

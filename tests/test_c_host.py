@@ -55,7 +55,7 @@ def test_c_host_renders_a_reference_fixture(tmp_path, host_poses):
     import torch
     from golden_util import load_case
     from hip_harness import err_stats
-    TOL, OUTLIER_FRAC, OUTLIER_MAX = 1e-4, 2e-2, 5e-2        # the contract / the pose-host outlier budget of tests/test_hip_parity.py
+    TOL, OUTLIER_FRAC, OUTLIER_MAX = 1e-4, 2e-2, 2e-2        # the contract / the device-pose budget of tests/test_hip_parity.py (DEVICE_POSE_MAX)
     exe = _compile()
     c, inp, z, sd, fx = load_case("t1_c1")
     b, V, P, H = c["b"], c["n_view"], c["P"], c["H"]

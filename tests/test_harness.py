@@ -101,7 +101,8 @@ def test_training_entry_point_runs_and_writes_reference_style_checkpoints(tmp_pa
     backward), checkpoints in the reference's {'model', 'optimizer'} format (training.py:82-84, 244-246)."""
     import torch
     cmd = [sys.executable, os.path.join(ROOT, "experiment_scripts", "train_realestate10k.py"), "--experiment_name", "t", "--views", "2",
-           "--img_sidelength", "64", "--batch_size", "2", "--max_steps", "4", "--steps_til_summary", "2", "--logging_root", str(tmp_path), "--depth"]
+           "--img_sidelength", "64", "--batch_size", "2", "--max_steps", "4", "--steps_til_summary", "2", "--logging_root", str(tmp_path), "--depth",
+           "--query_sparsity", "1024"]          # --depth: one 32 x 32 pixel patch per scene (the reference's depth-variance term works on such patches)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "trained 4 steps" in out.stdout
@@ -115,7 +116,9 @@ def test_training_entry_point_runs_and_writes_reference_style_checkpoints(tmp_pa
 def test_bench_prints_one_line_with_the_contract_fields():
     """`python bench.py` (small K / W, a 256-ray CPU sample): the last stdout line is ONE JSON object with the fields the driver reads —
     metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config —
-    plus the `roofline` (bound in {hbm, mfma}, achieved / peak / unit / frac / traffic) and `cpu_baseline` objects."""
+    plus the `roofline` (bound in {hbm, mfma}, achieved / peak / unit / frac / traffic) and `cpu_baseline` objects, and what the
+    restructured path keeps outside the timed region: `pair_setup_ms`, `lattice_bytes`, `workspace_bytes`, `eval_mode`, the gather stage with
+    its spread, the rank-share projection and the cost of handing the cameras over on the GPU."""
     import json
     import subprocess
     import sys
@@ -137,3 +140,23 @@ def test_bench_prints_one_line_with_the_contract_fields():
     assert 0.0 < r["frac"] < 1.0 and r["traffic"] is not None and set(r["live_fields"]).isdisjoint(r["static_fields"])
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert d["config"]["name"] == "c2" and d["config"]["builder_kept"] is False
+    assert d["pair_setup_ms"] > 0 and d["lattice_bytes"] > 2e9 and d["workspace_bytes"] > 1e10
+    ev = d["eval_mode"]
+    assert ev["unit"] == "rays/s" and ev["ms_per_step"] > d["ms_per_step"] and abs(ev["value"] - 65536 / (ev["ms_per_step"] * 1e-3)) < 1e-3 * ev["value"]
+    g = d["gather_stage"]
+    assert g["pairs"] >= 20 and g["warmup_pairs"] >= 30 and g["ms_min"] <= g["ms"] <= g["ms_max"] and g["frac_min"] <= g["frac"] <= g["frac_max"]
+    assert abs(g["spread"] - (g["ms_max"] - g["ms_min"]) / g["ms"]) < 1e-9
+    assert d["rank_share"]["rays_per_step"] == 8192 and 1.0 < d["rank_share"]["projected_scaling_8"] <= 8.5
+    assert d["pose_route"]["download_and_sync_ms"] > 0 and d["pose_route"]["cameras_on_gpu_ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_world_size_that_is_not_the_requested_gpu_count():
+    """--gpus N with fewer (or more) launched ranks must fail loudly, not print a line that looks like an N-GPU figure."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=root, env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
+    assert out.returncode != 0 and "--gpus 2" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]

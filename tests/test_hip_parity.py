@@ -20,10 +20,12 @@ from oracle import car_oracle as O
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4                   # the contract: |a-b| <= 1e-4 * max(1,|b|)
-# Only for the comparison that runs torch.inverse on *this* host against vectors made on another CPU (see
-# test_forward_host_poses_vs_reference): at most 2 % of an output's elements may exceed TOL, none by more than 5e-2.
-OUTLIER_FRAC = 2e-2
-OUTLIER_MAX = 5e-2
+# Only for the comparisons that run torch.inverse on *this* host against vectors made on another CPU (test_forward_host_poses_vs_reference,
+# test_forward_with_the_whole_input_dict_on_the_device): LAPACK's last ulp is host dependent.  Measured on the MI355X box (EPYC host) against
+# the fixtures (made on a Xeon), all 21 cases: 19 with every element inside 1e-4; t1_c1_diverging 1.0 % of rgb beyond it (worst 2.0e-4),
+# t2_c2 one ray of 64 = 1.6 % (worst 1.6e-3); depth_ray / at_wt always inside.  Budget: one ray of a 48-ray fixture, none beyond 5e-3.
+OUTLIER_FRAC = 2.1e-2
+OUTLIER_MAX = 5e-3
 # car_pose_setup's fp64 Gauss-Jordan against the fixture's matrices (the reference's fp32 LAPACK on the build host): a whole frame moves
 # 0.8-2 % of its elements by up to 1.3e-2 (profiles/round2_whole_frame_parity.md).  On the 48-256-ray fixtures: 0-1.6 % of the elements,
 # two rays of 48 (4.2 %) on t1_c1_diverging and t2_c5, worst 7.1e-3 (t2_c2) — the budget is two rays of the smallest fixture, and 2e-2
@@ -85,12 +87,17 @@ def test_linear_matches_torch(M, K, N, flags, no_glds):
 # ----------------------------------------------------------------------------------------------------------
 # stage kernels
 # ----------------------------------------------------------------------------------------------------------
-def test_gather_matches_grid_sample():
+@pytest.mark.parametrize("chans", [(8, 12, 4), (8, 16, 4), (4, 4, 4), (256, 64, 8), (4,)])
+def test_gather_matches_grid_sample(chans):
+    """car_gather_bilinear against F.grid_sample.  (8, 12, 4): a quad count that is no power of two -> the per-float4 kernel;
+    (8, 16, 4) / (4, 4, 4) / (4,): powers of two only, but a 4-channel level would need 64 rows per wave-task, more than a work group's 32
+    -> must fall back too (it used to leave that level's columns unwritten); (256, 64, 8): the wave-task kernel proper."""
     from cross_attention_renderer_amd.engine import RenderEngine
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(3)
     n, pts = 4, 700
-    z = [torch.randn(n, 8, 5, 7, generator=g), torch.randn(n, 12, 9, 6, generator=g), torch.randn(n, 4, 16, 16, generator=g)]
+    sizes = [(5, 7), (9, 6), (16, 16)]
+    z = [torch.randn(n, c_, *sizes[l], generator=g) for l, c_ in enumerate(chans)]
     grid = torch.rand(n, pts, 2, generator=g) * 2.6 - 1.3
     grid[0, 0] = torch.tensor([1e10, 1e10]); grid[0, 1] = torch.tensor([-1.0, 1.0]); grid[1, 2] = torch.tensor([7.8e7, -0.2])
 
@@ -99,21 +106,22 @@ def test_gather_matches_grid_sample():
     eng = RenderEngine.__new__(RenderEngine)
     eng.lib = _lib()
     maps = [t.permute(0, 2, 3, 1).contiguous().to(dev) for t in z]
-    Ct = 24
+    Ct = sum(chans)
+    ld = Ct + 8
     for mode, name in ((0, "border"), (1, "zeros")):
-        out = torch.full((n * pts, 32), -7.0, device=dev)
-        eng.gather(maps, grid.to(dev), pts, mode, 0, 1, out, 32, 4)
+        out = torch.full((n * pts, ld), -7.0, device=dev)
+        eng.gather(maps, grid.to(dev), pts, mode, 0, 1, out, ld, 4)
         torch.cuda.synchronize()
         want = torch.cat([torch.nn.functional.grid_sample(t, grid[:, :, None, :], mode="bilinear", padding_mode=name,
                                                           align_corners=False)[..., 0].permute(0, 2, 1) for t in z], dim=-1)
-        got = out.cpu().view(n, pts, 32)
+        got = out.cpu().view(n, pts, ld)
         assert (got[..., 4:4 + Ct] - want).abs().max() < 1e-5, name
         assert (got[..., :4] == -7).all() and (got[..., 4 + Ct:] == -7).all()
         # the same points declared as rays x samples (a work group takes one sample of 16 neighbouring rays; 700 = 35 rays x 20,
         # 28 x 25: ragged last ray block): another order of the same rows, bit-identical; a run that does not divide pts is ignored
         for run in (20, 25, 700, 13):
-            out2 = torch.full((n * pts, 32), -7.0, device=dev)
-            eng.gather(maps, grid.to(dev), pts, mode, 0, 1, out2, 32, 4, run=run)
+            out2 = torch.full((n * pts, ld), -7.0, device=dev)
+            eng.gather(maps, grid.to(dev), pts, mode, 0, 1, out2, ld, 4, run=run)
             assert torch.equal(out2, out), (name, run)
 
 
@@ -179,6 +187,24 @@ def test_forward_host_poses_vs_reference(name):
     comparison — and only this one — carries an outlier budget."""
     c, fx, ora, out = run_case(name)
     _check_outputs(out, lambda k: fx["out_" + k], "host poses vs reference fixture", frac=OUTLIER_FRAC, worst=OUTLIER_MAX)
+
+
+@pytest.mark.parametrize("name", HIP_CASES)
+def test_forward_with_the_whole_input_dict_on_the_device(name):
+    """The reference scripts' call (render_realestate10k_traj.py:85, 128-130: dict_to_gpu moves EVERYTHING, cameras included, and then
+    model(model_input, z=z)): the boundary's default route downloads the four camera tensors and runs the reference's own host pose
+    algebra, so the result is bit-identical to the forward with the cameras left on the host, and strict (1e-4, every element)
+    against the oracle on this host.  Against the reference's own outputs (made on another CPU) see
+    test_forward_host_poses_vs_reference: same budget, because the two forwards are the same bits."""
+    c, fx, ora, out = run_case(name, cameras_on_host=False)
+    _check_outputs(out, lambda k: ora[k], "whole dict on the device vs oracle")
+    _, _, _, host = run_case(name, cameras_on_host=True)
+    for k in ("rgb", "depth_ray", "at_wt", "valid_mask", "at_wt_max", "pixel_val"):
+        assert torch.equal(out[k], host[k]), k
+    worst = {k: err_stats(out[k], fx["out_" + k]) for k in ("rgb", "depth_ray", "at_wt")}
+    print(f"whole dict on the device vs reference fixture {name}: " + ", ".join(f"{k} beyond 1e-4 {e['f1e-4']:.5f} worst {e['max']:.2e}" for k, e in worst.items()))
+    for k, e in worst.items():
+        assert e["f1e-4"] <= OUTLIER_FRAC and e["max"] <= OUTLIER_MAX, f"whole dict on the device vs reference fixture {name} {k}: {e}"
 
 
 @pytest.mark.parametrize("name", ["t0_default", "t0_diverging", "t1_c1", "t2_c2", "t2_c5"])
@@ -311,20 +337,26 @@ def test_whole_frame_call_equals_chunked_calls():
 
 
 
-@pytest.mark.parametrize("name,ws_mib,level_mib", [("t2_c3", 30, None), ("t2_c3", None, 2600), ("t2_c2", 20, None)])
-def test_forward_split_into_several_calls_is_bit_identical(name, ws_mib, level_mib):
+@pytest.mark.parametrize("name,ws_mib,level_mib,pair_mib", [("t2_c3", 30, None, None), ("t2_c3", None, 2600, None), ("t2_c2", 20, None, None),
+                                                           ("t2_c3", None, None, 4000)])
+def test_forward_split_into_several_calls_is_bit_identical(name, ws_mib, level_mib, pair_mib):
     """The engine splits a forward into several car_render_forward calls when the workspace would not fit the free memory (ray
-    chunks, then scene groups).  Rays and scenes are independent and every call sees whole sample groups, so the result must not
-    change by a single bit.  The limits are shrunk here to force the split on small cases (level_mib: lattice bytes per call)."""
+    chunks, then scene groups), and builds the lattices of the scenes in several groups when all of them would not leave room for it
+    (each group its own car_project_maps).  Rays and scenes are independent and every call sees whole sample groups, so the result
+    must not change by a single bit.  The limits are shrunk here to force the splits on small cases (level_mib: lattice bytes per
+    call; pair_mib: bytes of one lattice buffer)."""
     c, fx, ora, one = run_case(name, debug=False)
 
     def setup(eng):
         eng.max_workspace_bytes = None if ws_mib is None else ws_mib << 20
         if level_mib is not None:
             eng.max_level_bytes = level_mib << 20
+        if pair_mib is not None:
+            eng.max_pair_bytes = pair_mib << 20
     calls = {}
     _, _, _, many = run_case(name, debug=False, engine_setup=lambda e: (setup(e), calls.setdefault("eng", e)))
     assert calls["eng"].last_calls > 1, "the limits did not force a split"
+    assert (calls["eng"].last_pair_groups > 1) == (pair_mib is not None)
     for k in ("rgb", "valid_mask", "depth_ray", "at_wt", "at_wt_max", "coords", "pixel_val"):
         assert torch.equal(one[k], many[k]), f"{name} {k}: max abs diff {(one[k].double() - many[k].double()).abs().max().item()}"
 
@@ -522,8 +554,8 @@ def test_forward_on_device_made_poses(name):
     poses = _device_poses(inp, c["H"])
     c, fx, ora, out = run_case(name, poses=poses)
     _check_outputs(out, lambda k: ora[k], "device poses vs oracle")
-    # the engine's own choice when the cameras are on the GPU: identical to handing it car_pose_setup's records
-    _, _, _, auto = run_case(name, cameras_on_host=False)
+    # the opt-in device route (module.pose_route = "device", cameras on the GPU): identical to handing the engine car_pose_setup's records
+    _, _, _, auto = run_case(name, cameras_on_host=False, pose_route="device")
     for k in ("rgb", "depth_ray", "at_wt"):
         assert torch.equal(auto[k], out[k]), k
     for k in ("rgb", "depth_ray", "at_wt"):
@@ -531,6 +563,27 @@ def test_forward_on_device_made_poses(name):
         print(f"device poses vs reference fixture {name} {k}: beyond 1e-4: {e['f1e-4']:.4f}, worst {e['max']:.2e}")
         assert e["f1e-4"] <= DEVICE_POSE_FRAC and e["max"] <= DEVICE_POSE_MAX, f"device poses vs reference fixture {k}: {e}"
     assert (np.asarray(out["valid_mask"]) == fx["out_valid_mask"]).all()
+
+
+def test_lattice_beyond_the_fused_kernels_range_takes_the_stage_route():
+    """A finest level wider than ~470 pixels makes the lattice of one (view, padding mode) exceed the 2 GiB the fused kernel can
+    address with its 32-bit tap offsets: the engine must select the stage route by itself (it used to fail with a hard error), and
+    car_fused_samples must refuse such a lattice with an error that names the limit.  The route test only asks the engine which
+    route it would take (a 512-pixel pyramid is 3.6 GB per scene: nothing is rendered here)."""
+    from cross_attention_renderer_amd.engine import RenderEngine
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=8, with_encoder=False).eval()
+    eng = RenderEngine(m)
+    for H, fits in ((256, True), (384, True), (464, True), (512, False)):
+        m.H = m.W = H
+        z = [torch.empty(2, 256, H // 4, H // 4, device="meta"), torch.empty(2, 256, H // 2, H // 2, device="meta"), torch.empty(2, 64, H, H, device="meta")]
+        assert eng._common_lattice(z)
+        assert eng._lattice_fits(1, 64, z) == fits, H
+    lib = _lib()
+    one = torch.zeros(64, device="cuda:0")
+    rc = lib.car_fused_samples(_ptr(one), _ptr(one), _ptr(one), _ptr(one), 1033, 1033, 5, _ptr(one), _ptr(one), _ptr(one), _ptr(one), 1, 2, 8, 8, 512, 512,
+                               _ptr(one), _ptr(one), _ptr(one), _ptr(one), _ptr(one), _ptr(one), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0 and b"2 GiB" in lib.car_last_error()
 
 
 def test_pyramid_without_a_common_lattice_takes_the_stage_route():

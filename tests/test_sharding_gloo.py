@@ -124,6 +124,25 @@ def _grad_worker(rank, world, port, ret):
             dist.all_gather(parts, g0)
             assert torch.allclose(p.grad, sum(parts) / world, rtol=0, atol=1e-6)
         assert all(p.grad is None for p in frozen.parameters())
+        # a branch only ONE rank back-propagated through (an unused layer, an encoder-less rank): the bucket is laid out over every
+        # parameter that requires a gradient, so the offsets agree; the other rank receives the average too and the replicas stay in step
+        net.zero_grad(set_to_none=True)
+        side = torch.nn.Linear(3, 2)
+        model2 = torch.nn.ModuleList([net, side, frozen])
+        y = net(x).sum()
+        if rank == 0:
+            y = y + side(torch.ones(1, 3)).sum()
+        y.backward()
+        mine = [None if p.grad is None else p.grad.clone() for p in model2.parameters()]
+        average_gradients(model2)
+        for p, g0 in zip(model2.parameters(), mine):
+            parts = [torch.zeros(p.shape) for _ in range(world)]
+            dist.all_gather(parts, torch.zeros(p.shape) if g0 is None else g0)
+            if all(float(t.abs().sum()) == 0 for t in parts) and g0 is None:
+                assert p.grad is None                          # nobody had one: stays None, the optimizer skips it (frozen)
+            else:
+                assert p.grad is not None and torch.allclose(p.grad, sum(parts) / world, rtol=0, atol=1e-6)
+        assert all(p.grad is not None for p in side.parameters())
         ret[rank] = 1
     finally:
         dist.destroy_process_group()

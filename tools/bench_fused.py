@@ -108,7 +108,7 @@ def main():
             lat.append((a, b_))
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b_) for a, b_ in lat[2:])
-        if v == 4:
+        if v == 4 or "CAR_STAMP_ALL" in os.environ.get("CAR_DEV_FLAGS", ""):
             st8 = pixel_val.view(torch.int64)[: (2 * R * bench.P // 192) * 16].view(-1, 16).cpu().double()
             seq = [0, 1, 2, 3, 4, 7, 8, 5, 6]                     # stamp indices in program order
             names = ["tables+geometry", "first gather + weights 0", "source pass 0", "source pass 1", "K1 over e_1 (+ its stores)", "K1 over e_0 (LDS-DMA rows)",
