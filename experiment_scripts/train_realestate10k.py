@@ -66,17 +66,24 @@ def train(rank, opt):
     ckpt_dir = os.path.join(opt.logging_root, opt.experiment_name, "checkpoints")
     if rank == 0:
         os.makedirs(ckpt_dir, exist_ok=True)
-    grid = synthetic.pixel_grid(H, H)
-    t0, losses = time.time(), []
+    # the scene (context images, cameras) goes to the device ONCE; every step only draws new rays there.  (Round 3's loop rebuilt the
+    # input dict on the host every step — twelve 65 536-element permutations on the CPU and a 19 MB upload of the context images — and
+    # spent 100 ms per step in it; render_train itself queues a step in ~33 ms and the GPU needs ~45 ms: profiles/round4_train_step.md.)
+    base = harness.to_device(base, dev, opt.cameras)
+    grid = synthetic.pixel_grid(H, H).to(dev)
+    gdev = torch.Generator(device=dev).manual_seed(4321 + rank)
+    t0, losses, t_warm = time.time(), [], None
     for step in range(opt.max_steps):
+        if step == min(2, opt.max_steps - 1):                     # steady-state clock: after the first steps' allocations and builds
+            torch.cuda.synchronize()
+            t_warm = (time.time(), step)
         if opt.depth:                                            # 32 x 32 pixel patches at random corners, row-major inside a patch
             gi = grid.view(H, H, 2)
-            uv = torch.stack([torch.cat([gi[y0:y0 + 32, x0:x0 + 32].reshape(1024, 2)
-                                         for y0, x0 in torch.randint(0, H - 31, (R // 1024, 2), generator=g).tolist()]) for _ in range(b)])[:, None]
-        else:
-            uv = torch.stack([grid[torch.randperm(H * H, generator=g)[:R]] for _ in range(b)])[:, None]   # (b, 1, R, 2)
+            corners = torch.randint(0, H - 31, (b, R // 1024, 2), generator=g).tolist()
+            uv = torch.stack([torch.cat([gi[y0:y0 + 32, x0:x0 + 32].reshape(1024, 2) for y0, x0 in corners[sc]]) for sc in range(b)])[:, None]
+        else:                                                    # R distinct random pixels per scene (query_sparsity), drawn on the device
+            uv = torch.stack([grid[torch.randperm(H * H, device=dev, generator=gdev)[:R]] for _ in range(b)])[:, None]   # (b, 1, R, 2)
         inp = {"context": base["context"], "query": dict(base["query"], uv=uv)}
-        inp = harness.to_device(inp, dev, opt.cameras)
         u = inp["query"]["uv"][:, 0] / (H - 1) * 3.14159
         feats = torch.stack([torch.sin(u[..., 0]), torch.cos(u[..., 1]), torch.sin(u[..., 0] + u[..., 1]), torch.ones_like(u[..., 0])], dim=-1)
         gt_rgb = torch.tanh(torch.einsum("brk,bck->brc", feats, coef))[:, None]                             # (b, 1, R, 3)
@@ -98,13 +105,17 @@ def train(rank, opt):
         optimizer.step()
         if z_optimizer is not None:
             z_optimizer.step()
-        losses.append(loss.item())
+        losses.append(loss.detach())                              # no .item() here: that would drain the queue every step
         if rank == 0 and (step % opt.steps_til_summary == 0 or step == opt.max_steps - 1):
-            print(f"step {step}: loss {losses[-1]:.5f}  ({(time.time() - t0) / (step + 1) * 1e3:.1f} ms/step, {b} scenes x {R} rays)", flush=True)
+            print(f"step {step}: loss {losses[-1].item():.5f}  ({(time.time() - t0) / (step + 1) * 1e3:.1f} ms/step since the start, {b} scenes x {R} rays)", flush=True)
             torch.save({"model": model.state_dict(), "optimizer": optimizer.state_dict()}, os.path.join(ckpt_dir, "model_current.pth"))
+    torch.cuda.synchronize()
     if rank == 0:
+        if t_warm is not None and opt.max_steps - t_warm[1] > 0:
+            print(f"steady state: {(time.time() - t_warm[0]) / (opt.max_steps - t_warm[1]) * 1e3:.1f} ms per step over the last {opt.max_steps - t_warm[1]} steps "
+                  f"(wall clock, checkpoint writes included)")
         torch.save({"model": model.state_dict(), "optimizer": optimizer.state_dict()}, os.path.join(ckpt_dir, "model_final.pth"))
-        print(f"trained {opt.max_steps} steps: loss {losses[0]:.5f} -> {losses[-1]:.5f}; wrote {os.path.join(ckpt_dir, 'model_final.pth')}")
+        print(f"trained {opt.max_steps} steps: loss {losses[0].item():.5f} -> {losses[-1].item():.5f}; wrote {os.path.join(ckpt_dir, 'model_final.pth')}")
     if opt.gpus > 1:
         dist.destroy_process_group()
 

@@ -29,7 +29,7 @@ def build_dev() -> str:
             subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCAR_ABLATION", *extra, "-c", src, "-o", obj,
                                    "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS[unit]])
         objs.append(obj)
-    for unit in ("car_fused_ws.hip",):                          # development-only units (kernels under evaluation): tools/probes/
+    for unit in (os.environ.get("CAR_DEV_UNIT", "car_fused_v2.hip"),):                          # development-only units (kernels under evaluation): tools/probes/
         src = os.path.join(ROOT, "tools", "probes", unit)
         if not os.path.exists(src):
             continue
