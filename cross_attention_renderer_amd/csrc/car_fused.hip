@@ -121,7 +121,8 @@ __device__ __forceinline__ NextChunk next_chunk_w2(const float* __restrict__ blo
 // 20: the full kernel with shader-clock sums per piece of the chunk loop (where a wave waits inside a chunk)
 // 21: the full kernel, writing each sample's north-west lattice node per source (-1: no fetch) over pixel_val (tap statistics)
 // 22: every tap inside a 1 MB window of its lattice (L2 hits); 28: inside 32 nodes (L1 hits); 23: no weight DMA (barriers kept); 24 = 22 + 23;
-// 30-33: the weight DMA with cache-policy bits nt / sc1 / sc0 sc1 / sc0
+// 30-33: the weight DMA with cache-policy bits nt / sc1 / sc0 sc1 / sc0; 40-43: waves leaving the barrier apart, taps spread over the slots;
+// 50-53: the chunk loop without slot fences, vector / LDS instructions interleaved under the MFMAs by sched_group_barrier (results stay right)
 template <int ABL>
 __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -371,7 +372,19 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
                 const float* w0 = wl + (2 * qs * 2) * 256;
                 { const long long t0 = tick(); if constexpr (ABL != 5) mfma_pair<ABL>(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo); t_mfma += tick() - t0; }
                 piece(qs);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ABL < 50 || ABL > 53) __builtin_amdgcn_sched_barrier(0);
+            }
+            // development build, variants 50-53: no slot fences — the scheduler is asked to put the chunk's vector / LDS instructions UNDER
+            // the MFMAs instead (two vector instructions per 16-clock MFMA are free: profiles/round4_fused_experiments.md section 5)
+            if constexpr (ABL >= 50 && ABL <= 53) {
+#pragma unroll
+                for (int k = 0; k < 54; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                              // one MFMA
+                    if constexpr (ABL == 50 || ABL == 52) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, ABL == 51 || ABL == 53 ? 1 : 2, 0);  // one / two vector instructions
+                    if constexpr (ABL == 51 || ABL == 53) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if constexpr (ABL >= 52) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // a vector-memory read where one is due
+                }
             }
             read_b(bhi, blo);                                          // next chunk's B operand (own LDS tile, in-order LDS)
             // the 8 tap loads issued in slots 3 and 6 stay in flight over the barrier (they are younger than every DMA piece)
@@ -610,7 +623,8 @@ int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* r
         case 24: kern = fused_kernel<24>; break;   case 28: kern = fused_kernel<28>; break;   case 30: kern = fused_kernel<30>; break;
         case 31: kern = fused_kernel<31>; break;   case 32: kern = fused_kernel<32>; break;   case 33: kern = fused_kernel<33>; break;
         case 40: kern = fused_kernel<40>; break;   case 41: kern = fused_kernel<41>; break;   case 42: kern = fused_kernel<42>; break;
-        case 43: kern = fused_kernel<43>; break;
+        case 43: kern = fused_kernel<43>; break;   case 50: kern = fused_kernel<50>; break;   case 51: kern = fused_kernel<51>; break;
+        case 52: kern = fused_kernel<52>; break;   case 53: kern = fused_kernel<53>; break;
         default: break;
     }
 #else
