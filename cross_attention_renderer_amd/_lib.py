@@ -19,7 +19,7 @@ _P = c_void_p
 
 class CarDims(ctypes.Structure):          # struct car_dims
     _fields_ = [("b", c_int), ("V", c_int), ("R", c_int), ("P", c_int), ("H", c_int), ("W", c_int), ("n_levels", c_int),
-                ("level_h", c_int * 4), ("level_w", c_int * 4), ("level_c", c_int * 4), ("repeat_attention", c_int)]
+                ("level_h", c_int * 4), ("level_w", c_int * 4), ("level_c", c_int * 4), ("repeat_attention", c_int), ("no_sample", c_int)]
 
 
 # struct car_weights: device pointers in declaration order (attribute path on the module, flattened to [out, in])
@@ -58,7 +58,7 @@ SIGNATURES = {
     "car_gather_encode": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_long, _P, c_int, _P]),
     "car_fused_blob_floats": (c_size_t, []),
     "car_fused_bias_floats": (c_size_t, []),
-    "car_fused_samples": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+    "car_fused_samples": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   _P, _P, _P, _P, _P, _P, _P]),
     "car_linear_packed_floats": (c_size_t, [c_int, c_int]),
     "car_linear_pack": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),

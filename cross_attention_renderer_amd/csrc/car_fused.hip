@@ -74,6 +74,7 @@ struct FusedArgs {
     const float* blob;
     const float* bias;
     int b, V, R, P, H, W;
+    int no_sample;             // samples at the depths `steps` on the query ray (models.py:221-222) instead of along the epipolar segment
     long S;
     int blk0;                  // first sample group of this launch (0 except in the development build's partial launches)
     float* e;
@@ -184,7 +185,13 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         const CarPose& Ps = a.poses[n];
         const CarRay ray = a.rays[nr];
         CarSample smp;
-        for (int k = 0; k < 2; ++k) smp.grid[k] = ray.start[k] + (ray.end[k] - ray.start[k]) * a.steps[p];
+        if (!a.no_sample) {
+            for (int k = 0; k < 2; ++k) smp.grid[k] = ray.start[k] + (ray.end[k] - ray.start[k]) * a.steps[p];
+        } else {                                                       // geometry.get_epipolar_lines_volumetric: the ray's point at depth steps[p]
+            const float sd = a.steps[p];
+            const float q[3] = {Ps.q_rel[3] + sd * ray.d[0], Ps.q_rel[7] + sd * ray.d[1], Ps.q_rel[11] + sd * ray.d[2]};
+            car_project_grid(Ps.kc, q, a.H, a.W, smp.grid);
+        }
         car_sample_setup(Ps, a.poses + sc * 2, ray, 2, a.H, a.W, &smp);
 #pragma unroll
         for (int sv = 0; sv < 2; ++sv) {
@@ -591,7 +598,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
 
 
 int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w, int lat_pad,
-                 const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W, float* e,
+                 const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W, int no_sample, float* e,
                  float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
     CAR_REQUIRE(poses && rays && steps && lattice && gmeta && wpt && blob && bias, "car_fused_samples: null input");
     CAR_REQUIRE(e && qry && g && logit && pt && pixel_val, "car_fused_samples: null output");
@@ -608,6 +615,7 @@ int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* r
     a.sx = (float)((lat_w - 2 * lat_pad + 1) / 2); a.sy = (float)((lat_h - 2 * lat_pad + 1) / 2);
     a.gmeta = gmeta; a.wpt = wpt; a.blob = blob; a.bias = bias;
     a.b = b; a.V = V; a.R = R; a.P = P; a.H = H; a.W = W;
+    a.no_sample = no_sample != 0;
     a.S = (long)b * V * R * P;
     a.blk0 = blk0;
     a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
@@ -645,28 +653,28 @@ extern "C" size_t car_fused_bias_floats(void) { return (size_t)kBiasFloats; }
 
 extern "C" int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
                                  int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P,
-                                 int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
-    return launch_fused(0, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt, pixel_val,
-                        stream);
+                                 int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+    return launch_fused(0, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, qry, g, logit, pt,
+                        pixel_val, stream);
 }
 
 #ifdef CAR_ABLATION
 // development build only (tools/build_dev.py): timing-only variants of the kernel, results are wrong by construction
 extern "C" int car_fused_samples_ablate(int abl, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h,
                                         int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b,
-                                        int V, int R, int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt,
+                                        int V, int R, int P, int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt,
                                         float* pixel_val, void* stream) {
-    return launch_fused(abl, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g, logit, pt,
+    return launch_fused(abl, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, qry, g, logit, pt,
                         pixel_val, stream);
 }
 // the same launch cut into slices of `nblk` sample groups (one kernel launch each): every slice starts its workgroups in phase
 extern "C" int car_fused_samples_sliced(int nblk, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h,
                                         int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b,
-                                        int V, int R, int P, int H, int W, float* e, float* qry, float* g, float* logit, float* pt,
+                                        int V, int R, int P, int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt,
                                         float* pixel_val, void* stream) {
     const long groups = (long)b * V * car_div_up(R, kTileRays) * car_div_up(P, kTileSteps);
     for (long b0 = 0; b0 < groups; b0 += nblk) {
-        const int rc = launch_fused(0, (int)b0, nblk, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, e, qry, g,
+        const int rc = launch_fused(0, (int)b0, nblk, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, qry, g,
                                     logit, pt, pixel_val, stream);
         if (rc != CAR_OK) return rc;
     }

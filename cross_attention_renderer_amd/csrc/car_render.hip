@@ -552,6 +552,7 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
     float* ws = static_cast<float*>(workspace);
     hipStream_t st = (hipStream_t)stream;
     const int b = d.b, V = d.V, R = d.R, P = d.P;
+    CAR_REQUIRE(!d.no_sample || in->steps, "car_render_forward: no_sample needs `steps` (the P depths along the query ray, models.py:221-222)");
     const float* steps = in->steps ? in->steps : pl + p.steps;
     const long BR = (long)b * R;
     float* coords = out->coords ? out->coords : ws + w.coords;
@@ -564,13 +565,13 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
     {   // a4-a6: rays, their epipolar segments, the decoder's ray input (columns 18, 19 of phi_x stay zero)
         Stage stage("ray_setup", st);
         if (hipMemsetAsync(ws + w.phi_x, 0, sizeof(float) * BR * kPhiLd, st) != hipSuccess) { car_set_error("car_render_forward: memset failed"); return CAR_E_LAUNCH; }
-        CAR_TRY(car_ray_setup(in->poses, in->uv, b, V, R, d.H, d.W, P, 0, steps, ws + w.rays, coords, ws + w.phi_x, kPhiLd, stream));
+        CAR_TRY(car_ray_setup(in->poses, in->uv, b, V, R, d.H, d.W, P, d.no_sample != 0, steps, ws + w.rays, coords, ws + w.phi_x, kPhiLd, stream));
     }
     {   // a6-a13 + round-1 logits: the fused per-sample kernel
         Stage stage("fused_samples", st);
         const Lattice L = lattice_of(d);
         CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->gmeta, pl + p.wpt, pl + p.blob,
-                                  pl + p.fbias, b, V, R, P, d.H, d.W, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
+                                  pl + p.fbias, b, V, R, P, d.H, d.W, d.no_sample != 0, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
     }
     {   // a14 + a16: attention round 1, depth read-out, argmax
         Stage stage("attend_1", st);

@@ -5,12 +5,13 @@ C ABI (``include/car_hip.h``); PyTorch is used for device memory, the stream han
 algebra on the host.  There is no CPU or eager-PyTorch fallback: tensors must live on a ROCm device and the library must load.
 
 Two routes:
-  * the reference's default configuration (n_view = 2, three pyramid levels, 576 channels, epipolar sampling) goes through the
+  * the reference's default configuration (n_view = 2, three pyramid levels, 576 channels; epipolar sampling or ``no_sample``'s depth
+    sampling, with or without the second attention round) goes through the
     ONE-CALL C ABI — ``car_plan_build`` once per set of weights, ``car_project_maps`` once per stereo pair,
     ``car_render_forward`` per batch of rays (csrc/car_render.hip: weight packing and the launch sequence are C++).  This
     module only sizes the calls: rays (and, if need be, scenes) are chunked so that the per-call workspace fits the free device
     memory (rays and scenes are independent, so this changes nothing);
-  * the constructor variants (n_view 1 / 3, no_sample, no_latent_concat, other widths) are sequenced here stage by stage —
+  * the other constructor variants (n_view 1 / 3, no_latent_concat, other widths) are sequenced here stage by stage —
     also the A/B partner of the first route in the tests.
 
 Stage map:
@@ -284,6 +285,7 @@ class RenderEngine:
         for l, t in enumerate(z):
             d.level_c[l], d.level_h[l], d.level_w[l] = t.shape[1], t.shape[2], t.shape[3]
         d.repeat_attention = int(m.repeat_attention)
+        d.no_sample = int(m.no_sample)
         return d
 
     def _plan_for(self, d, device) -> Tensor:
@@ -540,7 +542,7 @@ class RenderEngine:
         steps = self._linspace(0.1, 10.0, P, dev) if m.no_sample else self._linspace(0.0, 1.0, P, dev)
 
         concat2 = (V == 2 and not m.no_latent_concat)
-        if (self.fuse_samples and self.project_maps and concat2 and not m.no_sample and len(z) == 3
+        if (self.fuse_samples and self.project_maps and concat2 and len(z) == 3
                 and sum(t.shape[1] for t in z) == 576 and m.hidden_dim == 128 and m.phi.n_blocks == 3 and m.phi.d_hidden == 128
                 and self._common_lattice(z) and self._lattice_fits(b, R, z)):
             return self._render_one_call(inp, z, poses, uv, steps, b, V, R, P, H, W, debug)

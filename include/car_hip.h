@@ -132,6 +132,8 @@ int car_gather_encode(const float* const* gmaps, const int* level_h, const int* 
  * [-lat_pad, 2 W_m - 1 + lat_pad] that the levels' texel centres share (W_m: the widest level; car_project_maps builds it,
  * car_lattice_shape gives its size; csrc/car_geom.h car_lattice_taps).  `gmeta` [1]: max |lattice| (car_project_maps writes it),
  * from which the kernel derives the power of two that keeps the activations of the first layer inside fp16's range.
+ * `no_sample` = 1: `rays` come from car_ray_setup(no_sample = 1) and `steps` holds the P depths (models.py:221-222): a sample is the
+ * projection of the query ray's point at that depth instead of a point of the clipped epipolar segment; everything after it is the same.
  * Outputs: e [S,576], qry [S,128], g [S,16] (the geometric query local_coords, models.py:528), logit [S], pt [S,3],
  * pixel_val [S,2] with S = b*V*R*P.  The lattice of one (view, padding mode) must stay below 2 GiB (nodes are addressed by 32-bit
  * byte offsets with the upper range reserved for samples that read zeros): a finest level up to ~470 pixels wide; wider pyramids take the
@@ -140,7 +142,7 @@ size_t car_fused_blob_floats(void);
 size_t car_fused_bias_floats(void);
 int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
                       int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P,
-                      int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream);
+                      int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream);
 
 /* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
  *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).
@@ -249,12 +251,14 @@ int car_reduce_samples(const float* d, int b, int V, int R, int P, int C, float*
  *
  * All pointers are device pointers unless marked host; nothing is allocated, nothing is kept.  car_plan_build synchronises
  * the stream once (it uploads a small host table); the other calls are asynchronous.  Unsupported configurations
- * (n_view != 2, other widths, no_sample, no_latent_concat) return CAR_E_ARG: they run through the stage entries above. */
+ * (n_view != 2, other widths, no_latent_concat) return CAR_E_ARG: they run through the stage entries above. */
 typedef struct car_dims {
     int b, V, R, P, H, W;          /* scenes, context views (2), rays per scene, samples per ray and view, image size            */
     int n_levels;                  /* pyramid levels (3)                                                                      */
     int level_h[CAR_MAX_LEVELS], level_w[CAR_MAX_LEVELS], level_c[CAR_MAX_LEVELS];   /* e.g. 64x64x256, 128x128x256, 256x256x64 */
     int repeat_attention;          /* second attention round (models.py:547), the reference's default: 1                          */
+    int no_sample;                 /* 1: samples at uniform depths on the query ray (`steps` = the depths; geometry.py:165-187,     */
+                                   /*    models.py:221-222, 265-266) instead of uniformly along the clipped epipolar segment; default 0 */
 } car_dims;
 
 /* Parameters in the reference's state_dict layout: row-major [out][in] fp32, 1x1 convolutions flattened (models.py:96-144). */

@@ -218,7 +218,7 @@ def test_literal_gather_gemm_pipeline_matches_oracle(name):
     assert err_stats(out["stages"]["interp_val"], out2["stages"]["interp_val"])["max"] < 5e-5
 
 
-@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t2_c2", "t2_c3", "t2_c4", "t2_c5"])
+@pytest.mark.parametrize("name", ["t1_c1", "t1_c1_diverging", "t1_no_sample", "t2_c2", "t2_c3", "t2_c4", "t2_c5"])
 def test_one_call_route_matches_stage_pipeline(name):
     """A/B of the product route (one-call C ABI: csrc/car_render.hip sequencing csrc/car_fused.hip — geometry + encode + e +
     key/query MLPs + logits in one kernel on the f16 matrix pipe with fp16 hi/lo splits — and csrc/car_round2.hip) against the
@@ -581,7 +581,7 @@ def test_lattice_beyond_the_fused_kernels_range_takes_the_stage_route():
         assert eng._lattice_fits(1, 64, z) == fits, H
     lib = _lib()
     one = torch.zeros(64, device="cuda:0")
-    rc = lib.car_fused_samples(_ptr(one), _ptr(one), _ptr(one), _ptr(one), 1033, 1033, 5, _ptr(one), _ptr(one), _ptr(one), _ptr(one), 1, 2, 8, 8, 512, 512,
+    rc = lib.car_fused_samples(_ptr(one), _ptr(one), _ptr(one), _ptr(one), 1033, 1033, 5, _ptr(one), _ptr(one), _ptr(one), _ptr(one), 1, 2, 8, 8, 512, 512, 0,
                                _ptr(one), _ptr(one), _ptr(one), _ptr(one), _ptr(one), _ptr(one), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc != 0 and b"2 GiB" in lib.car_last_error()
 

@@ -100,7 +100,7 @@ def main():
             a.record()
             args = (eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), lat_ptr, lat_h, lat_w, lat_pad,
                     gmeta, wpt.data_ptr(), blob.data_ptr(),
-                    bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
+                    bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, 0, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
                     pixel_val.data_ptr(), st)
             rc = fn_sliced(v - 1000, *args) if v >= 1000 else prod(*args) if v == 100 else fn_ws(*args) if v == 200 else fn_base(*args) if v == 300 else fn(v, *args)
             b_.record()

@@ -32,7 +32,7 @@ def main():
         inp = S.stereo_scene(H, b=1, seed=5, n_view=V)
         z = [t.to(dev) for t in S.feature_maps(1, V, H, seed=1)]
         uv = inp["query"]["uv"]
-        chunks = [harness.to_device({"context": inp["context"], "query": dict(inp["query"], uv=uv[:, :, (96 + 32 * k) * H:(96 + 32 * k) * H + R].contiguous())}, dev)
+        chunks = [harness.to_device({"context": inp["context"], "query": dict(inp["query"], uv=uv[:, :, (16 + 32 * k) * H:(16 + 32 * k) * H + R].contiguous())}, dev)
                   for k in range(calls)]
         with torch.no_grad():
             m(chunks[0], z=z)

@@ -511,8 +511,9 @@ __global__ void __launch_bounds__(kThreads) fused_kernel_v2(const FusedArgs a) {
 
 extern "C" int car_fused_samples_ws(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
                                     int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P,
-                                    int H, int W, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+                                    int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
     CAR_REQUIRE(poses && rays && steps && lattice && gmeta && wpt && blob && bias, "car_fused_samples_v2: null input");
+    CAR_REQUIRE(!no_sample, "car_fused_samples_v2: epipolar sampling only");
     CAR_REQUIRE(e && qry && g && logit && pt && pixel_val, "car_fused_samples_v2: null output");
     CAR_REQUIRE(V == 2, "car_fused_samples_v2: built for V = 2 (got %d)", V);
     CAR_REQUIRE((long)lat_h * lat_w * (kC * 4) < kMaxMapBytes, "car_fused_samples_v2: lattice too large");
