@@ -17,8 +17,10 @@ Gradients flow to every renderer parameter on the path and to the feature pyrami
 autograd, into the encoder when ``z`` came from ``get_z``.  The geometry is not differentiated: nothing in it depends on a parameter.
 PyTorch is plumbing here as everywhere: storage, views, the autograd graph edge, ``torch.distributed``.
 
-Supported: the reference's default configuration family — two context views with the cross-view exchange (``n_view=2``, epipolar
-sampling), with or without the second attention round, any channel widths.  The other constructor variants raise.
+Supported: one or two context views — the default cross-view exchange (``n_view=2``), the single-view merge layer (``n_view=1``,
+models.py:478-485) and ``no_latent_concat`` (the gathered features go straight into the attention, models.py:476-477) —, epipolar or depth
+sampling (``no_sample``), with or without the second attention round, any channel widths.  ``n_view=3`` raises (its cross-view exchange is
+sequenced with torch glue in the inference engine and has no backward yet).
 """
 from __future__ import annotations
 
@@ -28,7 +30,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import _lib
-from .engine import ACCUM, PLACE_OTHER2, PLACE_OWN, RELU_IN, RELU_OUT, PackedLinear, RenderEngine, _ptr, _round_up, _stream
+from .engine import ACCUM, PLACE_OTHER2, PLACE_OWN, PLACE_PLAIN, RELU_IN, RELU_OUT, PackedLinear, RenderEngine, _ptr, _round_up, _stream
 
 Tensor = torch.Tensor
 
@@ -83,8 +85,17 @@ class _Ops:
 
 
 # parameters the path reads, in the order their gradients are returned
+def _mode(m) -> str:
+    """How the per-sample features e are made: "concat2" (two views, point MLP over own ‖ other features), "single" (one view,
+    update_val_merge over features ‖ point channels), "plain" (no_latent_concat: the gathered features themselves)."""
+    if m.no_latent_concat:
+        return "plain"
+    return "concat2" if m.n_view == 2 else "single"
+
+
 def _param_names(m) -> List[str]:
-    names = ["query_encode_latent", "query_encode_latent_2", "latent_value", "key_map", "key_map_2", "query_embed", "query_embed_2"]
+    names = {"concat2": ["query_encode_latent", "query_encode_latent_2"], "single": ["update_val_merge"], "plain": []}[_mode(m)]
+    names = names + ["latent_value", "key_map", "key_map_2", "query_embed", "query_embed_2"]
     if m.repeat_attention:
         names += ["query_repeat_embed", "query_repeat_embed_2", "encode_latent"]
     names += ["phi.lin_in", "phi.lin_out"]
@@ -109,36 +120,54 @@ class _RenderTrain(torch.autograd.Function):
         pk = eng._weights(dev)
         maps = eng._channel_last(z)
         C = sum(t.shape[3] for t in maps)
-        Dl, Ce, hid = m.latent_dim, V * (C // 2), m.phi.d_hidden
+        mode = _mode(m)
+        Dl, Ce, hid = m.latent_dim, (V * (C // 2) if mode == "concat2" else C), m.phi.d_hidden
         poses = eng._poses(inp, H, n, dev)
         uv = inp["query"]["uv"].detach().reshape(b, R, 2).float().contiguous()
-        steps = eng._linspace(0.0, 1.0, P, dev)
+        nos = int(m.no_sample)
+        steps = eng._linspace(0.1, 10.0, P, dev) if nos else eng._linspace(0.0, 1.0, P, dev)
 
         # geometry (constant with respect to every parameter)
         rays = torch.empty(n, R, 12, **f32)
         coords9 = torch.empty(n, R, 9, **f32)
         ld_phi = _round_up(9 * V, 4)
         phi_x = torch.zeros(b * R, ld_phi, **f32)
-        _check(lib.car_ray_setup(_ptr(poses), _ptr(uv), b, V, R, H, W, P, 0, _ptr(steps), _ptr(rays), _ptr(coords9), _ptr(phi_x), ld_phi, st),
+        _check(lib.car_ray_setup(_ptr(poses), _ptr(uv), b, V, R, H, W, P, nos, _ptr(steps), _ptr(rays), _ptr(coords9), _ptr(phi_x), ld_phi, st),
                "car_ray_setup")
         pixel_val = torch.empty(n, R, P, 2, **f32)
         pt = torch.empty(n, R, P, 3, **f32)
         g = torch.empty(S, 16, **f32)
-        grid_in = torch.empty(n, R, P, V, 2, **f32)
-        ld1 = _round_up(C + 3, 32)
-        x1 = torch.zeros(S * V, ld1, **f32)
-        _check(lib.car_sample_setup(_ptr(poses), _ptr(rays), _ptr(steps), b, V, R, P, H, W, 0, _ptr(pixel_val), _ptr(pt), _ptr(g), _ptr(grid_in),
-                                    _ptr(x1), ld1, C, None, st), "car_sample_setup")
-        # a7 / a10: the two gathers, literal
-        eng.gather(maps, pixel_val, R * P, 0, PLACE_OWN, V, x1, ld1, 0, run=P)
-        gi = grid_in.view(b, V, R, P, V, 2)
-        grid_other = torch.stack([gi[:, 1, :, :, 0], gi[:, 0, :, :, 1]], dim=1).contiguous()
-        eng.gather(maps, grid_other, R * P, 1, PLACE_OTHER2, V, x1, ld1, 0, run=P)
-        # a11
-        h1 = torch.empty(S * V, C, **f32)
-        eng.linear(x1, ld1, pk["query_encode_latent"], h1, C, S * V, RELU_OUT)
-        e = torch.empty(S, Ce, **f32)
-        eng.linear(h1, C, pk["query_encode_latent_2"], e, C // 2, S * V)
+        grid_in = grid_other = h1 = x1 = None
+        ld1 = 0
+        if mode == "concat2":
+            grid_in = torch.empty(n, R, P, V, 2, **f32)
+            ld1 = _round_up(C + 3, 32)
+            x1 = torch.zeros(S * V, ld1, **f32)
+            _check(lib.car_sample_setup(_ptr(poses), _ptr(rays), _ptr(steps), b, V, R, P, H, W, nos, _ptr(pixel_val), _ptr(pt), _ptr(g), _ptr(grid_in),
+                                        _ptr(x1), ld1, C, None, st), "car_sample_setup")
+            # a7 / a10: the two gathers, literal
+            eng.gather(maps, pixel_val, R * P, 0, PLACE_OWN, V, x1, ld1, 0, run=P)
+            gi = grid_in.view(b, V, R, P, V, 2)
+            grid_other = torch.stack([gi[:, 1, :, :, 0], gi[:, 0, :, :, 1]], dim=1).contiguous()
+            eng.gather(maps, grid_other, R * P, 1, PLACE_OTHER2, V, x1, ld1, 0, run=P)
+            # a11
+            h1 = torch.empty(S * V, C, **f32)
+            eng.linear(x1, ld1, pk["query_encode_latent"], h1, C, S * V, RELU_OUT)
+            e = torch.empty(S, Ce, **f32)
+            eng.linear(h1, C, pk["query_encode_latent_2"], e, C // 2, S * V)
+        elif mode == "single":                                   # models.py:478-485: features ‖ tanh(pt/5) ‖ tanh(pt/100) -> update_val_merge
+            ld1 = _round_up(C + 6, 32)
+            x1 = torch.zeros(S, ld1, **f32)
+            _check(lib.car_sample_setup(_ptr(poses), _ptr(rays), _ptr(steps), b, V, R, P, H, W, nos, _ptr(pixel_val), _ptr(pt), _ptr(g), None,
+                                        _ptr(x1), ld1, C, None, st), "car_sample_setup")
+            eng.gather(maps, pixel_val, R * P, 0, PLACE_PLAIN, V, x1, ld1, 0, run=P)
+            e = torch.empty(S, Ce, **f32)
+            eng.linear(x1, ld1, pk["update_val_merge"], e, Ce, S)
+        else:                                                    # no_latent_concat: the gathered features are e
+            _check(lib.car_sample_setup(_ptr(poses), _ptr(rays), _ptr(steps), b, V, R, P, H, W, nos, _ptr(pixel_val), _ptr(pt), _ptr(g), None,
+                                        None, 0, 0, None, st), "car_sample_setup")
+            e = torch.empty(S, Ce, **f32)
+            eng.gather(maps, pixel_val, R * P, 0, PLACE_PLAIN, V, e, Ce, 0, run=P)
         # a12, a13
         k1 = torch.empty(S, 128, **f32)
         eng.linear(e, Ce, pk["key_map"], k1, 128, S, RELU_OUT)
@@ -205,6 +234,7 @@ class _RenderTrain(torch.autograd.Function):
         saved.update(zrep=zrep, xas=xas, nets=nets, x3=x, valid=valid)
         ctx.saved, ctx.ops, ctx.module, ctx.n_levels = saved, ops, module, n_levels
         ctx.dims = (b, V, R, P, C, Dl, Ce, hid, ld1, ld_phi)
+        ctx.mode = mode
         ctx.maps = maps
         ctx.params = {nme: t for nme, t in zip(_param_names(m), tensors[n_levels:])}
         # the activations live as plain attributes (most are views into buffers autograd does not need to track), so autograd's own
@@ -270,7 +300,10 @@ class _RenderTrain(torch.autograd.Function):
             wgrad("phi.lin_in", d_x, hid, sv["phi_x"], ld_phi, bR)
             # the V copies of z
             d_zf = torch.empty(bR, Dl, **f32)
-            ops.add(d_zf, Dl, d_zrep, V * Dl, 1.0, d_zrep[:, Dl:], V * Dl, 1.0, bR, Dl)
+            if V == 1:
+                ops.add(d_zf, Dl, d_zrep, V * Dl, 1.0, None, 0, 0.0, bR, Dl)
+            else:
+                ops.add(d_zf, Dl, d_zrep, V * Dl, 1.0, d_zrep[:, Dl:], V * Dl, 1.0, bR, Dl)
             for v in range(2, V):
                 ops.add(d_zf, Dl, d_zf, Dl, 1.0, d_zrep[:, v * Dl:], V * Dl, 1.0, bR, Dl)
 
@@ -322,22 +355,35 @@ class _RenderTrain(torch.autograd.Function):
             dx("query_embed_2", d_q, 128, d_k1, 128, S)                                               # d q1 (buffer reused)
             ops.relu_mask(d_k1, 128, sv["q1"], 128, S, 128)
             wgrad("query_embed", d_k1, 128, sv["g"], 16, S)
-            # ---- a11
-            wgrad("query_encode_latent_2", d_e, C // 2, sv["h1"], C, S * V)
-            d_h1 = torch.empty(S * V, C, **f32)
-            dx("query_encode_latent_2", d_e, C // 2, d_h1, C, S * V)
-            ops.relu_mask(d_h1, C, sv["h1"], C, S * V, C)
-            wgrad("query_encode_latent", d_h1, C, sv["x1"], ld1, S * V)
             dz = [None] * ctx.n_levels
-            if ctx.need_dz:                                  # the pyramid asked for a gradient (z from get_z under autograd, or a leaf)
-                d_x1 = torch.empty(S * V, ld1, **f32)
-                dx("query_encode_latent", d_h1, C, d_x1, ld1, S * V)
+            need = list(ctx.needs_input_grad[3:3 + ctx.n_levels])
+            mode = ctx.mode
+            d_gather = None                                   # (gradient of the gathered rows, its row stride, [(grid, padding mode, placement)])
+            if mode == "concat2":
+                # ---- a11
+                wgrad("query_encode_latent_2", d_e, C // 2, sv["h1"], C, S * V)
+                d_h1 = torch.empty(S * V, C, **f32)
+                dx("query_encode_latent_2", d_e, C // 2, d_h1, C, S * V)
+                ops.relu_mask(d_h1, C, sv["h1"], C, S * V, C)
+                wgrad("query_encode_latent", d_h1, C, sv["x1"], ld1, S * V)
+                if ctx.need_dz:                               # the pyramid asked for a gradient (z from get_z under autograd, or a leaf)
+                    d_x1 = torch.empty(S * V, ld1, **f32)
+                    dx("query_encode_latent", d_h1, C, d_x1, ld1, S * V)
+                    d_gather = (d_x1, ld1, [(sv["pixel_val"], 0, PLACE_OWN), (sv["grid_other"], 1, PLACE_OTHER2)])
+            elif mode == "single":
+                wgrad("update_val_merge", d_e, Ce, sv["x1"], ld1, S)
+                if ctx.need_dz:
+                    d_x1 = torch.empty(S, ld1, **f32)
+                    dx("update_val_merge", d_e, Ce, d_x1, ld1, S)
+                    d_gather = (d_x1, ld1, [(sv["pixel_val"], 0, PLACE_PLAIN)])
+            elif ctx.need_dz:
+                d_gather = (d_e, Ce, [(sv["pixel_val"], 0, PLACE_PLAIN)])
+            if d_gather is not None:
                 # ---- a7 / a10: scatter into the pyramid
                 dmaps = [torch.zeros_like(t) for t in ctx.maps]
-                ops.gather_backward(dmaps, sv["pixel_val"], R * P, 0, PLACE_OWN, V, d_x1, ld1, 0)
-                ops.gather_backward(dmaps, sv["grid_other"], R * P, 1, PLACE_OTHER2, V, d_x1, ld1, 0)
-                dz = [t.permute(0, 3, 1, 2).contiguous().to(dt) if need else None
-                      for t, dt, need in zip(dmaps, ctx.z_dtypes, ctx.needs_input_grad[3:3 + ctx.n_levels])]
+                for grid, pad_mode, place in d_gather[2]:
+                    ops.gather_backward(dmaps, grid, R * P, pad_mode, place, V, d_gather[0], d_gather[1], 0)
+                dz = [t.permute(0, 3, 1, 2).contiguous().to(dt) if nd else None for t, dt, nd in zip(dmaps, ctx.z_dtypes, need)]
         out = [None, None, None] + dz + [grads[k].view_as(par[k]).to(par[k].dtype) for k in _param_names(m)]
         return tuple(out)
 
@@ -347,9 +393,9 @@ def render_train(module, inp, z: Optional[List[Tensor]] = None) -> Dict[str, Ten
     ``rgb`` and ``depth_ray`` carry gradients to the renderer's parameters and to ``z`` (``z=None``: ``get_z`` runs under autograd, so
     the encoder trains too)."""
     m = module
-    if m.n_view != 2 or m.no_latent_concat or m.no_sample:
-        raise NotImplementedError("render_train covers the reference's default configuration family (n_view = 2, epipolar sampling, "
-                                  "cross-view exchange); the constructor variants have no backward yet")
+    if m.n_view not in (1, 2):
+        raise NotImplementedError("render_train covers one or two context views (default exchange, single view, no_latent_concat, no_sample); "
+                                  "n_view = 3 has no backward yet")
     dev = inp["query"]["uv"].device
     if dev.type != "cuda":
         raise RuntimeError("render_train runs on the HIP engine only: move the model, the input dict and z to a ROCm device")

@@ -18,6 +18,10 @@ def test_oracle_autograd_reproduces_the_reference_gradients(name):
     stored = G.keys(fx)
     assert sorted(og) == stored, (sorted(set(og) ^ set(stored)))
     unused = set(fx["unused"].tolist())
-    assert "latent_avg_query.weight" in unused and "update_val_merge.weight" in unused       # declared, never on the n_view = 2 forward path
+    assert "latent_avg_query.weight" in unused               # declared by the reference, never on any forward path
+    if c["n_view"] == 2 and not c["no_latent_concat"]:
+        assert "update_val_merge.weight" in unused           # only the single-view forward uses it (models.py:485)
+    if c["no_latent_concat"]:
+        assert "feature_map.weight" in unused                # declared for no_latent_concat, never applied
     worst = max(G.compare(fx, k, og[k], tol=1e-4)[0] for k in stored)
     assert worst <= G.FLIP_WORST
