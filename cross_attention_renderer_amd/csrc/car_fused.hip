@@ -331,9 +331,15 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     }
     stream_sync();                                                     // weight chunk 0 landed
     mark(2);
-    constexpr bool kTapsLive = (ABL == 0 || ABL >= 4);
-    issue_row(bufA, 0, 1, 0);                                          // pipeline prologue: chunk (0, 1), both row groups
-    issue_row(bufB, 0, 1, 1);
+    // development build, variants 63-65: ONE tap buffer — a row group's taps are issued four slots (not a whole chunk) before they are blended:
+    // row group 0 in slot 0, blended in slot 4, where row group 1 is issued, blended in slot 8; nothing in flight over the barrier.  The 16
+    // registers this frees hold the NEXT slot's A operands (64, 65): a true double buffer instead of 4 reads + wait in front of every 6 MFMAs
+    constexpr bool kOneTapBuf = (ABL == 63 || ABL == 64 || ABL == 65);
+    constexpr bool kTapsLive = (ABL == 0 || ABL >= 4) && !kOneTapBuf;
+    if constexpr (!kOneTapBuf) {
+        issue_row(bufA, 0, 1, 0);                                      // pipeline prologue: chunk (0, 1), both row groups
+        issue_row(bufB, 0, 1, 1);
+    }
 
     // ABL 20 (development build): shader-clock time the wave spends, per piece of the chunk loop, summed over the source passes and
     // written over pixel_val (tools/bench_fused.py 20); in every other variant tick() is 0 and all of this folds away
@@ -374,12 +380,80 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
                 else if (qs == 3) { const long long t0 = tick(); blend_row(bufA, nsv, 0); const long long t1 = tick(); finish_row(0); issue_row(bufA, n2sv, n2c, 0); t_blend += t1 - t0; t_issue += tick() - t1; }
                 else if (qs == 6) { const long long t0 = tick(); blend_row(bufB, nsv, 1); const long long t1 = tick(); finish_row(1); issue_row(bufB, n2sv, n2c, 1); t_blend += t1 - t0; t_issue += tick() - t1; }
             };
+            if constexpr (kOneTapBuf) {
+                auto load_a = [&](int qs, half8 (&a)[4]) {
+                    const float* w0 = wl + (2 * qs * 2) * 256;
+                    a[0] = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0));
+                    a[1] = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0 + 512));
+                    a[2] = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0 + 256));
+                    a[3] = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0 + 768));
+                };
+                auto mma = [&](f32x4& c0, f32x4& c1, const half8 (&a)[4]) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bhi, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], bhi, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], blo, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], blo, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[2], bhi, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[3], bhi, c1, 0, 0, 0);
+                };
+                auto piece1 = [&](int qs) {
+                    if (qs < kPieces) stream_issue_piece<ABL>(nx, qs, lane, wave);
+                    if (qs == 0) { affine_row(nsv, nc, 0); affine_row(nsv, nc, 1); issue_row(bufA, nsv, nc, 0); }
+                    else if (qs == 4) { blend_row(bufA, nsv, 0); finish_row(0); issue_row(bufA, nsv, nc, 1); }
+                    else if (qs == 8) { blend_row(bufA, nsv, 1); finish_row(1); }
+                };
+                half8 a0[4], a1[4];
+                if constexpr (ABL != 63) load_a(0, a0);
+#pragma unroll
+                for (int qs = 0; qs < kTE / 2; ++qs) {
+                    if constexpr (ABL == 63) { load_a(qs, a0); mma(acc[2 * qs], acc[2 * qs + 1], a0); piece1(qs); }
+                    else {
+                        if (qs + 1 < kTE / 2) { if (qs & 1) load_a(qs + 1, a0); else load_a(qs + 1, a1); }
+                        if constexpr (ABL == 65) piece1(qs);               // 65: the piece under the LDS round trip, then the MFMAs
+                        if (qs & 1) mma(acc[2 * qs], acc[2 * qs + 1], a1); else mma(acc[2 * qs], acc[2 * qs + 1], a0);
+                        if constexpr (ABL == 64) piece1(qs);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (ABL == 60 || ABL == 61 || ABL == 62) {
+                // development build: the A operands of slot qs + 1 are read right after slot qs's MFMAs have issued — into the registers those
+                // MFMAs have just read — so that their LDS round trip runs under the slot's gather / DMA piece instead of in front of the next
+                // MFMAs (no extra registers: the read-ahead of round 3 needed 16 and spilled).  61: the piece comes BEFORE the MFMAs instead
+                // (reads issued, piece, MFMAs).  62: both (reads for the next slot after the MFMAs, and the piece first).
+                auto load_a = [&](int qs, half8& ah0, half8& ah1, half8& al0, half8& al1) {
+                    const float* w0 = wl + (2 * qs * 2) * 256;
+                    ah0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0));
+                    ah1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0 + 512));
+                    al0 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0 + 256));
+                    al1 = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w0 + 768));
+                };
+                auto mma = [&](f32x4& c0, f32x4& c1, const half8& ah0, const half8& ah1, const half8& al0, const half8& al1) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bhi, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bhi, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, blo, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, blo, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bhi, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bhi, c1, 0, 0, 0);
+                };
+                half8 ah0, ah1, al0, al1;
+                if constexpr (ABL != 61) load_a(0, ah0, ah1, al0, al1);
+#pragma unroll
+                for (int qs = 0; qs < kTE / 2; ++qs) {
+                    if constexpr (ABL == 61) { load_a(qs, ah0, ah1, al0, al1); piece(qs); }
+                    if constexpr (ABL == 62) piece(qs);
+                    mma(acc[2 * qs], acc[2 * qs + 1], ah0, ah1, al0, al1);
+                    if constexpr (ABL != 61) { if (qs + 1 < kTE / 2) load_a(qs + 1, ah0, ah1, al0, al1); }
+                    if constexpr (ABL == 60) piece(qs);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll
             for (int qs = 0; qs < kTE / 2; ++qs) {
                 const float* w0 = wl + (2 * qs * 2) * 256;
                 { const long long t0 = tick(); if constexpr (ABL != 5) mfma_pair<ABL>(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo); t_mfma += tick() - t0; }
                 piece(qs);
                 if constexpr (ABL < 50 || ABL > 53) __builtin_amdgcn_sched_barrier(0);
+            }
             }
             // development build, variants 50-53: no slot fences — the scheduler is asked to put the chunk's vector / LDS instructions UNDER
             // the MFMAs instead (two vector instructions per 16-clock MFMA are free: profiles/round4_fused_experiments.md section 5)
@@ -632,7 +706,9 @@ int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* r
         case 31: kern = fused_kernel<31>; break;   case 32: kern = fused_kernel<32>; break;   case 33: kern = fused_kernel<33>; break;
         case 40: kern = fused_kernel<40>; break;   case 41: kern = fused_kernel<41>; break;   case 42: kern = fused_kernel<42>; break;
         case 43: kern = fused_kernel<43>; break;   case 50: kern = fused_kernel<50>; break;   case 51: kern = fused_kernel<51>; break;
-        case 52: kern = fused_kernel<52>; break;   case 53: kern = fused_kernel<53>; break;
+        case 52: kern = fused_kernel<52>; break;   case 53: kern = fused_kernel<53>; break;   case 60: kern = fused_kernel<60>; break;
+        case 61: kern = fused_kernel<61>; break;   case 62: kern = fused_kernel<62>; break;   case 63: kern = fused_kernel<63>; break;
+        case 64: kern = fused_kernel<64>; break;   case 65: kern = fused_kernel<65>; break;
         default: break;
     }
 #else

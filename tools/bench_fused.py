@@ -179,7 +179,7 @@ def main():
             print(f"   gather wave per period: finish (wait taps, blend, split, write) {gx[2]:.0f}, issue of 4 x 6 tap loads {gx[5]:.0f}")
             print(f"   matrix wave per chunk: MFMA groups + DMA issue {mw[0]:.0f}, wait for own DMA {mw[2]:.0f}, barrier {mw[1]:.0f};  "
                   f"gather wave per period: 6 row groups {gw_[0]:.0f}, barrier {gw_[1]:.0f}  (s_memtime ticks)")
-        if v in (0, 100, 200, 300) or v >= 1000:                     # keep the results: the development kernels must equal the product's bit for bit
+        if v in (0, 100, 200, 300) or v >= 1000 or 60 <= v <= 69:    # keep the results: the development kernels must equal the product's bit for bit
             outs[v] = [torch.empty(cnt_, device=dev).copy_(eng._work[o_:o_ + cnt_]) for o_, cnt_ in
                        [(lambda n_: (lib.car_workspace_find(ctypes.byref(d), n_.encode(), ctypes.byref(off), ctypes.byref(cnt)), (off.value, cnt.value))[1])(n_)
                         for n_ in ("e", "qry", "logit", "pt", "g")]]

@@ -309,8 +309,12 @@ __global__ void __launch_bounds__(kThreads) fused_kernel_v2(const FusedArgs a) {
 #pragma unroll
                 for (int st = 0; st < kST; ++st) acc[ct * kST + st] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bhi[st], acc[ct * kST + st], 0, 0, 0);
                 if (ct < kPieces) stream_issue_piece<0>(nx, ct, lane, wave);
-                if (ct == 3) { gather_row(bufA, nsv, nc, 0, hn); issue_row(bufA, n2sv, n2c, 0); }
-                else if (ct == 6) { gather_row(bufB, nsv, nc, 1, hn); issue_row(bufB, n2sv, n2c, 1); }
+#ifndef CAR_V2_SLOT_A
+#define CAR_V2_SLOT_A 3
+#define CAR_V2_SLOT_B 6
+#endif
+                if (ct == CAR_V2_SLOT_A) { gather_row(bufA, nsv, nc, 0, hn); issue_row(bufA, n2sv, n2c, 0); }
+                else if (ct == CAR_V2_SLOT_B) { gather_row(bufB, nsv, nc, 1, hn); issue_row(bufB, n2sv, n2c, 1); }
                 __builtin_amdgcn_sched_barrier(0);
             }
             stream_sync<0, 8>();                                       // the 8 tap loads of slots 2 and 4 stay in flight over the barrier
