@@ -635,12 +635,13 @@ class RenderEngine:
 
         return self._finish(inp, z, b, V, R, P, Ce, Dl, e, key, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug)
 
-    def _encode_three_views(self, maps, poses, pixel_val, ptenc, pt_in, b, R, P, H, W, C, pk):
+    def _encode_three_views(self, maps, poses, pixel_val, ptenc, pt_in, b, R, P, H, W, C, pk, keep=None):
         """Cross-view exchange for three context views (models.py:345-475), restated literally: for the samples of context c
         the row is the channel-interleaved concatenation of enc(own features, point in frame c) and, for every other view o
         in ascending order, enc(features of view o where context o's points — moved into frame c, projected with view o's
         intrinsics — land in image o, those points in frame c).  All arithmetic is in HIP kernels (gather, projection, the two
-        1x1 layers); torch only moves rows into place."""
+        1x1 layers); torch only moves rows into place.  ``keep`` (a dict): the training forward's saves — the 579-wide rows, the first
+        layer's activations and every cross-view gather's grid (training.render_train)."""
         V, pts = 3, R * P
         S = b * V * pts
         dev = pixel_val.device
@@ -666,6 +667,8 @@ class RenderEngine:
                 _lib.check(self.lib.car_project_points(_ptr(poses), _ptr(q), b, pts, V, o, H, W, _ptr(grid), _stream()),
                            "car_project_points")
                 self.gather(per_view[o], grid, pts, 1, PLACE_PLAIN, 1, tmp2, C, 0, run=P)
+                if keep is not None:
+                    keep.setdefault("cross", []).append((c, o, k, grid.clone()))
                 x3v[:, c, :, k, :C] = tmp2.view(b, pts, C)
                 x3v[:, c, :, k, C:C + 3] = pe[:, o, :, c, :3]
                 k += 1
@@ -673,6 +676,8 @@ class RenderEngine:
         self.linear(x3, ld, pk["query_encode_latent"], h1, C, S * 3, RELU_OUT)
         enc = torch.empty(S * 3, C // 2, **f32)
         self.linear(h1, C, pk["query_encode_latent_2"], enc, C // 2, S * 3)
+        if keep is not None:
+            keep.update(x3=x3, h1=h1, ld=ld)
         # channel index = ch*3 + k (torch.cat on dim 2 then flatten(1, 2), models.py:446)
         return enc.view(S, 3, C // 2).permute(0, 2, 1).contiguous().view(S, 3 * (C // 2))
 

@@ -17,10 +17,10 @@ Gradients flow to every renderer parameter on the path and to the feature pyrami
 autograd, into the encoder when ``z`` came from ``get_z``.  The geometry is not differentiated: nothing in it depends on a parameter.
 PyTorch is plumbing here as everywhere: storage, views, the autograd graph edge, ``torch.distributed``.
 
-Supported: one or two context views — the default cross-view exchange (``n_view=2``), the single-view merge layer (``n_view=1``,
-models.py:478-485) and ``no_latent_concat`` (the gathered features go straight into the attention, models.py:476-477) —, epipolar or depth
-sampling (``no_sample``), with or without the second attention round, any channel widths.  ``n_view=3`` raises (its cross-view exchange is
-sequenced with torch glue in the inference engine and has no backward yet).
+Supported: every constructor variant of the reference — the default cross-view exchange (``n_view=2``), the three-view exchange
+(``n_view=3``, models.py:345-475), the single-view merge layer (``n_view=1``, models.py:478-485), ``no_latent_concat`` (the gathered
+features go straight into the attention, models.py:476-477), epipolar or depth sampling (``no_sample``), with or without the second
+attention round, any channel widths.
 """
 from __future__ import annotations
 
@@ -90,11 +90,12 @@ def _mode(m) -> str:
     update_val_merge over features ‖ point channels), "plain" (no_latent_concat: the gathered features themselves)."""
     if m.no_latent_concat:
         return "plain"
-    return "concat2" if m.n_view == 2 else "single"
+    return {1: "single", 2: "concat2", 3: "concat3"}[m.n_view]
 
 
 def _param_names(m) -> List[str]:
-    names = {"concat2": ["query_encode_latent", "query_encode_latent_2"], "single": ["update_val_merge"], "plain": []}[_mode(m)]
+    names = {"concat2": ["query_encode_latent", "query_encode_latent_2"], "concat3": ["query_encode_latent", "query_encode_latent_2"],
+             "single": ["update_val_merge"], "plain": []}[_mode(m)]
     names = names + ["latent_value", "key_map", "key_map_2", "query_embed", "query_embed_2"]
     if m.repeat_attention:
         names += ["query_repeat_embed", "query_repeat_embed_2", "encode_latent"]
@@ -121,7 +122,7 @@ class _RenderTrain(torch.autograd.Function):
         maps = eng._channel_last(z)
         C = sum(t.shape[3] for t in maps)
         mode = _mode(m)
-        Dl, Ce, hid = m.latent_dim, (V * (C // 2) if mode == "concat2" else C), m.phi.d_hidden
+        Dl, Ce, hid = m.latent_dim, (V * (C // 2) if mode in ("concat2", "concat3") else C), m.phi.d_hidden
         poses = eng._poses(inp, H, n, dev)
         uv = inp["query"]["uv"].detach().reshape(b, R, 2).float().contiguous()
         nos = int(m.no_sample)
@@ -155,6 +156,14 @@ class _RenderTrain(torch.autograd.Function):
             eng.linear(x1, ld1, pk["query_encode_latent"], h1, C, S * V, RELU_OUT)
             e = torch.empty(S, Ce, **f32)
             eng.linear(h1, C, pk["query_encode_latent_2"], e, C // 2, S * V)
+        elif mode == "concat3":                                  # models.py:345-475: the three-view exchange, sequenced by the engine
+            xpe = torch.zeros(S * V, 4, **f32)                    # tanh(pt in frame s / 5) per (sample, frame)
+            pt_in = torch.empty(n, R, P, V, 3, **f32)
+            _check(lib.car_sample_setup(_ptr(poses), _ptr(rays), _ptr(steps), b, V, R, P, H, W, nos, _ptr(pixel_val), _ptr(pt), _ptr(g), None,
+                                        _ptr(xpe), 4, 0, _ptr(pt_in), st), "car_sample_setup")
+            keep3: dict = {}
+            e = eng._encode_three_views(maps, poses, pixel_val, xpe, pt_in, b, R, P, H, W, C, pk, keep=keep3)
+            x1, h1, ld1 = keep3["x3"], keep3["h1"], keep3["ld"]
         elif mode == "single":                                   # models.py:478-485: features ‖ tanh(pt/5) ‖ tanh(pt/100) -> update_val_merge
             ld1 = _round_up(C + 6, 32)
             x1 = torch.zeros(S, ld1, **f32)
@@ -186,7 +195,7 @@ class _RenderTrain(torch.autograd.Function):
                               _ptr(depth), _ptr(amax), st), "car_attend")
         zrep = torch.empty(b * R, V * Dl, **f32)
         saved = dict(x1=x1, h1=h1, e=e, k1=k1, key=key, q1=q1, q=q, at_wt=at_wt, ebar1=ebar1, g=g, pt=pt, poses=poses, rays=rays, phi_x=phi_x,
-                     pixel_val=pixel_val, grid_other=grid_other)
+                     pixel_val=pixel_val, grid_other=grid_other, cross=(keep3["cross"] if mode == "concat3" else None))
         ops = getattr(eng, "_train_ops", None)              # kept on the engine: its transposed-weight cache (keyed on data_ptr / _version)
         if ops is None or ops.eng is not eng:               # then survives from step to step and re-packs only what the optimizer changed
             ops = eng._train_ops = _Ops(eng)
@@ -370,6 +379,28 @@ class _RenderTrain(torch.autograd.Function):
                     d_x1 = torch.empty(S * V, ld1, **f32)
                     dx("query_encode_latent", d_h1, C, d_x1, ld1, S * V)
                     d_gather = (d_x1, ld1, [(sv["pixel_val"], 0, PLACE_OWN), (sv["grid_other"], 1, PLACE_OTHER2)])
+            elif mode == "concat3":
+                # e[s, ch * 3 + k] = enc[(s, k), ch] (models.py:446): back to one row per (sample, component)
+                d_enc = d_e.view(S, C // 2, 3).permute(0, 2, 1).contiguous().view(S * 3, C // 2)
+                wgrad("query_encode_latent_2", d_enc, C // 2, sv["h1"], C, S * 3)
+                d_h1 = torch.empty(S * 3, C, **f32)
+                dx("query_encode_latent_2", d_enc, C // 2, d_h1, C, S * 3)
+                ops.relu_mask(d_h1, C, sv["h1"], C, S * 3, C)
+                wgrad("query_encode_latent", d_h1, C, sv["x1"], ld1, S * 3)
+                if ctx.need_dz:
+                    d_x3 = torch.empty(S * 3, ld1, **f32)
+                    dx("query_encode_latent", d_h1, C, d_x3, ld1, S * 3)
+                    d_x3v = d_x3.view(b, V, R * P, 3, ld1)
+                    dmaps = [torch.zeros_like(t) for t in ctx.maps]
+                    d_own = d_x3v[:, :, :, 0, :C].contiguous().view(S, C)       # component 0: the view's own features at its own samples
+                    ops.gather_backward(dmaps, sv["pixel_val"], R * P, 0, PLACE_PLAIN, V, d_own, C, 0)
+                    for c_, o_, k_, grid in sv["cross"]:                          # component k of context c: view o's features at `grid`
+                        d_rows = d_x3v[:, c_, :, k_, :C].contiguous().view(b * R * P, C)
+                        dm_o = [torch.zeros(b, *t.shape[1:], **f32) for t in ctx.maps]
+                        ops.gather_backward(dm_o, grid, R * P, 1, PLACE_PLAIN, 1, d_rows, C, 0)
+                        for full, part in zip(dmaps, dm_o):
+                            full.view(b, V, *full.shape[1:])[:, o_] += part
+                    dz = [t.permute(0, 3, 1, 2).contiguous().to(dt) if nd else None for t, dt, nd in zip(dmaps, ctx.z_dtypes, need)]
             elif mode == "single":
                 wgrad("update_val_merge", d_e, Ce, sv["x1"], ld1, S)
                 if ctx.need_dz:
@@ -393,9 +424,8 @@ def render_train(module, inp, z: Optional[List[Tensor]] = None) -> Dict[str, Ten
     ``rgb`` and ``depth_ray`` carry gradients to the renderer's parameters and to ``z`` (``z=None``: ``get_z`` runs under autograd, so
     the encoder trains too)."""
     m = module
-    if m.n_view not in (1, 2):
-        raise NotImplementedError("render_train covers one or two context views (default exchange, single view, no_latent_concat, no_sample); "
-                                  "n_view = 3 has no backward yet")
+    if m.n_view not in (1, 2, 3):
+        raise NotImplementedError("render_train covers one, two or three context views (the reference's n_view)")
     dev = inp["query"]["uv"].device
     if dev.type != "cuda":
         raise RuntimeError("render_train runs on the HIP engine only: move the model, the input dict and z to a ROCm device")

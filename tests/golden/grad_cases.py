@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
-GRAD_CASES = ("t0_default", "t0_no_repeat", "t1_c1", "t0_no_sample", "t0_no_latent_concat", "t0_nview1", "t1_no_sample", "t1_no_latent_concat", "t1_nview1")
+GRAD_CASES = ("t0_default", "t0_no_repeat", "t1_c1", "t0_no_sample", "t0_no_latent_concat", "t0_nview1", "t1_no_sample", "t1_no_latent_concat", "t1_nview1", "t0_nview3", "t1_nview3")
 WHOLE = 8192            # tensors up to this many entries are stored whole
 SAMPLE = 4096           # entries sampled from a larger one
 COT_SEED, IDX_SEED = 77, 78
