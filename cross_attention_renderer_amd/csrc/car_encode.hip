@@ -31,7 +31,7 @@ struct EncodeLevels {
 __global__ void __launch_bounds__(256) encode_kernel(EncodeLevels L, int Cg, const float* __restrict__ pixel_val,
                                                      const float* __restrict__ grid_in, const float* __restrict__ ptenc,
                                                      const float* __restrict__ wpt, int V, long pts, long rows,
-                                                     float* __restrict__ out, int ld_out) {
+                                                     float* __restrict__ out, int ld_out, const int* __restrict__ row_src) {
     __shared__ int s_idx[kRows][CAR_MAX_LEVELS][4];
     __shared__ float s_w[kRows][CAR_MAX_LEVELS][4];
     __shared__ float s_pe[kRows][4];
@@ -42,14 +42,20 @@ __global__ void __launch_bounds__(256) encode_kernel(EncodeLevels L, int Cg, con
         const int rl = tid / L.n_levels, l = tid % L.n_levels;
         long row = row0 + rl;
         if (row >= rows) row = rows - 1;
-        const long i = row / V;                  // sample (n, r, p)
-        const int s = (int)(row % V);            // source view of this row
-        const int n = (int)(i / pts);
-        const int v = n % V, sc = n / V;
         float gx, gy;
         int mode, m;
-        if (s == v) { gx = pixel_val[2 * i]; gy = pixel_val[2 * i + 1]; mode = 0; m = n; }
-        else { gx = grid_in[(i * V + s) * 2]; gy = grid_in[(i * V + s) * 2 + 1]; mode = 1; m = sc * V + s; }
+        if (row_src) {                           // explicit rows (car_gather_encode_rows): map | padding mode << 30, the row's own grid point
+            const int src = row_src[row];
+            m = src & 0x3fffffff; mode = (src >> 30) & 1;
+            gx = pixel_val[2 * row]; gy = pixel_val[2 * row + 1];
+        } else {
+            const long i = row / V;              // sample (n, r, p)
+            const int s = (int)(row % V);        // source view of this row
+            const int n = (int)(i / pts);
+            const int v = n % V, sc = n / V;
+            if (s == v) { gx = pixel_val[2 * i]; gy = pixel_val[2 * i + 1]; mode = 0; m = n; }
+            else { gx = grid_in[(i * V + s) * 2]; gy = grid_in[(i * V + s) * 2 + 1]; mode = 1; m = sc * V + s; }
+        }
         int idx[4];
         float w[4];
         car_bilinear_taps(gx, gy, L.w[l], L.h[l], mode, idx, w);
@@ -106,7 +112,33 @@ extern "C" int car_gather_encode(const float* const* gmaps, const int* level_h, 
     const long rows = (long)n_maps * pts * V;
     (void)hipGetLastError();
     hipLaunchKernelGGL(encode_kernel, dim3(car_div_up(rows, kRows)), dim3(256), 0, (hipStream_t)stream, L, Cg, pixel_val,
-                       grid_in, ptenc, wpt, V, pts, rows, out, ld_out);
+                       grid_in, ptenc, wpt, V, pts, rows, out, ld_out, (const int*)nullptr);
     CAR_CHECK_LAUNCH("car_gather_encode");
+    return CAR_OK;
+}
+
+// The same layer for an explicit list of rows: row i gathers map (row_src[i] & 0x3fffffff) at row_grid[i] with padding mode
+// (row_src[i] >> 30) & 1 (0 border, 1 zeros) and adds the point term of row_pe[i].  This is what the three-view exchange needs
+// (models.py:345-475: every sample of context c carries its own features and, per other view o, view o's features where CONTEXT o's points
+// land — nine different (map, grid, point) combinations per scene, listed by the host).
+extern "C" int car_gather_encode_rows(const float* const* gmaps, const int* level_h, const int* level_w, int n_levels, int Cg,
+                                      const int* row_src, const float* row_grid, const float* row_pe, const float* wpt, int n_maps,
+                                      long rows, float* out, int ld_out, void* stream) {
+    CAR_REQUIRE(gmaps && level_h && level_w && row_src && row_grid && row_pe && wpt && out, "car_gather_encode_rows: null pointer");
+    CAR_REQUIRE(n_levels > 0 && n_levels <= CAR_MAX_LEVELS && Cg > 0 && Cg % 4 == 0, "car_gather_encode_rows: bad level/channel count");
+    CAR_REQUIRE(n_maps > 0 && rows > 0, "car_gather_encode_rows: bad sizes");
+    CAR_REQUIRE(ld_out >= Cg && ld_out % 4 == 0, "car_gather_encode_rows: ld_out (%d) must be a multiple of 4 and >= C (%d)", ld_out, Cg);
+    EncodeLevels L;
+    L.n_levels = n_levels;
+    for (int l = 0; l < CAR_MAX_LEVELS; ++l) {
+        L.map[l] = l < n_levels ? gmaps[l] : nullptr;
+        L.h[l] = l < n_levels ? level_h[l] : 0;
+        L.w[l] = l < n_levels ? level_w[l] : 0;
+        if (l < n_levels) CAR_REQUIRE(L.map[l] && L.h[l] > 0 && L.w[l] > 0 && (long)n_maps * L.h[l] * L.w[l] < 1073741823L, "car_gather_encode_rows: bad level %d", l);
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(encode_kernel, dim3(car_div_up(rows, kRows)), dim3(256), 0, (hipStream_t)stream, L, Cg, row_grid,
+                       (const float*)nullptr, row_pe, wpt, 1, rows, rows, out, ld_out, row_src);
+    CAR_CHECK_LAUNCH("car_gather_encode_rows");
     return CAR_OK;
 }

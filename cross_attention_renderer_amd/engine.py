@@ -646,6 +646,43 @@ class RenderEngine:
         S = b * V * pts
         dev = pixel_val.device
         f32 = dict(device=dev, dtype=torch.float32)
+        if keep is None and self.project_maps:
+            # inference: the first layer applied per texel (car_project_maps' arithmetic, as on the two-view route): the 579 -> 576 GEMM over
+            # 3 S rows — two thirds of this variant's FLOPs — becomes one gather over the projected pyramid with an explicit row list
+            gmaps, wpt = self._projected_maps(maps, dev)
+            n = b * V
+            src = torch.empty(b, V, pts, 3, dtype=torch.int32, device=dev)
+            rgrid = torch.empty(b, V, pts, 3, 2, **f32)
+            rpe = torch.zeros(b, V, pts, 3, 4, **f32)
+            pe = ptenc.view(b, V, pts, V, 4)
+            pin = pt_in.view(b, V, pts, V, 3)
+            sc = torch.arange(b, device=dev, dtype=torch.int32).view(b, 1)
+            grid = torch.empty(b, pts, 2, **f32)
+            pv = pixel_val.view(b, V, pts, 2)
+            for c in range(V):
+                src[:, c, :, 0] = sc * V + c                              # own features, border padding (mode 0)
+                rgrid[:, c, :, 0] = pv[:, c]
+                rpe[:, c, :, 0, :3] = pe[:, c, :, c, :3]
+                k = 1
+                for o in range(V):
+                    if o == c:
+                        continue
+                    q = pin[:, o, :, c, :].contiguous()
+                    _lib.check(self.lib.car_project_points(_ptr(poses), _ptr(q), b, pts, V, o, H, W, _ptr(grid), _stream()), "car_project_points")
+                    src[:, c, :, k] = (sc * V + o) | (1 << 30)            # view o's features, zeros padding (mode 1)
+                    rgrid[:, c, :, k] = grid
+                    rpe[:, c, :, k, :3] = pe[:, o, :, c, :3]
+                    k += 1
+            h1 = torch.empty(S * 3, C, **f32)
+            L = len(gmaps)
+            ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in gmaps])
+            hs = (ctypes.c_int * L)(*[g.shape[1] for g in gmaps])
+            ws = (ctypes.c_int * L)(*[g.shape[2] for g in gmaps])
+            _lib.check(self.lib.car_gather_encode_rows(ptrs, hs, ws, L, C, _ptr(src), _ptr(rgrid), _ptr(rpe), _ptr(wpt), n, S * 3, _ptr(h1), C,
+                                                       _stream()), "car_gather_encode_rows")
+            enc = torch.empty(S * 3, C // 2, **f32)
+            self.linear(h1, C, pk["query_encode_latent_2"], enc, C // 2, S * 3)
+            return enc.view(S, 3, C // 2).permute(0, 2, 1).contiguous().view(S, 3 * (C // 2))
         ld = _round_up(C + 3, 32)
         x3 = torch.empty(S * 3, ld, **f32)
         x3v = x3.view(b, V, pts, 3, ld)                     # [scene, context c, point, component k, channel]

@@ -118,6 +118,11 @@ int car_gather_bilinear(const float* const* maps, const int* level_c, const int*
 int car_gather_encode(const float* const* gmaps, const int* level_h, const int* level_w, int n_levels, int C,
                       const float* pixel_val, const float* grid_in, const float* ptenc, const float* wpt,
                       int n_maps, int V, long pts, float* out, int ld_out, void* stream);
+/* The same layer for an explicit list of rows (the three-view exchange, models.py:345-475): row i gathers map (row_src[i] & 0x3fffffff)
+ * at row_grid[i] (2 floats) with padding mode (row_src[i] >> 30) & 1 and adds the point term of row_pe[i] (4 floats, the last unused). */
+int car_gather_encode_rows(const float* const* gmaps, const int* level_h, const int* level_w, int n_levels, int Cg,
+                           const int* row_src, const float* row_grid, const float* row_pe, const float* wpt, int n_maps,
+                           long rows, float* out, int ld_out, void* stream);
 
 /* ---- a6-a13 + logits of a14 in ONE kernel for the default configuration (V = 2, C = 576, hidden 128): geometry, the
  * per-texel-projected encode (car_gather_encode's arithmetic, with ALL pyramid levels summed once per stereo pair on their common

@@ -207,10 +207,11 @@ def test_forward_with_the_whole_input_dict_on_the_device(name):
         assert e["f1e-4"] <= OUTLIER_FRAC and e["max"] <= OUTLIER_MAX, f"whole dict on the device vs reference fixture {name} {k}: {e}"
 
 
-@pytest.mark.parametrize("name", ["t0_default", "t0_diverging", "t1_c1", "t2_c2", "t2_c5"])
+@pytest.mark.parametrize("name", ["t0_default", "t0_diverging", "t1_c1", "t2_c2", "t2_c5", "t0_nview3", "t1_nview3"])
 def test_literal_gather_gemm_pipeline_matches_oracle(name):
     """The literal pipeline (materialised 579-wide rows -> K=579 GEMM), kept for A/B against the default path that
-    applies the first point-MLP layer per texel (csrc/car_encode.hip): both must sit within 1e-4 of the oracle."""
+    applies the first point-MLP layer per texel (csrc/car_encode.hip; for three views through car_gather_encode_rows' explicit row
+    list): both must sit within 1e-4 of the oracle."""
     c, fx, ora, out = run_case(name, project_maps=False)
     _check_outputs(out, lambda k: ora[k], "literal pipeline vs oracle")
     _, _, _, out2 = run_case(name, project_maps=True, fuse_samples=False)
