@@ -151,7 +151,6 @@ def test_bench_prints_one_line_with_the_contract_fields():
     assert d["pose_route"]["download_and_sync_ms"] > 0 and d["pose_route"]["cameras_on_gpu_ms_per_step"] > 0
 
 
-@pytest.mark.gpu
 def test_bench_refuses_a_world_size_that_is_not_the_requested_gpu_count():
     """--gpus N with fewer (or more) launched ranks must fail loudly, not print a line that looks like an N-GPU figure."""
     import subprocess
