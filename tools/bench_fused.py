@@ -35,6 +35,14 @@ def main():
     if fn_ws is not None:
         fn_ws.restype = ctypes.c_int
         fn_ws.argtypes = _lib.SIGNATURES["car_fused_samples"][1]
+    fn_w8 = {}                                           # variants 201..: compile-time variants of the 8-wave candidate (tools/build_w8.py)
+    for v_ in range(0, 40):
+        pth = os.path.join(ROOT, "tools", "_dev", f"libw8_{v_}.so")
+        if os.path.exists(pth):
+            f_ = ctypes.CDLL(pth).car_fused_samples_ws
+            f_.restype = ctypes.c_int
+            f_.argtypes = _lib.SIGNATURES["car_fused_samples"][1]
+            fn_w8[v_] = f_
     base_path = os.path.join(ROOT, "tools", "_dev", "libcar_base.so")          # variant 300: a saved earlier build of the product library
     fn_base = None
     if os.path.exists(base_path):
@@ -90,20 +98,45 @@ def main():
     S = 2 * R * bench.P
     flop = 2.0 * S * bench.FUSED_MACS
     variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 5, 6, 7, 8]
+    if os.environ.get("CAR_ZERO"):                       # power probe: the same instruction stream over zeros (weights and / or lattice)
+        if "w" in os.environ["CAR_ZERO"]:
+            blob.zero_()
+        if "l" in os.environ["CAR_ZERO"]:
+            eng._pair.zero_()
+        torch.cuda.synchronize()
     prod = lib.car_fused_samples                        # variant 100: the product library's kernel, timed the same way
     outs = {}
+    # power / occupancy probe: CAR_CU_MASK=n runs the launches on a stream restricted to n compute units (every (256 / n)-th one),
+    # CAR_R=rays shrinks the launch with it
+    Rk = int(os.environ.get("CAR_R", R))
+    ext = None
+    if os.environ.get("CAR_CU_MASK"):
+        ncu = int(os.environ["CAR_CU_MASK"])
+        hip = ctypes.CDLL("libamdhip64.so")
+        words = (ctypes.c_uint32 * 8)()
+        mode = os.environ.get("CAR_CU_MODE", "stride")
+        for i in range(ncu):
+            c = i * (256 // ncu) if mode == "stride" else i
+            words[c // 32] |= 1 << (c % 32)
+        hs = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(hs), 8, words)
+        assert rc == 0, rc
+        ext = torch.cuda.ExternalStream(hs.value)
+        st = P_(hs.value)
+        flop = flop * Rk / R
+        print(f"stream restricted to {ncu} CUs ({mode}), {Rk} rays per launch")
     for v in variants:
         lat = []
         lat_ptr, lat_h, lat_w, lat_pad = eng._pair.data_ptr(), lh.value, lw.value, lpad.value
         for it in range(7):
             a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
+            a.record(ext) if ext is not None else a.record()
             args = (eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), lat_ptr, lat_h, lat_w, lat_pad,
                     gmeta, wpt.data_ptr(), blob.data_ptr(),
-                    bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, 0, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
+                    bias.data_ptr(), 1, 2, Rk, bench.P, bench.H, bench.H, 0, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
                     pixel_val.data_ptr(), st)
-            rc = fn_sliced(v - 1000, *args) if v >= 1000 else prod(*args) if v == 100 else fn_ws(*args) if v == 200 else fn_base(*args) if v == 300 else fn(v, *args)
-            b_.record()
+            rc = fn_sliced(v - 1000, *args) if v >= 1000 else prod(*args) if v == 100 else fn_ws(*args) if v == 200 else fn_w8[v - 201](*args) if 201 <= v < 260 else fn_base(*args) if v == 300 else fn(v, *args)
+            b_.record(ext) if ext is not None else b_.record()
             assert rc == 0, dev_lib.car_last_error()
             lat.append((a, b_))
         torch.cuda.synchronize()
@@ -169,6 +202,14 @@ def main():
             print(f"source passes, per wave and chunk (mean over {w8.shape[0]} waves, {n:.0f} chunks each; s_memtime ticks): "
                   f"9 x (A-operand reads + 6 MFMAs issued) {m(7):.0f}, DMA pieces {m(5):.0f}, affine {m(6):.0f}, blends incl. the wait for their taps {m(0):.0f}, "
                   f"h rows stored + tap loads issued {m(4):.0f}, chunk-end wait for the weight DMA {m(1):.0f}, barrier {m(2):.0f}")
+        if v == 210:                                       # 8-wave candidate with shader-clock sums per section of its chunk loop
+            nw = (2 * R * bench.P // 256) * 8
+            w10 = pixel_val.view(torch.int64)[: nw * 10].view(-1, 10).cpu().double()
+            n = w10[:, 7].mean().item()
+            m = lambda k: w10[:, k].mean().item() / n
+            print(f"8-wave candidate, per wave and chunk (mean over {w10.shape[0]} waves, {n:.0f} chunks; s_memtime ticks): 9 x (A reads + 12 MFMAs) {m(0):.0f}, DMA pieces {m(1):.0f}, "
+                  f"4 x gather_row (waits for its taps) {m(2):.0f}, 4 x tap issue {m(3):.0f}, B operands read + split {m(4):.0f}, vmcnt {m(5):.0f}, barrier {m(6):.0f}; "
+                  f"source passes {w10[:, 8].mean().item():.0f}, from there to the end {w10[:, 9].mean().item() - w10[:, 8].mean().item():.0f}")
         if v == 200 and "CAR_WS_STAMP" in os.environ:      # development build with -DCAR_WS_STAMP: per-wave tick sums of the source passes
             w4 = pixel_val.view(torch.int64)[: (2 * R * bench.P // 192) * 16 * 8].view(-1, 16, 8).cpu().double()
             mw, gw_ = w4[:, :12, :3].mean(dim=(0, 1)) / 36, w4[:, 12:, :3].mean(dim=(0, 1)) / 36
@@ -179,7 +220,7 @@ def main():
             print(f"   gather wave per period: finish (wait taps, blend, split, write) {gx[2]:.0f}, issue of 4 x 6 tap loads {gx[5]:.0f}")
             print(f"   matrix wave per chunk: MFMA groups + DMA issue {mw[0]:.0f}, wait for own DMA {mw[2]:.0f}, barrier {mw[1]:.0f};  "
                   f"gather wave per period: 6 row groups {gw_[0]:.0f}, barrier {gw_[1]:.0f}  (s_memtime ticks)")
-        if v in (0, 100, 200, 300) or v >= 1000 or 60 <= v <= 69:    # keep the results: the development kernels must equal the product's bit for bit
+        if v in (0, 100, 200, 300) or v >= 1000 or 60 <= v <= 69 or 201 <= v < 260:    # keep the results: the development kernels must equal the product's bit for bit
             outs[v] = [torch.empty(cnt_, device=dev).copy_(eng._work[o_:o_ + cnt_]) for o_, cnt_ in
                        [(lambda n_: (lib.car_workspace_find(ctypes.byref(d), n_.encode(), ctypes.byref(off), ctypes.byref(cnt)), (off.value, cnt.value))[1])(n_)
                         for n_ in ("e", "qry", "logit", "pt", "g")]]

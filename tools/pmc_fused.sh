@@ -19,7 +19,7 @@ import sqlite3, glob
 for d in sorted(glob.glob('gpurun_out/pmc_fused/*/p_results.db')):
     c = sqlite3.connect(d).cursor()
     print(d)
-    for r in c.execute("select counter_name, count(*), avg(value) from counters_collection where kernel_name like '%fused%' group by 1"):
-        print("   %-34s n=%d avg=%.4g" % r)
+    for r in c.execute("select substr(kernel_name, 1, 40), counter_name, count(*), avg(value) from counters_collection where kernel_name like '%fused%' group by 1, 2"):
+        print("   %-42s %-34s n=%d avg=%.4g" % r)
 PY
 find $OUT -name "*.db" -size +3M -delete
