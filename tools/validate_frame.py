@@ -45,13 +45,13 @@ def main():
         t_or = time.time() - t0
         ora = {k: torch.cat([p[k] for p in parts], dim=(2 if k == "rgb" else 1)) for k in ("rgb", "depth_ray", "at_wt", "valid_mask", "at_wt_max")}
         dz = [t.to(dev) for t in z]
-        # cameras on the host: the pose algebra is the reference's own torch.inverse on this CPU, like the oracle's (strict comparison);
-        # cameras on the device: car_pose_setup (fp64 Gauss-Jordan), whose last-ulp differences the fp64 Pluecker intersection amplifies
-        # on the few samples whose pixel ray is nearly parallel to the query ray (the reference itself moves by as much
-        # between two LAPACK builds)
-        for where in ("host", "device"):
+        # three ways the cameras can arrive (engine.RenderEngine._poses): on the host (the tests' / bench's default); the WHOLE dict on the
+        # GPU (the reference scripts' dict_to_gpu call: the engine copies the four camera tensors back through one pinned buffer and
+        # runs the same host algebra — the default since round 4); the opt-in device route (car_pose_setup, fp64 Gauss-Jordan, no sync)
+        for where in ("host", "GPU, default route (host algebra)", "GPU, opt-in device route"):
             cams = ("cam2world", "intrinsics")
             dinp = {k: {kk: (vv if (where == "host" and kk in cams) else vv.to(dev)) for kk, vv in v.items()} for k, v in inp.items()}
+            model.pose_route = "device" if "opt-in" in where else "host"
             with torch.no_grad():
                 model(dinp, z=dz)
                 torch.cuda.synchronize()
