@@ -91,6 +91,8 @@ SIGNATURES = {
     "car_workspace_bytes": (c_size_t, [ctypes.POINTER(CarDims)]),
     "car_render_forward": (c_int, [ctypes.POINTER(CarDims), _P, ctypes.POINTER(CarInputs), ctypes.POINTER(CarOutputs), _P,
                                    c_size_t, _P]),
+    "car_render_forward_phase": (c_int, [ctypes.POINTER(CarDims), _P, ctypes.POINTER(CarInputs), ctypes.POINTER(CarOutputs), _P,
+                                         c_size_t, c_int, _P]),
     "car_linspace": (None, [c_float, c_float, c_int, _P]),
     "car_linear_wgrad": (c_int, [_P, c_int, _P, c_int, c_long, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "car_attend_backward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_int, _P, _P]),

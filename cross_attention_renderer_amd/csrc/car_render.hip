@@ -538,8 +538,10 @@ extern "C" int car_project_maps(const car_dims* dims, const void* plan, const fl
     return CAR_OK;
 }
 
-extern "C" int car_render_forward(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+// the launches of one forward call in two phases: CAR_PHASE_SAMPLES = rays + the fused per-sample kernel (compute / power bound),
+// CAR_PHASE_RAYS = the attention rounds and the per-ray chains (HBM bound), which only read what the first phase left in the workspace
+static int render_phases(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
+                         void* workspace, size_t workspace_bytes, int phases, void* stream) {
     CAR_TRY(check_dims(dims, "car_render_forward"));
     CAR_REQUIRE(plan && in && out && workspace, "car_render_forward: null pointer");
     CAR_REQUIRE(in->poses && in->uv && in->lattice && in->gmeta && out->rgb, "car_render_forward: poses, uv, lattice, gmeta and rgb are required");
@@ -562,6 +564,7 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
     float* valid = out->valid_mask ? out->valid_mask : ws + w.valid;
     int32_t* amax = out->at_wt_max ? out->at_wt_max : reinterpret_cast<int32_t*>(ws + w.amax);
 
+    if (phases & CAR_PHASE_SAMPLES) {
     {   // a4-a6: rays, their epipolar segments, the decoder's ray input (columns 18, 19 of phi_x stay zero)
         Stage stage("ray_setup", st);
         if (hipMemsetAsync(ws + w.phi_x, 0, sizeof(float) * BR * kPhiLd, st) != hipSuccess) { car_set_error("car_render_forward: memset failed"); return CAR_E_LAUNCH; }
@@ -573,6 +576,8 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
         CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->gmeta, pl + p.wpt, pl + p.blob,
                                   pl + p.fbias, b, V, R, P, d.H, d.W, d.no_sample != 0, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
     }
+    }
+    if (!(phases & CAR_PHASE_RAYS)) return CAR_OK;
     {   // a14 + a16: attention round 1, depth read-out, argmax
         Stage stage("attend_1", st);
         CAR_TRY(car_attend(ws + w.logit, nullptr, kD, ws + w.e, kC, b, V, R, P, nullptr, 0.0f, at_wt, ws + w.ebar, kC, 1, ws + w.pt, in->poses,
@@ -617,4 +622,16 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
                              ws + w.rays, b, V, R, out->rgb, valid, stream));
     }
     return CAR_OK;
+}
+
+extern "C" int car_render_forward(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    return render_phases(dims, plan, in, out, workspace, workspace_bytes, CAR_PHASE_SAMPLES | CAR_PHASE_RAYS, stream);
+}
+
+extern "C" int car_render_forward_phase(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
+                                        void* workspace, size_t workspace_bytes, int phases, void* stream) {
+    CAR_REQUIRE(phases == CAR_PHASE_SAMPLES || phases == CAR_PHASE_RAYS || phases == (CAR_PHASE_SAMPLES | CAR_PHASE_RAYS),
+                "car_render_forward_phase: phases = %d (CAR_PHASE_SAMPLES, CAR_PHASE_RAYS or both)", phases);
+    return render_phases(dims, plan, in, out, workspace, workspace_bytes, phases, stream);
 }

@@ -322,6 +322,15 @@ int car_project_maps(const car_dims* dims, const void* plan, const float* const*
 size_t car_workspace_bytes(const car_dims* dims);
 int car_render_forward(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The same launches in two phases, for hosts that overlap them across batches of rays on two streams (engine.py):
+ * CAR_PHASE_SAMPLES = rays + the fused per-sample kernel (matrix-pipe / power bound; writes e, qry, g, logit, pt into the workspace),
+ * CAR_PHASE_RAYS = both attention rounds and the per-ray chains (HBM bound; reads them, writes the outputs).  The second phase of a
+ * batch must be ordered after its first phase (an event) and use the same dims / inputs / outputs / workspace; batches with their own
+ * workspaces are independent.  phases = both is car_render_forward. */
+#define CAR_PHASE_SAMPLES 1
+#define CAR_PHASE_RAYS 2
+int car_render_forward_phase(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
+                             void* workspace, size_t workspace_bytes, int phases, void* stream);
 /* Where a named intermediate lives inside the workspace after car_render_forward (tests, debugging, profiling): one of
  * "rays" "e" "qry" "g" "logit" "logit2" "pt" "at_wt2" "ebar" "z1" "uh".  Returns 0 and the float offset / count. */
 int car_workspace_find(const car_dims* dims, const char* name, size_t* offset_floats, size_t* n_floats);

@@ -418,6 +418,66 @@ def test_one_call_c_abi_without_second_round():
         assert err_stats(eng[k].cpu(), ora[k])["max"] <= TOL, k
 
 
+def test_two_phase_entry_on_two_streams_equals_the_one_call():
+    """car_render_forward_phase (include/car_hip.h): the per-sample phase of every ray batch on one stream, the per-ray phase on a second
+    one behind an event, each batch in its own workspace — bit-identical to car_render_forward on the whole set of rays."""
+    import ctypes
+    from cross_attention_renderer_amd import _lib, synthetic as S
+    from cross_attention_renderer_amd.engine import _ptr
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    dev = torch.device("cuda:0")
+    H, P, R, nb = 64, 32, 192, 2
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).eval()
+    S.perturb_parameters(m, seed=6)
+    m.H = m.W = H
+    inp = S.stereo_scene(H, b=1, uv=C.select_rays(H, R), seed=9, alpha=0.6)
+    z = S.feature_maps(1, 2, H, seed=3)
+    md = m.to(dev)
+    dinp, dz = to_device(inp, dev, cameras_on_host=True), [t.to(dev) for t in z]
+    with torch.no_grad():
+        ref = md(dinp, z=dz)
+    eng, lib = md._engine, _lib.load()
+    assert eng.last_calls == 1
+    f32 = dict(device=dev, dtype=torch.float32)
+    poses = eng._poses(dinp, H, 2, dev)
+    uv = dinp["query"]["uv"].reshape(1, R, 2).float().contiguous()
+    steps = eng._linspace(0.0, 1.0, P, dev)
+    plan = eng._plan_for(eng._dims(1, R, dz), dev)
+    pair, d_pair = eng._pair_for(plan, dz, dev, 0, 1, R)
+    rc = R // nb
+    d = eng._dims(1, rc, dz)
+    need = lib.car_workspace_bytes(ctypes.byref(d))
+    order = ("rgb", "valid_mask", "depth_ray", "at_wt", "at_wt_max", "coords", "pixel_val")
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    keep, outs = [], []
+    for c in range(nb):
+        o = {"rgb": torch.empty(1, 1, rc, 3, **f32), "valid_mask": torch.empty(1, rc, 1, **f32), "depth_ray": torch.empty(1, rc, 1, **f32),
+             "at_wt": torch.empty(2, rc, P, **f32), "at_wt_max": torch.empty(2, rc, 1, device=dev, dtype=torch.int32),
+             "coords": torch.empty(2, rc, 9, **f32), "pixel_val": torch.empty(2, rc, P, 2, **f32)}
+        u = uv[:, c * rc:(c + 1) * rc].contiguous()
+        work = torch.empty(need // 4, **f32)
+        ci = _lib.CarInputs()
+        ci.poses, ci.uv, ci.lattice, ci.steps = poses.data_ptr(), u.data_ptr(), pair.data_ptr(), steps.data_ptr()
+        ci.gmeta = pair.data_ptr() + 4 * lib.car_gmeta_offset(ctypes.byref(d_pair))
+        co = _lib.CarOutputs(*[o[k].data_ptr() for k in order])
+        ev = torch.cuda.Event()
+        for phase, stream in ((1, sa), (2, sb)):
+            if phase == 2:
+                sb.wait_event(ev)
+            _lib.check(lib.car_render_forward_phase(ctypes.byref(d), _ptr(plan), ctypes.byref(ci), ctypes.byref(co), _ptr(work), need, phase,
+                                                    ctypes.c_void_p(stream.cuda_stream)), "car_render_forward_phase")
+            if phase == 1:
+                ev.record(sa)
+        keep += [u, work, ci, co, ev]
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([o["rgb"] for o in outs], dim=2), ref["rgb"])
+    for k in ("depth_ray", "at_wt", "valid_mask"):
+        assert torch.equal(torch.cat([o[k] for o in outs], dim=1), ref[k]), k
+    assert lib.car_render_forward_phase(ctypes.byref(d), _ptr(plan), ctypes.byref(ci), ctypes.byref(co), _ptr(work), need, 4, None) != 0
+
+
 # ----------------------------------------------------------------------------------------------------------
 # dynamic range of the split-fp16 arithmetic (csrc/car_fused_mma.h): fp16 halves keep 11 bits only between 2^-14 and 65504
 # ----------------------------------------------------------------------------------------------------------
