@@ -128,7 +128,7 @@ def main():
     for v in variants:
         lat = []
         lat_ptr, lat_h, lat_w, lat_pad = eng._pair.data_ptr(), lh.value, lw.value, lpad.value
-        for it in range(7):
+        for it in range(int(os.environ.get("CAR_LOOP", 7))):
             a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(ext) if ext is not None else a.record()
             args = (eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), lat_ptr, lat_h, lat_w, lat_pad,
