@@ -1,0 +1,217 @@
+// car_linear16.hip — one wide linear layer of the stage entries on the f16 matrix pipe (car_linear_x3): Y = act(act_in(X) W^T + b (+ Y)).
+// The staged route (constructor variants, training forward, the backward's data gradients: reference models.py:333-341, 487-491, 529,
+// 548, 553) spends most of its time in 576 -> 576 / 288 / 128 layers over every epipolar sample; car_linear runs them on the fp32 matrix
+// pipe (157 TFLOP/s peak).  This kernel is the fused per-sample kernel's layer machinery (car_fused_mma.h) with the B operands read
+// from the rows of X: fp16 hi / lo halves of both operands, three v_mfma_f32_16x16x32_f16 products per term, fp32 accumulation
+// (fp32-class accuracy, 2500 / 3 TFLOP/s peak); the layer's weights carry a power of two chosen at pack time, every row of X a power of two
+// that follows the largest magnitude seen so far along the row (when a later chunk outgrows it, the row's accumulators are moved to the
+// new power of two — an exact multiplication — so X is read once, not twice), both undone exactly on the accumulators.
+// A workgroup = 12 waves x 16 rows; a wave keeps NT tiles of 16 outputs (NT = 18: 288 columns, 72 accumulator registers; wider layers
+// run as column groups); the weight chunks (K = 32 x the group's columns) stream L2 -> LDS by LDS-DMA, double buffered.
+#include "car_common.h"
+
+namespace {
+
+constexpr int kWaves = 12, kRows = 16, kGroupRows = kWaves * kRows;
+constexpr int kThreads = 64 * kWaves;
+constexpr int kPieces = 3;
+
+#include "car_fused_mma.h"
+
+__device__ __forceinline__ constexpr int chunk_tile_offset(int) { return 0; }      // the fused kernel's chunk tables: not used here
+__device__ __forceinline__ constexpr int chunk_tiles(int) { return 0; }
+
+struct LinArgs {
+    const float* X; int ldx;
+    const float* Wp; int tiles_total;      // [K step][tiles_total][512]
+    const float* bias;                     // N floats or null
+    const float* down;                     // 2^-shift of the packed layer
+    int K, chunks;
+    float* Y; int ldy;
+    long M;
+    int flags;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][NT][512]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = lane & 15, q4 = lane >> 4;
+    // the column groups of a block of rows are neighbours in launch order: they read the same rows of X at about the same time (L2)
+    const int groups = a.tiles_total / NT;
+    const long row = (long)(blockIdx.x / groups) * kGroupRows + wave * kRows + s;
+    const long lrow = row < a.M ? row : a.M - 1;
+    const float* xrow = a.X + lrow * a.ldx;
+    const int tile0 = (blockIdx.x % groups) * NT;
+    const bool relu_in = (a.flags & CAR_LIN_RELU_IN) != 0;
+    const int K = a.K;
+
+    auto chunk_desc = [&](int c) {
+        const int ce = c < a.chunks ? c : a.chunks - 1;
+        NextChunk n;
+        n.src = a.Wp + ((long)ce * a.tiles_total + tile0) * kTile;
+        n.dst = lds + (ce & 1) * NT * kTile;
+        n.nkb = 2 * NT;
+        return n;
+    };
+    {
+        const NextChunk n0 = chunk_desc(0);
+#pragma unroll
+        for (int p = 0; p < kPieces; ++p) stream_issue_piece(n0, p, lane, wave);
+    }
+    // this lane's eight values of chunk c: k = 32 c + 8 q4 .. + 7 (zeros beyond K; relu on the way in where the layer asks for it)
+    auto load_x = [&](int c, float (&x)[8]) {
+        const int k0 = 32 * c + 8 * q4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kq = k0 + 4 * h;
+            const float4 v = *reinterpret_cast<const float4*>(xrow + (kq < K ? kq : 0));
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float t = kq + i < K ? e[i] : 0.0f;
+                x[4 * h + i] = relu_in ? fmaxf(t, 0.0f) : t;
+            }
+        }
+    };
+    // largest magnitude of the row's values in a chunk (the four lanes of a row hold eight each)
+    auto row_max = [&](const float (&x)[8]) {
+        float m = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(x[e]));
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        return fmaxf(m, __shfl_xor(m, 32, 64));
+    };
+    const float dW = a.down[0];
+    float xc[8];
+    load_x(0, xc);
+    float mrun = fmaxf(row_max(xc), 1e-30f), p, pinv;
+    pow2_scale(mrun, p, pinv);
+
+    f32x4 acc[NT];
+    if (a.bias) init_bias<NT>(acc, a.bias + 16 * tile0, q4, p / dW);
+    else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    half8 bhi, blo;
+    split8(xc, p, bhi, blo);
+    stream_sync();                                                     // weight chunk 0 landed
+
+#pragma unroll 1
+    for (int c = 0; c < a.chunks; ++c) {
+        const float* wl = lds + (c & 1) * NT * kTile + 4 * lane;
+        const NextChunk nx = chunk_desc(c + 1);
+        float xn[8];
+        load_x(c + 1 < a.chunks ? c + 1 : c, xn);                      // next chunk's rows: in flight under this chunk's MFMAs
+#pragma unroll
+        for (int qs = 0; qs < NT / 2; ++qs) {
+            const float* w0 = wl + (2 * qs * 2) * 256;
+            mfma_pair(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
+            if (qs < kPieces) stream_issue_piece(nx, qs, lane, wave);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next chunk may outgrow the row's power of two: move the row (accumulators and scale) to the smaller one, exactly
+        const float mn = row_max(xn);
+        if (__builtin_amdgcn_ballot_w64(mn > mrun) != 0) {
+            float pn, pninv;
+            mrun = fmaxf(mrun, mn);
+            pow2_scale(mrun, pn, pninv);
+            scale_acc<NT>(acc, pn * pinv);
+            p = pn; pinv = pninv;
+        }
+        split8(xn, p, bhi, blo);
+        stream_sync();
+    }
+    if (row >= a.M) return;
+    scale_acc<NT>(acc, dW * pinv);
+    const bool relu_out = (a.flags & CAR_LIN_RELU_OUT) != 0, accum = (a.flags & CAR_LIN_ACCUM) != 0;
+    float* yrow = a.Y + row * a.ldy + 16 * tile0 + 4 * q4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float4* dst = reinterpret_cast<float4*>(yrow + 16 * t);
+        float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        if (accum) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (relu_out) v = make_float4(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f), fmaxf(v.w, 0.0f));
+        *dst = v;
+    }
+}
+
+// scale[0] = 2^shift with max |W| 2^shift in [2^13, 2^14), scale[1] = 2^-shift.  One workgroup.
+__global__ void scale16_kernel(const float* __restrict__ W, int ldw, int K, int N, float* __restrict__ scale) {
+    __shared__ float red[16];
+    float m = 0.0f;
+    for (long idx = threadIdx.x; idx < (long)N * K; idx += blockDim.x) m = fmaxf(m, fabsf(W[(idx / K) * ldw + idx % K]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x / 64); ++w) m = fmaxf(m, red[w]);
+        float p, inv;
+        pow2_scale(fmaxf(m, 1e-30f), p, inv);
+        scale[0] = p;
+        scale[1] = inv;
+    }
+}
+// [K step][tile][hi | lo][lane][8 halves]: lane l carries output 16 tile + l % 16 and k = 32 step + 8 (l >> 4) + e
+__global__ void pack16x3_kernel(const float* __restrict__ W, int ldw, int K, int N, int tiles, long total, const float* __restrict__ scale,
+                                _Float16* __restrict__ out) {
+    const float p = scale[0];
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const long tile = idx >> 9;
+        const int t = (int)(tile % tiles), ks = (int)(tile / tiles);
+        const int n = 16 * t + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + e;
+        const float w = (n < N && k < K) ? W[(long)n * ldw + k] * p : 0.0f;
+        const _Float16 hi = (_Float16)w;
+        _Float16* o = out + tile * 1024 + lane * 8 + e;
+        o[0] = hi;
+        o[512] = (_Float16)(w - (float)hi);
+    }
+}
+
+template <int NT>
+int launch16(const LinArgs& a, int groups, hipStream_t st) {
+    const size_t lds_bytes = (size_t)2 * NT * kTile * sizeof(float);
+    hipError_t e = hipFuncSetAttribute((const void*)linear16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { car_set_error("car_linear_x3: cannot reserve LDS: %s", hipGetErrorString(e)); return CAR_E_LAUNCH; }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(linear16_kernel<NT>, dim3((unsigned)(car_div_up(a.M, kGroupRows) * groups)), dim3(kThreads), lds_bytes, st, a);
+    CAR_CHECK_LAUNCH("car_linear_x3");
+    return CAR_OK;
+}
+
+}  // namespace
+
+// Packed weights of car_linear_x3: ceil(K / 32) x (N / 16) tiles of 512 floats, then two floats (2^shift, 2^-shift).
+extern "C" size_t car_linear_x3_packed_floats(int K, int N) { return (size_t)((K + 31) / 32) * ((N + 15) / 16) * kTile + 64; }
+extern "C" int car_linear_x3_pack(const float* W, int ldw, int K, int N, float* packed, void* stream) {
+    CAR_REQUIRE(W && packed && K > 0 && N > 0 && ldw >= K && N % 16 == 0, "car_linear_x3_pack: bad arguments (N must be a multiple of 16)");
+    const int tiles = N / 16, ksteps = (K + 31) / 32;
+    float* scale = packed + (size_t)ksteps * tiles * kTile;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(scale16_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, W, ldw, K, N, scale);
+    hipLaunchKernelGGL(pack16x3_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, W, ldw, K, N, tiles, (long)ksteps * tiles * 512, scale,
+                       reinterpret_cast<_Float16*>(packed));
+    CAR_CHECK_LAUNCH("car_linear_x3_pack");
+    return CAR_OK;
+}
+
+extern "C" int car_linear_x3(const float* X, int ldx, const float* packed, const float* bias, int K, int N, float* Y, int ldy, long M, int flags,
+                             void* stream) {
+    CAR_REQUIRE(X && packed && Y && M > 0 && K > 0 && N > 0, "car_linear_x3: bad arguments");
+    CAR_REQUIRE(N % 32 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= ((K + 3) & ~3) && ldy >= N,
+                "car_linear_x3: N = %d must be a multiple of 32, ldx = %d / ldy = %d multiples of 4 that hold a row", N, ldx, ldy);
+    CAR_REQUIRE(((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0), "car_linear_x3: X, Y and bias must be 16-byte aligned");
+    const int tiles = N / 16, ksteps = (K + 31) / 32;
+    LinArgs a;
+    a.X = X; a.ldx = ldx; a.Wp = packed; a.tiles_total = tiles; a.bias = bias;
+    a.down = packed + (size_t)ksteps * tiles * kTile + 1;
+    a.K = K; a.chunks = ksteps; a.Y = Y; a.ldy = ldy; a.M = M; a.flags = flags;
+    hipStream_t st = (hipStream_t)stream;
+    if (tiles % 18 == 0) return launch16<18>(a, tiles / 18, st);
+    if (tiles % 8 == 0) return launch16<8>(a, tiles / 8, st);
+    if (tiles % 4 == 0) return launch16<4>(a, tiles / 4, st);
+    return launch16<2>(a, tiles / 2, st);
+}

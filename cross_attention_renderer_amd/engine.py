@@ -60,6 +60,13 @@ class PackedLinear:
         self.packed = torch.empty(n, device=device, dtype=torch.float32)
         _lib.check(lib.car_linear_pack(_ptr(w), self.K, _ptr(bdev), self.K, self.N, _ptr(self.packed), _stream()),
                    "car_linear_pack")
+        # the same layer for the split-fp16 kernel (car_linear_x3: 5x the fp32 pipe's ceiling): layers wide enough to matter, whose
+        # outputs fill whole 32-channel tiles; the narrow ones (point embeddings, the 16-wide query input, rgb) stay on car_linear
+        self.x3 = None
+        if self.N % 32 == 0 and self.K >= 64:
+            tiles = torch.empty(lib.car_linear_x3_packed_floats(self.K, self.N), device=device, dtype=torch.float32)
+            _lib.check(lib.car_linear_x3_pack(_ptr(w), self.K, self.K, self.N, _ptr(tiles), _stream()), "car_linear_x3_pack")
+            self.x3 = (tiles, bdev)
 
 
 class RenderEngine:
@@ -76,6 +83,8 @@ class RenderEngine:
         self._maps_src = None          # the z tensors the channel-last copies were made from (kept alive, see _channel_last)
         self._steps: Dict[tuple, Tensor] = {}
         self.linear_flags = 0          # tests may set NO_GLDS for A/B
+        self.linear_x3 = True          # stage entries: wide layers on the split-fp16 path (car_linear_x3); False = all on the fp32 pipe
+        self.linear_x3_min_rows = 4096 # below this many rows a launch is latency bound either way
         self.pose_records = None       # tests: (b*V, 96) CarPose records to use instead of the host pose algebra
         # "host": the reference's torch.inverse on the CPU wherever the cameras live (strict parity; cameras on the GPU cost one small
         # download per new pose); "device": car_pose_setup when the cameras are on the GPU (no host round trip, budgeted parity)
@@ -497,6 +506,12 @@ class RenderEngine:
 
     # ------------------------------------------------------------------ kernels
     def linear(self, x: Tensor, ldx: int, layer: PackedLinear, y: Tensor, ldy: int, M: int, flags: int = 0):
+        if (self.linear_x3 and layer.x3 is not None and ldx % 4 == 0 and ldy % 4 == 0 and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0
+                and M >= self.linear_x3_min_rows):
+            tiles, bias = layer.x3
+            _lib.check(self.lib.car_linear_x3(_ptr(x), ldx, _ptr(tiles), _ptr(bias), layer.K, layer.N, _ptr(y), ldy, M, flags, _stream()),
+                       "car_linear_x3")
+            return
         _lib.check(self.lib.car_linear(_ptr(x), ldx, _ptr(layer.packed), layer.K, layer.N, _ptr(y), ldy, M,
                                        flags | self.linear_flags, _stream()), "car_linear")
 

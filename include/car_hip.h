@@ -157,6 +157,17 @@ int car_linear_pack(const float* W, int ldw, const float* bias, int K, int N, fl
 int car_linear(const float* X, int ldx, const float* packed, int K, int N, float* Y, int ldy, long M, int flags,
                void* stream);
 
+/* The same layer on the f16 matrix pipe (csrc/car_linear16.hip), for the stage entries' wide layers: fp16 hi / lo halves of both
+ * operands, three products per term, fp32 accumulation — the fused kernel's arithmetic (fp32-class accuracy; car_linear's fp32 pipe
+ * peaks at 157 TFLOP/s, this path at 2500 / 3).  The weights carry a power of two chosen by car_linear_x3_pack, every row of X one chosen
+ * from its largest magnitude (a first pass over the row).  Y[M, N] = act(act_in(X[M, K]) W^T + bias (+ Y)), flags as car_linear; bias: N
+ * floats or NULL (not folded into the pack).  N % 32 == 0, ldx % 4 == 0 (and >= K rounded up to 4), ldy % 4 == 0, X / Y / bias 16-byte
+ * aligned; car_linear serves every other shape. */
+size_t car_linear_x3_packed_floats(int K, int N);
+int car_linear_x3_pack(const float* W, int ldw, int K, int N, float* packed, void* stream);
+int car_linear_x3(const float* X, int ldx, const float* packed, const float* bias, int K, int N, float* Y, int ldy, long M, int flags,
+                  void* stream);
+
 /* ---- a14-a16: per-ray softmax attention over the V*P samples (models.py:532-594)
  * qa, qb [b*V,R,P,dq] (row stride dq): logit = <qa,qb>/16; with qb == NULL, qa is the precomputed logit [b*V,R,P]
  * (dq ignored).  val [b*V,R,P,D].

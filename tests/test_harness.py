@@ -123,7 +123,7 @@ def test_bench_prints_one_line_with_the_contract_fields():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-rays", "256"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--cpu-rays", "256"],
                          capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
@@ -133,7 +133,7 @@ def test_bench_prints_one_line_with_the_contract_fields():
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["metric"] == "rendered_rays_per_sec" and d["unit"] == "rays/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - 65536 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9

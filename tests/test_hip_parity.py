@@ -84,6 +84,48 @@ def test_linear_matches_torch(M, K, N, flags, no_glds):
     assert rel_err(Ya.cpu()[:, :N], want_acc) < 2e-5
 
 
+@pytest.mark.parametrize("M,K,N,flags", [
+    (4096, 576, 576, 2), (1000, 579, 576, 0), (777, 576, 288, 1), (300, 128, 128, 3), (5000, 288, 128, 0), (129, 144, 128, 2), (640, 64, 32, 0),
+    (2048, 576, 64, 2), (333, 100, 96, 1),
+])
+def test_split_fp16_linear_matches_torch(M, K, N, flags):
+    """car_linear_x3: the stage entries' wide layers on the f16 matrix pipe (fp16 hi / lo halves, three products, fp32 accumulate, a power of
+    two per row and per layer) against an fp64 reference — the same bound as the fp32-pipe kernel — with rows of very different magnitudes."""
+    from cross_attention_renderer_amd.engine import PackedLinear
+    lib = _lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M * 7 + K * 3 + N)
+    ldx = (K + 3) // 4 * 4 + 4
+    ldy = N + 4
+    X = torch.randn(M, ldx, generator=g) * torch.logspace(-6, 4, M).unsqueeze(1)          # rows from 1e-6 to 1e4
+    if M % 2:                                                                               # and magnitudes that grow 1e6-fold along the row: the
+        X = X * torch.logspace(-3, 3, ldx).unsqueeze(0)                                     # row's power of two is re-chosen chunk after chunk
+    Wt = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    Y0 = torch.randn(M, ldy, generator=g)
+    xin = (torch.relu(X[:, :K]) if flags & 1 else X[:, :K]).double()
+    want = xin @ Wt.double().T + bias.double()
+    if flags & 2:
+        want = torch.relu(want)
+    layer = PackedLinear(Wt, bias, dev)
+    assert layer.x3 is not None
+    tiles, bdev = layer.x3
+    Xd, Yd, Ya = X.to(dev), Y0.clone().to(dev), Y0.clone().to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.car_linear_x3(_ptr(Xd), ldx, _ptr(tiles), _ptr(bdev), K, N, _ptr(Yd), ldy, M, flags, st) == 0, lib.car_last_error()
+    assert lib.car_linear_x3(_ptr(Xd), ldx, _ptr(tiles), _ptr(bdev), K, N, _ptr(Ya), ldy, M, (flags & 1) | 4, st) == 0
+    torch.cuda.synchronize()
+    got = Yd.cpu()
+    # per row: the error is relative to the row's own scale (|x| |W| summed), whatever the row's magnitude
+    bound = (xin.abs() @ Wt.double().abs().T + bias.double().abs())
+    assert ((got[:, :N].double() - want).abs() / bound).max().item() < 4e-6
+    assert torch.equal(got[:, N:], Y0[:, N:]), "columns beyond N were touched"
+    want_acc = Y0[:, :N].double() + xin @ Wt.double().T + bias.double()
+    assert ((Ya.cpu()[:, :N].double() - want_acc).abs() / (bound + Y0[:, :N].double().abs())).max().item() < 4e-6
+    # shapes the entry refuses (car_linear serves them)
+    assert lib.car_linear_x3(_ptr(Xd), ldx, _ptr(tiles), _ptr(bdev), K, N - 1, _ptr(Yd), ldy, M, 0, st) != 0
+
+
 # ----------------------------------------------------------------------------------------------------------
 # stage kernels
 # ----------------------------------------------------------------------------------------------------------
