@@ -48,7 +48,7 @@ class _Ops:
 
     def transposed(self, name: str, w: Tensor) -> PackedLinear:
         """W [N, K] -> the layer x -> x W (weight W^T [K, N], no bias): car_linear then computes dX = dY W."""
-        key = (name, w.data_ptr(), w._version, str(w.device))
+        key = (name, w.data_ptr(), w._version, str(w.device), tuple(w.shape))
         if key not in self._t:
             self._t = {k: v for k, v in self._t.items() if k[0] != name}
             self._t[key] = PackedLinear(w.detach().reshape(w.shape[0], -1).t().contiguous(), None, w.device, name + "^T")
@@ -280,8 +280,13 @@ class _RenderTrain(torch.autograd.Function):
                 K = Kfull if K is None else K
                 ops.wgrad(dy, ldy, x, ldx, M, N, K, w.view(N, Kfull)[:, col0:], Kfull, grads[name + ".bias"] if bias else None, relu_x)
 
-            def dx(name, dy, ldy, out, ldo, M, flags=0, wt=None):
-                eng.linear(dy, ldy, ops.transposed(name, W(name) if wt is None else wt), out, ldo, M, flags)
+            def dx(name, dy, ldy, out, ldo, M, flags=0, wt=None, cols=None):
+                # cols: only the first `cols` input columns get a gradient (the rest — point coordinates — never need one): the transposed
+                # layer then has a multiple of 32 outputs and runs on the split-fp16 path (engine.linear)
+                w = W(name) if wt is None else wt
+                if cols is not None:
+                    w, name = w.reshape(w.shape[0], -1)[:, :cols], f"{name}[:, :{cols}]"
+                eng.linear(dy, ldy, ops.transposed(name, w), out, ldo, M, flags)
 
             # ---- a18 / a17: white background, decoder
             d_rgb = torch.zeros(b, R, 3, **f32) if d_rgb is None else d_rgb.detach().reshape(b, R, 3).float().contiguous()
@@ -377,7 +382,7 @@ class _RenderTrain(torch.autograd.Function):
                 wgrad("query_encode_latent", d_h1, C, sv["x1"], ld1, S * V)
                 if ctx.need_dz:                               # the pyramid asked for a gradient (z from get_z under autograd, or a leaf)
                     d_x1 = torch.empty(S * V, ld1, **f32)
-                    dx("query_encode_latent", d_h1, C, d_x1, ld1, S * V)
+                    dx("query_encode_latent", d_h1, C, d_x1, ld1, S * V, cols=C)
                     d_gather = (d_x1, ld1, [(sv["pixel_val"], 0, PLACE_OWN), (sv["grid_other"], 1, PLACE_OTHER2)])
             elif mode == "concat3":
                 # e[s, ch * 3 + k] = enc[(s, k), ch] (models.py:446): back to one row per (sample, component)
@@ -389,7 +394,7 @@ class _RenderTrain(torch.autograd.Function):
                 wgrad("query_encode_latent", d_h1, C, sv["x1"], ld1, S * 3)
                 if ctx.need_dz:
                     d_x3 = torch.empty(S * 3, ld1, **f32)
-                    dx("query_encode_latent", d_h1, C, d_x3, ld1, S * 3)
+                    dx("query_encode_latent", d_h1, C, d_x3, ld1, S * 3, cols=C)
                     d_x3v = d_x3.view(b, V, R * P, 3, ld1)
                     dmaps = [torch.zeros_like(t) for t in ctx.maps]
                     d_own = d_x3v[:, :, :, 0, :C].contiguous().view(S, C)       # component 0: the view's own features at its own samples
@@ -405,7 +410,7 @@ class _RenderTrain(torch.autograd.Function):
                 wgrad("update_val_merge", d_e, Ce, sv["x1"], ld1, S)
                 if ctx.need_dz:
                     d_x1 = torch.empty(S, ld1, **f32)
-                    dx("update_val_merge", d_e, Ce, d_x1, ld1, S)
+                    dx("update_val_merge", d_e, Ce, d_x1, ld1, S, cols=C)
                     d_gather = (d_x1, ld1, [(sv["pixel_val"], 0, PLACE_PLAIN)])
             elif ctx.need_dz:
                 d_gather = (d_e, Ce, [(sv["pixel_val"], 0, PLACE_PLAIN)])
