@@ -420,13 +420,15 @@ def main():
                     "achieved": flop / mean / 1e12, "peak": F16_MFMA_PEAK / 3 / 1e12, "unit": "TFLOP/s", "frac": flop / mean / (F16_MFMA_PEAK / 3),
                     "peak_note": "dense f16 MFMA peak 2500 / 3 products per fp32 term.  What keeps the kernel from it (limiter): MFMAs and ordinary "
                                  "vector instructions share a SIMD's issue, the A operands wait on LDS, the tap loads stall in the texture "
-                                 "path's issue, and the chip clocks to its power budget under this mix (~1.7 of 2.4 GHz; DESIGN.md section 4.6)",
+                                 "path's issue, and the chip clocks to its power budget under this mix (1.8-2.0 of 2.4 GHz): per compute unit the same "
+                                 "stream reaches 0.47 of this peak when a quarter of the chip or less is running (DESIGN.md section 4.6 vi)",
                     "frac_of_fp32_pipe_peak": flop / mean / FP32_MFMA_PEAK,
                     "ta_busy": pmc.get("ta_busy"), "mfma_busy": pmc.get("mfma_busy"), "valu_share": pmc.get("valu_share"), "l1_bytes": pmc.get("l1_bytes_per_launch"),
+                    "per_unit_unthrottled_frac": pmc.get("per_unit_unthrottled_frac"),
                     "traffic": pmc.get("bytes_per_launch"), "traffic_source": pmc.get("source"),
                     # which of these fields this run measured and which it copied from the committed counter passes
                     "live_fields": ["achieved", "frac", "frac_of_fp32_pipe_peak", "launches", "ms_per_launch", "flop_per_launch"],
-                    "static_fields": ["limiter", "ta_busy", "mfma_busy", "valu_share", "l1_bytes", "traffic"],
+                    "static_fields": ["limiter", "ta_busy", "mfma_busy", "valu_share", "l1_bytes", "traffic", "per_unit_unthrottled_frac"],
                     "static": "profiles/traffic.json: rocprofv3 --pmc passes of an earlier run of this kernel at config c2 (separate passes, not collected here; null for the other configs)",
                     "launches": len(lat), "ms_per_launch": mean * 1e3, "flop_per_launch": flop}
         fr = prof.get("frame")
