@@ -54,6 +54,8 @@ SIGNATURES = {
     "car_sample_setup": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P,
                                  c_int, c_int, _P, _P]),
     "car_gather_encode_rows": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_long, _P, c_int, _P]),
+    "car_merge_lattice": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "car_lattice_encode_rows": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_long, _P, c_int, _P]),
     "car_project_points": (c_int, [_P, _P, c_int, c_long, c_int, c_int, c_int, c_int, _P, _P]),
     "car_gather_bilinear": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_long, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "car_gather_encode": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_long, _P, c_int, _P]),

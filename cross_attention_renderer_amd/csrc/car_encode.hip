@@ -22,6 +22,9 @@ namespace {
 
 constexpr int kRows = 16;
 
+// lat_w > 0: `map[0]` is the merged lattice of car_merge_lattice ([n_maps][2 padding modes][lat_h][lat_w][C]): one four-tap lookup of the
+// row's (map, padding mode) lattice replaces the four taps per level
+struct EncodeLattice { int h, w, pad; float sx, sy; };
 struct EncodeLevels {
     const float* map[CAR_MAX_LEVELS];
     int h[CAR_MAX_LEVELS], w[CAR_MAX_LEVELS];
@@ -31,7 +34,7 @@ struct EncodeLevels {
 __global__ void __launch_bounds__(256) encode_kernel(EncodeLevels L, int Cg, const float* __restrict__ pixel_val,
                                                      const float* __restrict__ grid_in, const float* __restrict__ ptenc,
                                                      const float* __restrict__ wpt, int V, long pts, long rows,
-                                                     float* __restrict__ out, int ld_out, const int* __restrict__ row_src) {
+                                                     float* __restrict__ out, int ld_out, const int* __restrict__ row_src, EncodeLattice lat) {
     __shared__ int s_idx[kRows][CAR_MAX_LEVELS][4];
     __shared__ float s_w[kRows][CAR_MAX_LEVELS][4];
     __shared__ float s_pe[kRows][4];
@@ -58,8 +61,17 @@ __global__ void __launch_bounds__(256) encode_kernel(EncodeLevels L, int Cg, con
         }
         int idx[4];
         float w[4];
+        if (lat.w > 0) {
+            int node, flags;
+            car_lattice_taps(gx, gy, lat.w, lat.h, lat.pad, lat.sx, lat.sy, &node, &flags, w);
+            const bool dead = mode == 1 && (flags & 4);                // zeros padding, on or beyond the outer ring: exactly zero
+            const int base = (m * 2 + mode) * lat.h * lat.w + node;
+            idx[0] = base; idx[1] = base + 1; idx[2] = base + lat.w; idx[3] = base + lat.w + 1;
+            for (int t = 0; t < 4; ++t) { s_idx[rl][l][t] = dead ? 0 : idx[t]; s_w[rl][l][t] = dead ? 0.0f : w[t]; }
+        } else {
         car_bilinear_taps(gx, gy, L.w[l], L.h[l], mode, idx, w);
         for (int t = 0; t < 4; ++t) { s_idx[rl][l][t] = m * L.h[l] * L.w[l] + idx[t]; s_w[rl][l][t] = w[t]; }
+        }
         if (l == 0) for (int k = 0; k < 4; ++k) s_pe[rl][k] = ptenc[row * 4 + k];
     }
     __syncthreads();
@@ -112,7 +124,7 @@ extern "C" int car_gather_encode(const float* const* gmaps, const int* level_h, 
     const long rows = (long)n_maps * pts * V;
     (void)hipGetLastError();
     hipLaunchKernelGGL(encode_kernel, dim3(car_div_up(rows, kRows)), dim3(256), 0, (hipStream_t)stream, L, Cg, pixel_val,
-                       grid_in, ptenc, wpt, V, pts, rows, out, ld_out, (const int*)nullptr);
+                       grid_in, ptenc, wpt, V, pts, rows, out, ld_out, (const int*)nullptr, EncodeLattice{0, 0, 0, 0.f, 0.f});
     CAR_CHECK_LAUNCH("car_gather_encode");
     return CAR_OK;
 }
@@ -138,7 +150,28 @@ extern "C" int car_gather_encode_rows(const float* const* gmaps, const int* leve
     }
     (void)hipGetLastError();
     hipLaunchKernelGGL(encode_kernel, dim3(car_div_up(rows, kRows)), dim3(256), 0, (hipStream_t)stream, L, Cg, row_grid,
-                       (const float*)nullptr, row_pe, wpt, 1, rows, rows, out, ld_out, row_src);
+                       (const float*)nullptr, row_pe, wpt, 1, rows, rows, out, ld_out, row_src, EncodeLattice{0, 0, 0, 0.f, 0.f});
     CAR_CHECK_LAUNCH("car_gather_encode_rows");
+    return CAR_OK;
+}
+
+// The same rows from the merged lattice of car_merge_lattice (every level summed on the common lattice, one lattice per map and padding
+// mode: DESIGN.md 4.3): four taps per row instead of four per level.
+extern "C" int car_lattice_encode_rows(const float* lattice, int lat_h, int lat_w, int lat_pad, int Cg, const int* row_src, const float* row_grid,
+                                       const float* row_pe, const float* wpt, int n_maps, long rows, float* out, int ld_out, void* stream) {
+    CAR_REQUIRE(lattice && row_src && row_grid && row_pe && wpt && out, "car_lattice_encode_rows: null pointer");
+    CAR_REQUIRE(Cg > 0 && Cg % 4 == 0 && n_maps > 0 && rows > 0, "car_lattice_encode_rows: bad sizes");
+    CAR_REQUIRE(lat_pad >= 2 && lat_h > 2 * lat_pad + 1 && lat_w > 2 * lat_pad + 1 && ((lat_h - 2 * lat_pad) & 1) && ((lat_w - 2 * lat_pad) & 1),
+                "car_lattice_encode_rows: bad lattice %d x %d, pad %d (car_merge_lattice)", lat_h, lat_w, lat_pad);
+    CAR_REQUIRE((long)n_maps * 2 * lat_h * lat_w < 2147483647L, "car_lattice_encode_rows: too many lattice nodes");
+    CAR_REQUIRE(ld_out >= Cg && ld_out % 4 == 0, "car_lattice_encode_rows: ld_out (%d) must be a multiple of 4 and >= C (%d)", ld_out, Cg);
+    EncodeLevels L{};
+    L.n_levels = 1;
+    L.map[0] = lattice; L.h[0] = lat_h; L.w[0] = lat_w;
+    const EncodeLattice lat{lat_h, lat_w, lat_pad, (float)((lat_w - 2 * lat_pad + 1) / 2), (float)((lat_h - 2 * lat_pad + 1) / 2)};
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(encode_kernel, dim3(car_div_up(rows, kRows)), dim3(256), 0, (hipStream_t)stream, L, Cg, row_grid,
+                       (const float*)nullptr, row_pe, wpt, 1, rows, rows, out, ld_out, row_src, lat);
+    CAR_CHECK_LAUNCH("car_lattice_encode_rows");
     return CAR_OK;
 }

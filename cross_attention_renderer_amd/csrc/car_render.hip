@@ -538,6 +538,35 @@ extern "C" int car_project_maps(const car_dims* dims, const void* plan, const fl
     return CAR_OK;
 }
 
+// The lattice alone, for hosts that project the levels themselves (engine.py: the three-view exchange, which has no plan): levels[l] =
+// the projected level [n_maps, level_h[l], level_w[l], 576] channel-last; lattice = [n_maps][2 padding modes][lat_h][lat_w][576] (NULL: only
+// the shape is returned).
+extern "C" int car_merge_lattice(const float* const* levels, const int* level_h, const int* level_w, int n_levels, int n_maps, float* lattice,
+                                 int* lat_h, int* lat_w, int* lat_pad, void* stream) {
+    CAR_REQUIRE(levels && level_h && level_w && n_levels > 0 && n_levels <= CAR_MAX_LEVELS && n_maps > 0, "car_merge_lattice: bad arguments");
+    car_dims d{};
+    d.b = n_maps; d.V = 1; d.n_levels = n_levels;
+    for (int l = 0; l < n_levels; ++l) { d.level_h[l] = level_h[l]; d.level_w[l] = level_w[l]; }
+    const Lattice L = lattice_of(d);
+    CAR_REQUIRE(L.ok, "car_merge_lattice: every level must be an integer factor coarser than the widest one, the same factor in both directions");
+    if (lat_h) *lat_h = L.h;
+    if (lat_w) *lat_w = L.w;
+    if (lat_pad) *lat_pad = L.pad;
+    if (!lattice) return CAR_OK;
+    MergeArgs a{};
+    for (int l = 0; l < n_levels; ++l) {
+        CAR_REQUIRE(levels[l], "car_merge_lattice: level %d is null", l);
+        a.g[l] = levels[l]; a.h[l] = level_h[l]; a.w[l] = level_w[l]; a.r[l] = L.r[l];
+    }
+    a.n_levels = n_levels; a.lh = L.h; a.lw = L.w; a.pad = L.pad;
+    a.total = (long)n_maps * 2 * L.h * L.w * (kC / 4);
+    a.lat = lattice;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)car_div_up(a.total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    CAR_CHECK_LAUNCH("car_merge_lattice");
+    return CAR_OK;
+}
+
 // the launches of one forward call in two phases: CAR_PHASE_SAMPLES = rays + the fused per-sample kernel (compute / power bound),
 // CAR_PHASE_RAYS = the attention rounds and the per-ray chains (HBM bound), which only read what the first phase left in the workspace
 static int render_phases(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,

@@ -115,6 +115,8 @@ class RenderEngine:
         self._plan: Optional[Tensor] = None
         self._plan_keep: List[Tensor] = []
         self._pair_key = None
+        self._xlat = None              # merged lattice of the three-view exchange (car_merge_lattice), cached like the projected maps
+        self._xlat_key = None
         self._pair: Optional[Tensor] = None
         self._work: Optional[Tensor] = None
 
@@ -150,6 +152,12 @@ class RenderEngine:
         for n in ("latent_value", "key_map", "key_map_2", "query_embed", "query_embed_2", "encode_latent",
                   "query_repeat_embed_2", "phi.lin_in", "phi.lin_out"):
             add(n)
+        if m.n_view == 3 and not m.no_latent_concat:
+            # inference keeps e in component-major order [S, 3, C/2] (what query_encode_latent_2 writes) instead of the reference's channel-
+            # major interleave e[s, 3 ch + k] (models.py:446): the layers that read e get their input columns permuted once instead
+            for n in ("latent_value", "key_map"):
+                w = sd[n + ".weight"].reshape(sd[n + ".weight"].shape[0], -1)
+                pk[n + ".kmajor"] = PackedLinear(w.view(w.shape[0], -1, 3).permute(0, 2, 1).reshape(w.shape[0], -1), sd[n + ".bias"], device, n + ".kmajor")
         wr = sd["query_repeat_embed.weight"].reshape(128, -1)
         pk["query_repeat_embed.h"] = PackedLinear(wr[:, :128], None, device, "query_repeat_embed.h")           # z_embed half, per ray
         pk["query_repeat_embed.g"] = PackedLinear(wr[:, 128:], sd["query_repeat_embed.bias"], device, "query_repeat_embed.g")  # local_coords half
@@ -581,6 +589,7 @@ class RenderEngine:
         g = torch.empty(S, 16, **f32)
         single = (V == 1 and not m.no_latent_concat)
         concat3 = (V == 3 and not m.no_latent_concat)
+        kmajor = False
         grid_in = torch.empty(n, R, P, V, 2, **f32) if concat2 else None
         pt_in = torch.empty(n, R, P, V, 3, **f32) if concat3 else None
         x1 = None
@@ -626,6 +635,7 @@ class RenderEngine:
         elif concat3:
             e = self._encode_three_views(maps, poses, pixel_val, x1, pt_in, b, R, P, H, W, C, pk)
             Ce = 3 * (C // 2)
+            kmajor = self.project_maps                              # the inference path of _encode_three_views leaves e component-major
         elif single:
             self.gather(maps, pixel_val, R * P, 0, PLACE_PLAIN, V, x1, ld1, 0, run=P)
             e = torch.empty(S, C, **f32)
@@ -641,14 +651,35 @@ class RenderEngine:
         # commutes with the attention average: sum_s w_s (Wv e_s + bv) = Wv (sum_s w_s e_s) + bv because the softmax
         # weights of a ray sum to 1, so it is applied once per ray after the reduction instead of once per sample.
         k1 = torch.empty(S, 128, **f32)
-        self.linear(e, Ce, pk["key_map"], k1, 128, S, RELU_OUT)
+        self.linear(e, Ce, pk["key_map.kmajor" if kmajor else "key_map"], k1, 128, S, RELU_OUT)
         key = torch.empty(S, 128, **f32)
         self.linear(k1, 128, pk["key_map_2"], key, 128, S)
         self.linear(g, 16, pk["query_embed"], k1, 128, S, RELU_OUT)
         q = torch.empty(S, 128, **f32)
         self.linear(k1, 128, pk["query_embed_2"], q, 128, S)
 
-        return self._finish(inp, z, b, V, R, P, Ce, Dl, e, key, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug)
+        return self._finish(inp, z, b, V, R, P, Ce, Dl, e, key, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug, kmajor)
+
+    def _exchange_lattice(self, gmaps, ptrs, hs, ws, n_maps, C, dev):
+        """The projected levels of the three-view exchange summed on their common lattice (car_merge_lattice), cached with the projected
+        maps; None when the levels have no common lattice, the channel count is not the lattice kernels' 576, or it would not fit."""
+        if C != 576:
+            return None
+        key = self._gmaps_key                                      # identifies the projected levels' CONTENT (pyramid + layer versions)
+        if self._xlat is not None and self._xlat_key == key:
+            return self._xlat
+        L = len(gmaps)
+        lh, lw, lpad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        if self.lib.car_merge_lattice(ptrs, hs, ws, L, n_maps, None, ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(lpad), _stream()) != 0:
+            return None
+        floats = n_maps * 2 * lh.value * lw.value * C
+        if n_maps * 2 * lh.value * lw.value >= 2 ** 31 - 1 or floats * 4 > self._free_budget(dev) // 2:
+            return None
+        self._xlat = None
+        lattice = torch.empty(floats, device=dev, dtype=torch.float32)
+        _lib.check(self.lib.car_merge_lattice(ptrs, hs, ws, L, n_maps, _ptr(lattice), None, None, None, _stream()), "car_merge_lattice")
+        self._xlat, self._xlat_key = (lattice, lh.value, lw.value, lpad.value), key
+        return self._xlat
 
     def _encode_three_views(self, maps, poses, pixel_val, ptenc, pt_in, b, R, P, H, W, C, pk, keep=None):
         """Cross-view exchange for three context views (models.py:345-475), restated literally: for the samples of context c
@@ -693,11 +724,17 @@ class RenderEngine:
             ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in gmaps])
             hs = (ctypes.c_int * L)(*[g.shape[1] for g in gmaps])
             ws = (ctypes.c_int * L)(*[g.shape[2] for g in gmaps])
-            _lib.check(self.lib.car_gather_encode_rows(ptrs, hs, ws, L, C, _ptr(src), _ptr(rgrid), _ptr(rpe), _ptr(wpt), n, S * 3, _ptr(h1), C,
-                                                       _stream()), "car_gather_encode_rows")
+            lat = self._exchange_lattice(gmaps, ptrs, hs, ws, n, C, dev)
+            if lat is not None:                                     # four taps of the merged lattice per row instead of twelve
+                lattice, lh, lw, lpad = lat
+                _lib.check(self.lib.car_lattice_encode_rows(_ptr(lattice), lh, lw, lpad, C, _ptr(src), _ptr(rgrid), _ptr(rpe), _ptr(wpt), n, S * 3,
+                                                            _ptr(h1), C, _stream()), "car_lattice_encode_rows")
+            else:
+                _lib.check(self.lib.car_gather_encode_rows(ptrs, hs, ws, L, C, _ptr(src), _ptr(rgrid), _ptr(rpe), _ptr(wpt), n, S * 3, _ptr(h1), C,
+                                                           _stream()), "car_gather_encode_rows")
             enc = torch.empty(S * 3, C // 2, **f32)
             self.linear(h1, C, pk["query_encode_latent_2"], enc, C // 2, S * 3)
-            return enc.view(S, 3, C // 2).permute(0, 2, 1).contiguous().view(S, 3 * (C // 2))
+            return enc.view(S, 3 * (C // 2))                          # component-major: the consumers' weights are permuted (_weights)
         ld = _round_up(C + 3, 32)
         x3 = torch.empty(S * 3, ld, **f32)
         x3v = x3.view(b, V, pts, 3, ld)                     # [scene, context c, point, component k, channel]
@@ -733,7 +770,7 @@ class RenderEngine:
         # channel index = ch*3 + k (torch.cat on dim 2 then flatten(1, 2), models.py:446)
         return enc.view(S, 3, C // 2).permute(0, 2, 1).contiguous().view(S, 3 * (C // 2))
 
-    def _finish(self, inp, z, b, V, R, P, Ce, Dl, e, key, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug):
+    def _finish(self, inp, z, b, V, R, P, Ce, Dl, e, key, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug, kmajor=False):
         """Attention rounds, decoder and output dict of the staged route; ``g`` is the geometric
         query local_coords [S,16]."""
         m, lib = self.m, self.lib
@@ -741,6 +778,7 @@ class RenderEngine:
         f32 = dict(device=dev, dtype=torch.float32)
         st = _stream()
         pk = self._packed
+        lv = pk["latent_value.kmajor" if kmajor else "latent_value"]
         n, S = b * V, b * V * R * P
         n_qry = 1
         qry = inp["query"]
@@ -756,7 +794,7 @@ class RenderEngine:
         at_wt2 = None
         if rep:
             z1 = torch.empty(b * R, Dl, **f32)
-            self.linear(ebar, Ce, pk["latent_value"], z1, Dl, b * R)
+            self.linear(ebar, Ce, lv, z1, Dl, b * R)
             # a15: second round; the z_embed half of query_repeat_embed is per ray, the local_coords half per sample
             hb = torch.empty(b * R, 128, **f32)
             self.linear(z1, Dl, pk["encode_latent"], hb, 128, b * R)
@@ -781,9 +819,9 @@ class RenderEngine:
             # z = (Wv ebar2 + bv) + V * z1   (models.py:561-565: "+ z_local" per view, then the view sum)
             zv = zrep.view(b * R, V, Dl)
             zv[:, 0] = z1 * float(V)
-            self.linear(ebar, Ce, pk["latent_value"], zrep, V * Dl, b * R, ACCUM)
+            self.linear(ebar, Ce, lv, zrep, V * Dl, b * R, ACCUM)
         else:
-            self.linear(ebar, Ce, pk["latent_value"], zrep, V * Dl, b * R)
+            self.linear(ebar, Ce, lv, zrep, V * Dl, b * R)
         if V > 1:                                         # the per-view replication of models.py:541, 565, 605-606
             zv = zrep.view(b * R, V, Dl)
             zv[:, 1:] = zv[:, :1]
@@ -821,6 +859,8 @@ class RenderEngine:
         }
         if debug:
             out["stages"] = {"rays": rays, "pt": pt.view(n, R, P, 3),
-                             "local_coords": g.view(n, R, P, 16), "interp_val": e.view(n, R, P, Ce),
+                             "local_coords": g.view(n, R, P, 16),
+                             # the reference's channel order e[s, 3 ch + k] (models.py:446) when e was kept component-major
+                             "interp_val": (e.view(S, 3, Ce // 3).permute(0, 2, 1).reshape(n, R, P, Ce) if kmajor else e.view(n, R, P, Ce)),
                              "z_final": zrep[:, :Dl].reshape(b, R, Dl), "at_wt2": at_wt2, "poses": poses}
         return out

@@ -123,6 +123,13 @@ int car_gather_encode(const float* const* gmaps, const int* level_h, const int* 
 int car_gather_encode_rows(const float* const* gmaps, const int* level_h, const int* level_w, int n_levels, int Cg,
                            const int* row_src, const float* row_grid, const float* row_pe, const float* wpt, int n_maps,
                            long rows, float* out, int ld_out, void* stream);
+/* The same rows from ONE merged lattice per (map, padding mode) instead of the levels: car_merge_lattice sums the projected
+ * levels [n_maps, Hl, Wl, 576] on their common integer lattice — [n_maps][2][lat_h][lat_w][576]; with lattice == NULL it only returns the
+ * shape — and car_lattice_encode_rows reads four taps of it per row (row_src / row_grid / row_pe as above). */
+int car_merge_lattice(const float* const* levels, const int* level_h, const int* level_w, int n_levels, int n_maps, float* lattice,
+                      int* lat_h, int* lat_w, int* lat_pad, void* stream);
+int car_lattice_encode_rows(const float* lattice, int lat_h, int lat_w, int lat_pad, int Cg, const int* row_src, const float* row_grid,
+                            const float* row_pe, const float* wpt, int n_maps, long rows, float* out, int ld_out, void* stream);
 
 /* ---- a6-a13 + logits of a14 in ONE kernel for the default configuration (V = 2, C = 576, hidden 128): geometry, the
  * per-texel-projected encode (car_gather_encode's arithmetic, with ALL pyramid levels summed once per stereo pair on their common
