@@ -100,6 +100,8 @@ def test_split_fp16_linear_matches_torch(M, K, N, flags):
     X = torch.randn(M, ldx, generator=g) * torch.logspace(-6, 4, M).unsqueeze(1)          # rows from 1e-6 to 1e4
     if M % 2:                                                                               # and magnitudes that grow 1e6-fold along the row: the
         X = X * torch.logspace(-3, 3, ldx).unsqueeze(0)                                     # row's power of two is re-chosen chunk after chunk
+    X[::5, :min(K, 96)] = 0.0                                                               # rows that start with whole chunks of zeros
+    X[7::11] = 0.0                                                                          # and all-zero rows (the output is the bias)
     Wt = torch.randn(N, K, generator=g) / K ** 0.5
     bias = torch.randn(N, generator=g)
     Y0 = torch.randn(M, ldy, generator=g)
