@@ -56,40 +56,52 @@ __global__ void __launch_bounds__(256) wgrad_tile_kernel(const float* __restrict
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 stage[kPer];
-    // float4 f of a block: the first kA4 belong to dY (row f / (WN / 4), columns 4 (f % (WN / 4)) ...), the rest to X
+    // float4 f of a block: the first kA4 belong to dY (row f / (WN / 4), columns 4 (f % (WN / 4)) ...), the rest to X.  fetch() only issues
+    // the loads (from a clamped, always valid address); what a value must be replaced by — zeros past the edges, the bias column, relu — is
+    // applied in commit(), after the block's MFMAs: touching the loaded registers here would put the memory latency in front of them
+    // (it was 40 % of the kernel's time)
     auto fetch = [&](long m) {
 #pragma unroll
         for (int p = 0; p < kPer; ++p) {
             const int f = tid + 256 * p;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (f < kA4) {
                 const int r = f / (WN / 4), c = 4 * (f % (WN / 4));
-                const long row = m + r;
-                if (row < m_end && n0 + c < ldy) v = *reinterpret_cast<const f32x4*>(dY + row * ldy + n0 + c);
-                for (int e = 0; e < 4; ++e) if (n0 + c + e >= N) v[e] = 0.0f;
+                const long row = m + r < m_end ? m + r : m_end - 1;
+                const int cc = n0 + c < ldy - 3 ? n0 + c : 0;
+                stage[p] = *reinterpret_cast<const f32x4*>(dY + row * ldy + cc);
             } else if (f < kA4 + kB4) {
                 const int g = f - kA4, r = g / (WK / 4), c = 4 * (g % (WK / 4));
-                const long row = m + r;
-                if (row < m_end && k0 + c < ldx) v = *reinterpret_cast<const f32x4*>(X + row * ldx + k0 + c);
-                for (int e = 0; e < 4; ++e) {
-                    const int k = k0 + c + e;
-                    if (k >= K) v[e] = (k == K && db && row < m_end) ? 1.0f : 0.0f;        // the bias column, then nothing
-                    else if (relu_x) v[e] = fmaxf(v[e], 0.0f);
-                }
+                const long row = m + r < m_end ? m + r : m_end - 1;
+                const int cc = k0 + c < ldx - 3 ? k0 + c : 0;
+                stage[p] = *reinterpret_cast<const f32x4*>(X + row * ldx + cc);
             }
-            stage[p] = v;
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, long m) {
 #pragma unroll
         for (int p = 0; p < kPer; ++p) {
             const int f = tid + 256 * p;
-            if (f < kA4) *reinterpret_cast<f32x4*>(la + buf * kWtRows * WN + 4 * f) = stage[p];
-            else if (f < kA4 + kB4) *reinterpret_cast<f32x4*>(lb + buf * kWtRows * WK + 4 * (f - kA4)) = stage[p];
+            f32x4 v = stage[p];
+            if (f < kA4) {
+                const int r = f / (WN / 4), c = 4 * (f % (WN / 4));
+                const bool live = m + r < m_end && n0 + c < ldy - 3;
+                for (int e = 0; e < 4; ++e) if (!live || n0 + c + e >= N) v[e] = 0.0f;
+                *reinterpret_cast<f32x4*>(la + buf * kWtRows * WN + 4 * f) = v;
+            } else if (f < kA4 + kB4) {
+                const int g = f - kA4, r = g / (WK / 4), c = 4 * (g % (WK / 4));
+                const bool in_rows = m + r < m_end, live = in_rows && k0 + c < ldx - 3;
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + c + e;
+                    if (k >= K) v[e] = (k == K && db && in_rows) ? 1.0f : 0.0f;                // the bias column, then nothing
+                    else if (!live) v[e] = 0.0f;
+                    else if (relu_x) v[e] = fmaxf(v[e], 0.0f);
+                }
+                *reinterpret_cast<f32x4*>(lb + buf * kWtRows * WK + 4 * (f - kA4)) = v;
+            }
         }
     };
     const int half = lane >> 5, col = lane & 31;
-    if (m_begin < m_end) { fetch(m_begin); commit(0); }
+    if (m_begin < m_end) { fetch(m_begin); commit(0, m_begin); }
     __syncthreads();
     int buf = 0;
     for (long m = m_begin; m < m_end; m += kWtRows) {
@@ -97,19 +109,26 @@ __global__ void __launch_bounds__(256) wgrad_tile_kernel(const float* __restrict
         if (more) fetch(m + kWtRows);
         const float* pa = la + buf * kWtRows * WN + wn * (TN * 32) + col;
         const float* pb = lb + buf * kWtRows * WK + wk * (TK * 32) + col;
+        // the operands of step u + 1 are read while the MFMAs of step u run (one wave per SIMD: nobody else hides the LDS round trip)
+        float a[2][TN], bq[2][TK];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) a[0][i] = pa[half * WN + 32 * i];
+#pragma unroll
+        for (int j = 0; j < TK; ++j) bq[0][j] = pb[half * WK + 32 * j];
 #pragma unroll
         for (int u = 0; u < kWtRows / 2; ++u) {
-            float a[TN], bq[TK];
+            if (u + 1 < kWtRows / 2) {
 #pragma unroll
-            for (int i = 0; i < TN; ++i) a[i] = pa[(2 * u + half) * WN + 32 * i];
+                for (int i = 0; i < TN; ++i) a[(u + 1) & 1][i] = pa[(2 * (u + 1) + half) * WN + 32 * i];
 #pragma unroll
-            for (int j = 0; j < TK; ++j) bq[j] = pb[(2 * u + half) * WK + 32 * j];
+                for (int j = 0; j < TK; ++j) bq[(u + 1) & 1][j] = pb[(2 * (u + 1) + half) * WK + 32 * j];
+            }
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u & 1][i], bq[u & 1][j], acc[i][j], 0, 0, 0);
         }
-        if (more) commit(buf ^ 1);
+        if (more) commit(buf ^ 1, m + kWtRows);
         __syncthreads();
         buf ^= 1;
     }
