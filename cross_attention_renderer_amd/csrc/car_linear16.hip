@@ -60,14 +60,23 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
 #pragma unroll
         for (int p = 0; p < kPieces; ++p) stream_issue_piece(n0, p, lane, wave);
     }
-    // this lane's eight values of chunk c: k = 32 c + 8 q4 .. + 7 (zeros beyond K; relu on the way in where the layer asks for it)
-    auto load_x = [&](int c, float (&x)[8]) {
+    // this lane's eight values of chunk c: k = 32 c + 8 q4 .. + 7.  issue_x only issues the two loads (from a clamped, valid address);
+    // finish_x turns them into values (zeros beyond K, relu where the layer asks for it) when they are consumed — touching the loaded
+    // registers at the load would put the memory latency in front of the chunk's MFMAs
+    auto issue_x = [&](int c, float4 (&raw)[2]) {
         const int k0 = 32 * c + 8 * q4;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int kq = k0 + 4 * h;
-            const float4 v = *reinterpret_cast<const float4*>(xrow + (kq < K ? kq : 0));
-            const float e[4] = {v.x, v.y, v.z, v.w};
+            raw[h] = *reinterpret_cast<const float4*>(xrow + (kq < K ? kq : 0));
+        }
+    };
+    auto finish_x = [&](int c, const float4 (&raw)[2], float (&x)[8]) {
+        const int k0 = 32 * c + 8 * q4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kq = k0 + 4 * h;
+            const float e[4] = {raw[h].x, raw[h].y, raw[h].z, raw[h].w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float t = kq + i < K ? e[i] : 0.0f;
@@ -85,7 +94,11 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
     };
     const float dW = a.down[0];
     float xc[8];
-    load_x(0, xc);
+    {
+        float4 raw[2];
+        issue_x(0, raw);
+        finish_x(0, raw, xc);
+    }
     float mrun = fmaxf(row_max(xc), 1e-30f), p, pinv;
     pow2_scale(mrun, p, pinv);
 
@@ -103,8 +116,9 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
     for (int c = 0; c < a.chunks; ++c) {
         const float* wl = lds + (c & 1) * NT * kTile + 4 * lane;
         const NextChunk nx = chunk_desc(c + 1);
-        float xn[8];
-        load_x(c + 1 < a.chunks ? c + 1 : c, xn);                      // next chunk's rows: in flight under this chunk's MFMAs
+        const int cn = c + 1 < a.chunks ? c + 1 : c;
+        float4 rawn[2];
+        issue_x(cn, rawn);                                             // next chunk's rows: in flight under this chunk's MFMAs
 #pragma unroll
         for (int qs = 0; qs < NT / 2; ++qs) {
             const float* w0 = wl + (2 * qs * 2) * 256;
@@ -113,6 +127,8 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // the next chunk may outgrow the row's power of two: move the row (accumulators and scale) to the smaller one, exactly
+        float xn[8];
+        finish_x(cn, rawn, xn);
         const float mn = row_max(xn);
         if (__builtin_amdgcn_ballot_w64(mn > mrun) != 0) {
             float pn, pninv;
