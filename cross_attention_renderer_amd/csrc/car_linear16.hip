@@ -14,7 +14,9 @@ namespace {
 
 constexpr int kWaves = 12, kRows = 16, kGroupRows = kWaves * kRows;
 constexpr int kThreads = 64 * kWaves;
-constexpr int kPieces = 3;
+constexpr int kPieces = 3;                         // LDS-DMA pieces of the widest chunk (18 tiles = 36 KB over 12 waves); narrower column groups
+                                                   // take fewer (pieces_of): a piece index past the chunk would copy from beyond it
+constexpr int pieces_of(int nt) { return (2 * nt + kWaves - 1) / kWaves; }
 
 #include "car_fused_mma.h"
 
@@ -35,6 +37,7 @@ struct LinArgs {
 template <int NT>
 __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][NT][512]
+    static_assert(kWaves * pieces_of(NT) <= 3 * 2 * NT, "stream_issue_piece wraps a piece index into the chunk with two subtractions");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s = lane & 15, q4 = lane >> 4;
@@ -58,7 +61,7 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
     {
         const NextChunk n0 = chunk_desc(0);
 #pragma unroll
-        for (int p = 0; p < kPieces; ++p) stream_issue_piece(n0, p, lane, wave);
+        for (int p = 0; p < pieces_of(NT); ++p) stream_issue_piece(n0, p, lane, wave);
     }
     // this lane's eight values of chunk c: k = 32 c + 8 q4 .. + 7.  issue_x only issues the two loads (from a clamped, valid address);
     // finish_x turns them into values (zeros beyond K, relu where the layer asks for it) when they are consumed — touching the loaded
@@ -123,7 +126,7 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
         for (int qs = 0; qs < NT / 2; ++qs) {
             const float* w0 = wl + (2 * qs * 2) * 256;
             mfma_pair(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
-            if (qs < kPieces) stream_issue_piece(nx, qs, lane, wave);
+            if (qs < pieces_of(NT)) stream_issue_piece(nx, qs, lane, wave);
             __builtin_amdgcn_sched_barrier(0);
         }
         // the next chunk may outgrow the row's power of two: move the row (accumulators and scale) to the smaller one, exactly
