@@ -63,11 +63,15 @@ SIGNATURES = {
     "car_fused_bias_floats": (c_size_t, []),
     "car_fused_samples": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   _P, _P, _P, _P, _P, _P, _P]),
+    "car_fused_tile_steps": (c_int, []),
+    "car_fused_samples_parts": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        _P, _P, _P, _P, _P, _P, _P, _P]),
     "car_linear_packed_floats": (c_size_t, [c_int, c_int]),
     "car_linear_pack": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "car_linear": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_long, c_int, _P]),
     "car_attend": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P, c_int, c_int,
                            _P, _P, _P, _P, _P]),
+    "car_attend_parts": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     "car_round2_packed_floats": (c_size_t, []),
     "car_round2_bias_floats": (c_size_t, []),
     "car_round2_logits": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),

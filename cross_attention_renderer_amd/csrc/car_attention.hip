@@ -21,13 +21,19 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// PARTS (car_attend_parts): `val` holds, per ray and group of `tile_steps` consecutive steps of a view, the partial sum
+// sum_j exp(logit_j - m_g) val_j with m_g the group's largest logit (written by the fused per-sample kernel, csrc/car_fused.hip); the value
+// reduction then runs over the V * ceil(P / tile_steps) groups with the weights exp(m_g - M) / L instead of over the V * P sample rows —
+// the same sum, 1 / tile_steps of the bytes.  The softmax weights themselves (w_out, depth, argmax) are computed exactly as without.
+template <bool PARTS>
 __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ qa, const float* __restrict__ qb, int dq,
                                                      const float* __restrict__ val, int D, int b, int V, int R, int P,
                                                      const float* __restrict__ zprev, float zprev_scale,
                                                      float* __restrict__ w_out, float* __restrict__ z_out, int ld_z, int reps,
                                                      const float* __restrict__ pt, const CarPose* __restrict__ poses,
-                                                     float* __restrict__ depth, int32_t* __restrict__ w_argmax) {
+                                                     float* __restrict__ depth, int32_t* __restrict__ w_argmax, int tile_steps) {
     __shared__ float s_w[kMaxSamples];
+    __shared__ float s_g[PARTS ? kMaxSamples / 4 : 1];       // PARTS: the groups' weights exp(m_g - M) / L
     __shared__ float s_red[8];
     __shared__ __attribute__((aligned(16))) float s_z[4 * 64 * kMaxSeg];       // per-wave partial sums of the value reduction
     const int sc = blockIdx.x / R, r = blockIdx.x % R;
@@ -62,6 +68,16 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
     if (lane == 0) s_red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const int pgs = PARTS ? (P + tile_steps - 1) / tile_steps : 0;
+    if constexpr (PARTS) {                                  // exp(m_g - M) of every group, from the raw logits (before they are overwritten)
+        for (int gi = tid; gi < V * pgs; gi += 256) {
+            const int v = gi / pgs, p0 = (gi % pgs) * tile_steps;
+            float mg = -INFINITY;
+            for (int p = p0; p < p0 + tile_steps && p < P; ++p) mg = fmaxf(mg, s_w[v * P + p]);
+            s_g[gi] = expf(mg - m);
+        }
+        __syncthreads();
+    }
     float sum = 0.0f;
     for (int s = tid; s < S; s += 256) { const float e = expf(s_w[s] - m); s_w[s] = e; sum += e; }
     sum = wave_sum(sum);
@@ -73,7 +89,15 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
         s_w[s] = w;
         w_out[row_of(s)] = w;
     }
+    if constexpr (PARTS) { for (int gi = tid; gi < V * pgs; gi += 256) s_g[gi] = s_g[gi] / sum; }
     __syncthreads();
+    // rows of the value reduction and their weights: the samples, or (PARTS) the step groups
+    const int NV = PARTS ? V * pgs : S;
+    const float* wv = PARTS ? s_g : s_w;
+    auto vrow_of = [&](int i) -> long {
+        if constexpr (PARTS) return ((long)(sc * V + i / pgs) * R + r) * pgs + (i % pgs);
+        else return row_of(i);
+    };
     // 3. z = sum_s w_s val[s] (+ scale * zprev), replicated `reps` times
     if (D % 64 == 0 && D <= 64 * kMaxSeg) {
         // Streaming form for wide rows: a 16-lane group reads a whole row as D/64 float4 loads (16 B per lane, the row's D*4
@@ -83,11 +107,11 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
         float4 part[kMaxSeg];
 #pragma unroll
         for (int j = 0; j < kMaxSeg; ++j) part[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s0 = 0; s0 < S; s0 += 16) {
+        for (int s0 = 0; s0 < NV; s0 += 16) {
             const int sidx = s0 + grp;
-            const bool on = sidx < S;
-            const float w = on ? s_w[sidx] : 0.0f;
-            const float* rowp = val + row_of(on ? sidx : S - 1) * D + 4 * sub;
+            const bool on = sidx < NV;
+            const float w = on ? wv[sidx] : 0.0f;
+            const float* rowp = val + vrow_of(on ? sidx : NV - 1) * D + 4 * sub;
 #pragma unroll
             for (int j = 0; j < kMaxSeg; ++j) {
                 if (j < nseg) {
@@ -119,7 +143,7 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
     } else
     for (int d = tid; d < D; d += 256) {
         float acc = 0.0f;
-        for (int s = 0; s < S; ++s) acc += s_w[s] * val[row_of(s) * D + d];
+        for (int s = 0; s < NV; ++s) acc += wv[s] * val[vrow_of(s) * D + d];
         if (zprev) acc += zprev_scale * zprev[((long)sc * R + r) * D + d];
         for (int k = 0; k < reps; ++k) z_out[((long)sc * R + r) * ld_z + (long)k * D + d] = acc;
     }
@@ -180,10 +204,25 @@ extern "C" int car_attend(const float* qa, const float* qb, int dq, const float*
     CAR_REQUIRE((!qb || (dq > 0 && dq % 4 == 0)) && D > 0 && reps >= 1 && ld_z >= reps * D, "car_attend: bad widths dq=%d D=%d", dq, D);
     CAR_REQUIRE(!pt || (poses && depth), "car_attend: pt needs poses and depth");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(attend_kernel, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, qa, qb, dq, val,
+    hipLaunchKernelGGL(attend_kernel<false>, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, qa, qb, dq, val,
                        D, b, V, R, P, zprev, zprev_scale, w_out, z_out, ld_z, reps, pt, (const CarPose*)poses, depth,
-                       w_argmax);
+                       w_argmax, 0);
     CAR_CHECK_LAUNCH("car_attend");
+    return CAR_OK;
+}
+
+extern "C" int car_attend_parts(const float* logit, const float* part, int tile_steps, int D, int b, int V, int R, int P, float* w_out,
+                                float* z_out, int ld_z, int reps, const float* pt, const float* poses, float* depth, int32_t* w_argmax,
+                                void* stream) {
+    CAR_REQUIRE(logit && part && w_out && z_out, "car_attend_parts: null pointer");
+    CAR_REQUIRE(b > 0 && V > 0 && V <= CAR_MAX_VIEWS && R > 0 && P > 0 && V * P <= kMaxSamples, "car_attend_parts: bad sizes");
+    CAR_REQUIRE(tile_steps >= 4 && D > 0 && reps >= 1 && ld_z >= reps * D, "car_attend_parts: bad widths D=%d tile_steps=%d", D, tile_steps);
+    CAR_REQUIRE(!pt || (poses && depth), "car_attend_parts: pt needs poses and depth");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(attend_kernel<true>, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, logit, (const float*)nullptr, 0,
+                       part, D, b, V, R, P, (const float*)nullptr, 0.0f, w_out, z_out, ld_z, reps, pt, (const CarPose*)poses, depth, w_argmax,
+                       tile_steps);
+    CAR_CHECK_LAUNCH("car_attend_parts");
     return CAR_OK;
 }
 

@@ -83,6 +83,7 @@ struct FusedArgs {
     float* logit;
     float* pt;
     float* pixel_val;
+    float* part;               // [b*V][R][ceil(P / kTileSteps)][kC]: per (ray, step group) sum_j exp(logit_j - max_j logit) e_j, or NULL
 };
 
 // chunk order:  W2 x18 (source 0) | W2 x18 (source 1) | K1 over e_1 x5 (2,2,2,2,1 K steps) | K1 over e_0 x5 | K2 x2 | Q1 | Q2 x2
@@ -656,6 +657,58 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         if (q4 == 0) a.logit[i] = dot / 16.0f;
     }
     mark(6);
+    // ---- first attention round, this workgroup's share (models.py:533-541): for each of its rays the step group's
+    //      sum_j exp(logit_j - m) e_j with m = max_j logit_j over the group's kTileSteps samples, read back from the rows of e this
+    //      workgroup has just written (L2) — 1/kTileSteps of the bytes the attention launch would otherwise stream from HBM; that launch
+    //      (car_attend_parts) folds the groups of a ray together with exp(m - M) / L.  A wave owns kTileRays / kWaves rays; a 16-lane
+    //      group reads a whole 2304-byte row as nine float4 per lane, the wave's four groups take four rows at a time.
+    if (a.part) {
+        constexpr int kRaysPerWave = kTileRays / kWaves, kRowIts = kTileSteps / 4;
+        static_assert(kTileRays % kWaves == 0 && kTileSteps % 4 == 0, "partial sums: whole rays per wave, four rows at a time");
+        float* lgt = lds + kLdsG;                                      // the wave's g rows are dead: row (wave, s) keeps its logit in float 0
+        if (q4 == 0) lgt[(wave * kRows + s) * 16] = live ? dot / 16.0f : -INFINITY;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's e / qry rows have reached L2 (same XCD, write-through L1)
+        __syncthreads();
+        const int sub = lane & 15, grp = lane >> 4;
+        auto lgt_of = [&](int rr, int k) -> float {                    // logit of the tile's (ray rr, step k): inverse of tile_ray / tile_step
+            const int w_ = (rr / kWaveRays) * kStepWaves + k / kWaveSteps, s_ = (rr % kWaveRays) + kWaveRays * (k % kWaveSteps);
+            return lgt[(w_ * kRows + s_) * 16];
+        };
+#pragma unroll 1
+        for (int rw = 0; rw < kRaysPerWave; ++rw) {
+            const int rr = wave * kRaysPerWave + rw, ray_g = bun * kTileRays + rr;
+            if (ray_g >= a.R) break;                                   // wave-uniform
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < kTileSteps; ++k) mx = fmaxf(mx, lgt_of(rr, k));
+            f32x4 x[kRowIts][kC / 64];
+            float pw[kRowIts];
+#pragma unroll
+            for (int it = 0; it < kRowIts; ++it) {
+                const int k = 4 * it + grp, pp_k = pg * kTileSteps + k;
+                pw[it] = expf(lgt_of(rr, k) - mx);                     // a step past P carries -inf: weight 0 (its row is a duplicate of step P - 1)
+                const f32x4* rowp = reinterpret_cast<const f32x4*>(a.e + (((long)nn * a.R + ray_g) * a.P + (pp_k < a.P ? pp_k : a.P - 1)) * kC + 4 * sub);
+#pragma unroll
+                for (int j = 0; j < kC / 64; ++j) x[it][j] = __builtin_nontemporal_load(rowp + 16 * j);    // read once, written by other waves: past L1
+            }
+            float* out = a.part + (((long)nn * a.R + ray_g) * pgs + pg) * kC + 4 * sub;
+#pragma unroll
+            for (int j = 0; j < kC / 64; ++j) {
+                f32x4 acc = x[0][j] * pw[0];
+#pragma unroll
+                for (int it = 1; it < kRowIts; ++it) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = fmaf(pw[it], x[it][j][c], acc[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[c] += __shfl_xor(acc[c], 16, 64);
+                    acc[c] += __shfl_xor(acc[c], 32, 64);
+                }
+                if (grp == 0) *reinterpret_cast<f32x4*>(out + 64 * j) = acc;
+            }
+        }
+    }
     if constexpr (ABL == 20) {
         if (lane == 0) {
             long long* out = reinterpret_cast<long long*>(a.pixel_val) + ((long)blk * kWaves + wave) * 8;
@@ -673,7 +726,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
 
 int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w, int lat_pad,
                  const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W, int no_sample, float* e,
-                 float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+                 float* qry, float* g, float* logit, float* pt, float* pixel_val, float* part, void* stream) {
     CAR_REQUIRE(poses && rays && steps && lattice && gmeta && wpt && blob && bias, "car_fused_samples: null input");
     CAR_REQUIRE(e && qry && g && logit && pt && pixel_val, "car_fused_samples: null output");
     CAR_REQUIRE(V == 2, "car_fused_samples: built for V = 2 (got %d)", V);
@@ -692,7 +745,7 @@ int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* r
     a.no_sample = no_sample != 0;
     a.S = (long)b * V * R * P;
     a.blk0 = blk0;
-    a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val;
+    a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val; a.part = part;
     long groups = (long)b * V * car_div_up(R, kTileRays) * car_div_up(P, kTileSteps);
     if (nblk > 0) groups = (groups - blk0 < nblk) ? groups - blk0 : nblk;     // development build: a slice of the sample groups
     void (*kern)(const FusedArgs) = fused_kernel<0>;
@@ -731,7 +784,19 @@ extern "C" int car_fused_samples(const float* poses, const float* rays, const fl
                                  int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P,
                                  int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
     return launch_fused(0, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, qry, g, logit, pt,
-                        pixel_val, stream);
+                        pixel_val, nullptr, stream);
+}
+
+// the same launch, which also leaves the first attention round's per-step-group partial sums in `part`
+// [b*V][R][ceil(P / car_fused_tile_steps())][576] for car_attend_parts
+extern "C" int car_fused_tile_steps(void) { return kTileSteps; }
+extern "C" int car_fused_samples_parts(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
+                                       int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,
+                                       int P, int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val,
+                                       float* part, void* stream) {
+    CAR_REQUIRE(part, "car_fused_samples_parts: null output");
+    return launch_fused(0, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, qry, g, logit, pt,
+                        pixel_val, part, stream);
 }
 
 #ifdef CAR_ABLATION
@@ -741,7 +806,7 @@ extern "C" int car_fused_samples_ablate(int abl, const float* poses, const float
                                         int V, int R, int P, int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt,
                                         float* pixel_val, void* stream) {
     return launch_fused(abl, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, qry, g, logit, pt,
-                        pixel_val, stream);
+                        pixel_val, nullptr, stream);
 }
 // the same launch cut into slices of `nblk` sample groups (one kernel launch each): every slice starts its workgroups in phase
 extern "C" int car_fused_samples_sliced(int nblk, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h,
@@ -751,7 +816,7 @@ extern "C" int car_fused_samples_sliced(int nblk, const float* poses, const floa
     const long groups = (long)b * V * car_div_up(R, kTileRays) * car_div_up(P, kTileSteps);
     for (long b0 = 0; b0 < groups; b0 += nblk) {
         const int rc = launch_fused(0, (int)b0, nblk, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, qry, g,
-                                    logit, pt, pixel_val, stream);
+                                    logit, pt, pixel_val, nullptr, stream);
         if (rc != CAR_OK) return rc;
     }
     return CAR_OK;

@@ -13,6 +13,7 @@
 
 extern "C" size_t car_fused_blob_floats(void);
 extern "C" size_t car_fused_bias_floats(void);
+extern "C" int car_fused_tile_steps(void);
 extern "C" size_t car_round2_packed_floats(void);
 extern "C" size_t car_round2_bias_floats(void);
 extern "C" size_t car_chain_packed_floats(int K, int N);
@@ -123,50 +124,155 @@ __global__ void wpt_kernel(const float* __restrict__ w1, const float* __restrict
     m = block_max(m, red);
     if (threadIdx.x == 0) bound[0] = m;
 }
-// out[0] = max |x[i]| (non-negative floats order like their bit patterns); out must be zeroed first
-__global__ void absmax_kernel(const float* __restrict__ x, long n4, unsigned* __restrict__ out) {
-    float m = 0.0f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const float4 v = reinterpret_cast<const float4*>(x)[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
-}
 // The merged lattice (car_geom.h car_lattice_taps): node (jy, jx) of map (m, mode) = sum over the levels of the bilinear
 // interpolation of the projected level G_l[m] at lattice coordinate u = j - pad, i.e. at texel coordinate (u + 1 - r_l) / (2 r_l) of
-// a level r_l times coarser than the finest, with the level's own padding rule (mode 0 border, 1 zeros).  One thread = four channels
-// of one node.
+// a level r_l times coarser than the finest, with the level's own padding rule (mode 0 border, 1 zeros).
+// A 16-lane group owns one node of one map and writes BOTH padding modes of it: the taps and weights of every level are worked out
+// once per node (per 16-lane group, not per float4 of channels: that arithmetic used to be most of the kernel's time); a source row
+// both modes read with a non-zero weight — every tap of an interior node — is loaded once; taps of weight zero (three of four on
+// the finest level's own texel centres) get an out-of-range buffer offset: the load returns zeros without touching memory, and an
+// instruction whose lanes are all out of range costs the texture path nothing (profiles/round3_fused_experiments.md).  No branch
+// per tap, so a whole channel step's loads are in flight together.  Lane `sub` takes the channel quads sub + 16 j: a load / store
+// instruction of the group moves 256 contiguous bytes.  The sums run in the order the one-mode kernel used (levels from the last
+// index down, taps nw ne sw se, one fused multiply-add each; a skipped tap had weight zero), so the values are the same up to the
+// sign of an exact zero.
+// gmax (optional): the largest |lattice value| goes there (atomic max of the bit pattern: non-negative floats order like integers; the
+// caller zeroes it) — one atomic per workgroup of a grid-stride launch; it bounds h in the fused kernel's fp16 split.
 struct MergeArgs {
-    const float* g[CAR_MAX_LEVELS];
+    const float* g[CAR_MAX_LEVELS];   // level l of the launch's first map
+    unsigned bytes[CAR_MAX_LEVELS];   // the launch's maps of level l: range of the buffer loads (< 2 GiB, car_project_maps slices the maps)
     int h[CAR_MAX_LEVELS], w[CAR_MAX_LEVELS], r[CAR_MAX_LEVELS];
     int n_levels, lh, lw, pad;
-    long total;                   // n_maps * 2 * lh * lw * (kC / 4)
-    float* lat;
+    long nodes;                       // maps of the launch * lh * lw
+    float* lat;                       // [maps][2][lh][lw][kC] of the launch's first map
 };
-__global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.total) return;
-    const int q = (int)(idx % (kC / 4));
-    long node = idx / (kC / 4);
-    const int jx = (int)(node % a.lw); node /= a.lw;
-    const int jy = (int)(node % a.lh); node /= a.lh;
-    const int mode = (int)(node & 1), m = (int)(node >> 1);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int l = a.n_levels - 1; l >= 0; --l) {
-        const float r2 = (float)(2 * a.r[l]);
-        const float ix = (float)(jx - a.pad + 1 - a.r[l]) / r2, iy = (float)(jy - a.pad + 1 - a.r[l]) / r2;
-        int t4[4];
-        float w4[4];
-        car_bilinear_taps_px(ix, iy, a.w[l], a.h[l], mode, t4, w4);
-        const float* base = a.g[l] + (long)m * a.h[l] * a.w[l] * kC + 4 * q;
+typedef float mf32x4 __attribute__((ext_vector_type(4)));
+typedef float mf32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kNoTap = 0xc0000000u;          // beyond any sliced level: the load returns zeros
+// Level l's four taps at node (jx, jy) of the launch's map m, for the lane that owns channel quad `sub`: ob = byte offset of the load
+// that serves border mode — or, where border mode's weight is zero and zeros mode's is not, zeros mode's texel (e.g. on the ring just
+// outside the map) — kNoTap when neither needs it; wb the border weight of what that load returns, ws the zeros weight.  Should both
+// modes ever need DIFFERENT texels for one tap, `second` is set and (oz, wn) describe the extra load of the slow path.
+struct LevelTaps { unsigned ob[4], oz[4]; float wb[4], ws[4], wn[4]; bool second; };
+__device__ __forceinline__ LevelTaps level_taps(const MergeArgs& a, int l, int jx, int jy, int m, int sub) {
+    LevelTaps T;
+    const float r2 = (float)(2 * a.r[l]);
+    const float ix = (float)(jx - a.pad + 1 - a.r[l]) / r2, iy = (float)(jy - a.pad + 1 - a.r[l]) / r2;
+    int tb[4], tz[4];
+    float wz[4];
+    car_bilinear_taps_px(ix, iy, a.w[l], a.h[l], 0, tb, T.wb);
+    car_bilinear_taps_px(ix, iy, a.w[l], a.h[l], 1, tz, wz);
+    const unsigned mbase = (unsigned)m * (unsigned)(a.h[l] * a.w[l]);
+    T.second = false;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (long)t4[t] * kC);
-            acc.x = fmaf(w4[t], v.x, acc.x); acc.y = fmaf(w4[t], v.y, acc.y); acc.z = fmaf(w4[t], v.z, acc.z); acc.w = fmaf(w4[t], v.w, acc.w);
+    for (int t = 0; t < 4; ++t) {
+        const bool on0 = T.wb[t] != 0.0f, on1 = wz[t] != 0.0f;
+        const bool borrow = on1 && !on0, second = on1 && on0 && tz[t] != tb[t];
+        T.ob[t] = (on0 || borrow) ? (mbase + (unsigned)(borrow ? tz[t] : tb[t])) * (unsigned)(kC * 4) + 16u * sub : kNoTap;
+        T.oz[t] = second ? (mbase + (unsigned)tz[t]) * (unsigned)(kC * 4) + 16u * sub : kNoTap;
+        T.ws[t] = (on1 && !second) ? wz[t] : 0.0f;
+        T.wn[t] = second ? wz[t] : 0.0f;
+        T.second = T.second || second;
+    }
+    return T;
+}
+__device__ __forceinline__ void merge_fma(float w, const mf32x4& v, mf32x2& lo, mf32x2& hi) {
+    const mf32x2 w2 = {w, w};
+    lo = __builtin_elementwise_fma(w2, mf32x2{v[0], v[1]}, lo);
+    hi = __builtin_elementwise_fma(w2, mf32x2{v[2], v[3]}, hi);
+}
+template <int NL>
+__global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a, unsigned* __restrict__ gmax) {
+    __shared__ float red[4];
+    const int sub = threadIdx.x & 15;
+    const long plane = (long)a.lh * a.lw;
+    __amdgpu_buffer_rsrc_t rs[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) rs[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[l]), 0, (int)a.bytes[l], 0x00027000);
+    float mx = 0.0f;
+    for (long node = (long)blockIdx.x * 16 + (threadIdx.x >> 4); node < a.nodes; node += (long)gridDim.x * 16) {
+        const int m = (int)(node / plane);
+        const int jy = (int)((node - m * plane) / a.lw), jx = (int)(node - m * plane - (long)jy * a.lw);
+        unsigned ob[NL][4];
+        float wb[NL][4], ws[NL][4];
+        bool second = false;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const LevelTaps T = level_taps(a, l, jx, jy, m, sub);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { ob[l][t] = T.ob[t]; wb[l][t] = T.wb[t]; ws[l][t] = T.ws[t]; }
+            second = second || T.second;
+        }
+        float* out0 = a.lat + (((long)m * 2 + 0) * plane + (long)jy * a.lw + jx) * kC + 4 * sub;
+        float* out1 = out0 + plane * kC;
+        const bool slow = __builtin_amdgcn_ballot_w64(second) != 0;   // wave-uniform
+#pragma unroll 1
+        for (int j = 0; j < kC / 64; ++j) {
+            mf32x2 a0l = {0.f, 0.f}, a0h = {0.f, 0.f}, a1l = {0.f, 0.f}, a1h = {0.f, 0.f};
+            if (!slow) {                                               // one load per live tap serves both modes; every level's in flight together
+                mf32x4 v[NL][4];
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[l][t] = __builtin_bit_cast(mf32x4, __builtin_amdgcn_raw_buffer_load_b128(rs[l], (int)ob[l][t], 256 * j, 0));
+#pragma unroll
+                for (int l = NL - 1; l >= 0; --l)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { merge_fma(wb[l][t], v[l][t], a0l, a0h); merge_fma(ws[l][t], v[l][t], a1l, a1h); }
+            } else {                                                   // never seen with the two padding rules of grid_sample; kept for safety
+#pragma unroll 1
+                for (int l = NL - 1; l >= 0; --l) {
+                    const LevelTaps T = level_taps(a, l, jx, jy, m, sub);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const mf32x4 v = __builtin_bit_cast(mf32x4, __builtin_amdgcn_raw_buffer_load_b128(rs[l], (int)T.ob[t], 256 * j, 0));
+                        const mf32x4 u = __builtin_bit_cast(mf32x4, __builtin_amdgcn_raw_buffer_load_b128(rs[l], (int)T.oz[t], 256 * j, 0));
+                        merge_fma(T.wb[t], v, a0l, a0h); merge_fma(T.ws[t], v, a1l, a1h); merge_fma(T.wn[t], u, a1l, a1h);
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(out0 + 64 * j) = make_float4(a0l[0], a0l[1], a0h[0], a0h[1]);
+            *reinterpret_cast<float4*>(out1 + 64 * j) = make_float4(a1l[0], a1l[1], a1h[0], a1h[1]);
+            mx = fmaxf(fmaxf(mx, fmaxf(fmaxf(fabsf(a0l[0]), fabsf(a0l[1])), fmaxf(fabsf(a0h[0]), fabsf(a0h[1])))),
+                       fmaxf(fmaxf(fabsf(a1l[0]), fabsf(a1l[1])), fmaxf(fabsf(a1h[0]), fabsf(a1h[1]))));
         }
     }
-    reinterpret_cast<float4*>(a.lat)[idx] = acc;
+    if (gmax) {
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(gmax, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    }
+}
+// grid-stride launch: every compute unit holds several workgroups, each walks the nodes 16 at a time
+inline unsigned merge_blocks(long nodes) {
+    const long want = (nodes + 15) / 16;
+    return (unsigned)(want < 2048 ? want : 2048);
+}
+// the merge over n_maps maps, in launches whose widest level stays below the 2 GiB a buffer load addresses
+int launch_merge(const float* const* levels, const int* hs, const int* ws, const int* rs, int n_levels, int lh, int lw, int pad, int n_maps,
+                 float* lattice, unsigned* gmax, hipStream_t st, const char* who) {
+    long widest = 0;
+    for (int l = 0; l < n_levels; ++l) widest = (long)hs[l] * ws[l] > widest ? (long)hs[l] * ws[l] : widest;
+    const long per = 0x7fffffffL / (widest * kC * 4);
+    CAR_REQUIRE(per >= 1, "%s: one map of the widest level exceeds 2 GiB", who);
+    (void)hipGetLastError();
+    for (int m0 = 0; m0 < n_maps; m0 += (int)per) {
+        const int nm = n_maps - m0 < per ? n_maps - m0 : (int)per;
+        MergeArgs a{};
+        for (int l = 0; l < n_levels; ++l) {
+            a.g[l] = levels[l] + (long)m0 * hs[l] * ws[l] * kC;
+            a.bytes[l] = (unsigned)((long)nm * hs[l] * ws[l] * kC * 4);
+            a.h[l] = hs[l]; a.w[l] = ws[l]; a.r[l] = rs[l];
+        }
+        a.n_levels = n_levels; a.lh = lh; a.lw = lw; a.pad = pad;
+        a.nodes = (long)nm * lh * lw;
+        a.lat = lattice + (long)m0 * 2 * lh * lw * kC;
+        void (*kern)(const MergeArgs, unsigned*) = n_levels == 1 ? merge_kernel<1> : n_levels == 2 ? merge_kernel<2> : n_levels == 3 ? merge_kernel<3> : merge_kernel<4>;
+        hipLaunchKernelGGL(kern, dim3(merge_blocks(a.nodes)), dim3(256), 0, st, a, gmax);
+    }
+    CAR_CHECK_LAUNCH(who);
+    return CAR_OK;
 }
 // Every level is summed on the lattice: it must be an integer factor r_l coarser than the widest level, the same factor in both
 // directions; lat = 2 W_max + 2 r_max + 1 nodes, pad = r_max + 1 (521 x 521 nodes, pad 5, for the 64 / 128 / 256 pyramid of a 256 x 256
@@ -243,8 +349,10 @@ int check_dims(const car_dims* d, const char* who) {
 
 // ---- workspace layout ----------------------------------------------------------------------------------------------
 struct Work {
-    size_t rays, phi_x, e, q, g, logit, logit2, pt, pixel_val, coords, at_wt, at_wt2, amax, depth, ebar, z1, uh, valid, total;                                        // offsets in floats
+    size_t rays, phi_x, e, q, g, logit, logit2, pt, pixel_val, coords, at_wt, at_wt2, amax, depth, ebar, z1, uh, valid, part, total;                                  // offsets in floats
 };
+// step groups per (view, ray) of the first round's partial sums (car_fused_samples_parts)
+inline size_t step_groups(const car_dims& d) { const int ts = car_fused_tile_steps(); return (size_t)((d.P + ts - 1) / ts); }
 Work work_layout(const car_dims& d) {
     Work w;
     size_t o = 0;
@@ -268,6 +376,7 @@ Work work_layout(const car_dims& d) {
     w.z1 = take(BR * kE);
     w.uh = take(BR * kD);
     w.valid = take(BR);
+    w.part = take(n * d.R * step_groups(d) * kC);
     w.total = o;
     return w;
 }
@@ -375,7 +484,7 @@ extern "C" int car_workspace_find(const car_dims* dims, const char* name, size_t
     const struct { const char* name; size_t off, cnt; } tab[] = {
         {"rays", w.rays, n * dims->R * CAR_RAY_FLOATS}, {"e", w.e, S * kC}, {"qry", w.q, S * kD}, {"g", w.g, S * CAR_G_DIM},
         {"logit", w.logit, S}, {"logit2", w.logit2, S}, {"pt", w.pt, S * 3}, {"at_wt2", w.at_wt2, S}, {"ebar", w.ebar, BR * kC},
-        {"z1", w.z1, BR * kE}, {"uh", w.uh, BR * kD}};
+        {"z1", w.z1, BR * kE}, {"uh", w.uh, BR * kD}, {"part", w.part, n * dims->R * step_groups(*dims) * kC}};
     for (const auto& t : tab)
         if (strcmp(t.name, name) == 0) { *offset_floats = t.off; *n_floats = t.cnt; return CAR_OK; }
     car_set_error("car_workspace_find: unknown tensor '%s'", name);
@@ -516,26 +625,18 @@ extern "C" int car_project_maps(const car_dims* dims, const void* plan, const fl
     float* gmeta = gmaps + car_gmeta_offset(dims);
     if (hipMemsetAsync(gmeta, 0, sizeof(float) * CAR_MAX_LEVELS, st) != hipSuccess) { car_set_error("car_project_maps: memset failed"); return CAR_E_LAUNCH; }
     const Lattice L = lattice_of(*dims);
-    MergeArgs a{};
-    int nm = 0;
+    const float* lv[CAR_MAX_LEVELS];
     for (int l = 0; l < dims->n_levels; ++l) {
         CAR_REQUIRE(maps[l], "car_project_maps: level %d is null", l);
         const long M = (long)dims->b * dims->V * dims->level_h[l] * dims->level_w[l];
         float* gl = gmaps + level_offset(*dims, l);
         CAR_TRY(car_linear(maps[l], dims->level_c[l], base + p.proj[l], dims->level_c[l], kC, gl, kC, M, 0, stream));
-        a.g[nm] = gl; a.h[nm] = dims->level_h[l]; a.w[nm] = dims->level_w[l]; a.r[nm] = L.r[l];
-        ++nm;
+        lv[l] = gl;
     }
-    a.n_levels = nm; a.lh = L.h; a.lw = L.w; a.pad = L.pad;
-    a.total = (long)lattice_floats(*dims) / 4;
-    a.lat = gmaps;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)car_div_up(a.total, 256)), dim3(256), 0, st, a);
-    CAR_CHECK_LAUNCH("car_project_maps (merge)");
-    // largest |lattice value|: bounds h (the fused kernel scales its fp16 operands by it)
-    hipLaunchKernelGGL(absmax_kernel, dim3(4096), dim3(256), 0, st, gmaps, a.total, reinterpret_cast<unsigned*>(gmeta));
-    CAR_CHECK_LAUNCH("car_project_maps (absmax)");
-    return CAR_OK;
+    // the lattice, and in the same pass its largest magnitude (gmeta[0], zeroed above): it bounds h (the fused kernel scales its fp16
+    // operands by it)
+    return launch_merge(lv, dims->level_h, dims->level_w, L.r, dims->n_levels, L.h, L.w, L.pad, dims->b * dims->V, gmaps,
+                        reinterpret_cast<unsigned*>(gmeta), st, "car_project_maps (merge)");
 }
 
 // The lattice alone, for hosts that project the levels themselves (engine.py: the three-view exchange, which has no plan): levels[l] =
@@ -553,18 +654,8 @@ extern "C" int car_merge_lattice(const float* const* levels, const int* level_h,
     if (lat_w) *lat_w = L.w;
     if (lat_pad) *lat_pad = L.pad;
     if (!lattice) return CAR_OK;
-    MergeArgs a{};
-    for (int l = 0; l < n_levels; ++l) {
-        CAR_REQUIRE(levels[l], "car_merge_lattice: level %d is null", l);
-        a.g[l] = levels[l]; a.h[l] = level_h[l]; a.w[l] = level_w[l]; a.r[l] = L.r[l];
-    }
-    a.n_levels = n_levels; a.lh = L.h; a.lw = L.w; a.pad = L.pad;
-    a.total = (long)n_maps * 2 * L.h * L.w * (kC / 4);
-    a.lat = lattice;
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(merge_kernel, dim3((unsigned)car_div_up(a.total, 256)), dim3(256), 0, (hipStream_t)stream, a);
-    CAR_CHECK_LAUNCH("car_merge_lattice");
-    return CAR_OK;
+    for (int l = 0; l < n_levels; ++l) CAR_REQUIRE(levels[l], "car_merge_lattice: level %d is null", l);
+    return launch_merge(levels, level_h, level_w, L.r, n_levels, L.h, L.w, L.pad, n_maps, lattice, nullptr, (hipStream_t)stream, "car_merge_lattice");
 }
 
 // the launches of one forward call in two phases: CAR_PHASE_SAMPLES = rays + the fused per-sample kernel (compute / power bound),
@@ -602,15 +693,17 @@ static int render_phases(const car_dims* dims, const void* plan, const car_input
     {   // a6-a13 + round-1 logits: the fused per-sample kernel
         Stage stage("fused_samples", st);
         const Lattice L = lattice_of(d);
-        CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->gmeta, pl + p.wpt, pl + p.blob,
-                                  pl + p.fbias, b, V, R, P, d.H, d.W, d.no_sample != 0, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
+        CAR_TRY(car_fused_samples_parts(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->gmeta, pl + p.wpt, pl + p.blob,
+                                        pl + p.fbias, b, V, R, P, d.H, d.W, d.no_sample != 0, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt,
+                                        pixel_val, ws + w.part, stream));
     }
     }
     if (!(phases & CAR_PHASE_RAYS)) return CAR_OK;
-    {   // a14 + a16: attention round 1, depth read-out, argmax
+    {   // a14 + a16: attention round 1, depth read-out, argmax.  The value average comes from the per-step-group partial sums the
+        // fused kernel left behind (an eighth of the rows of e), so e itself is streamed from HBM by the second round only
         Stage stage("attend_1", st);
-        CAR_TRY(car_attend(ws + w.logit, nullptr, kD, ws + w.e, kC, b, V, R, P, nullptr, 0.0f, at_wt, ws + w.ebar, kC, 1, ws + w.pt, in->poses,
-                           depth, amax, stream));
+        CAR_TRY(car_attend_parts(ws + w.logit, ws + w.part, car_fused_tile_steps(), kC, b, V, R, P, at_wt, ws + w.ebar, kC, 1, ws + w.pt, in->poses,
+                                 depth, amax, stream));
     }
     // weight-chunk tables of the two per-ray chains (car_raychain.hip): float offset inside the plan and tile count of every K = 32
     // chunk, in the order the kernels consume them

@@ -155,6 +155,15 @@ size_t car_fused_bias_floats(void);
 int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
                       int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P,
                       int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream);
+/* The same launch, which also leaves the FIRST attention round's value sum of every (view, ray, group of car_fused_tile_steps()
+ * consecutive steps) in `part` [b*V][R][ceil(P / tile_steps)][576]: sum_j exp(logit_j - m) e_j over the group's samples, m their largest
+ * logit — each workgroup reads the rows of e it has just written back from L2, an eighth of the bytes the attention launch would
+ * otherwise stream from HBM.  car_attend_parts (below) folds a ray's groups together; models.py:533-541. */
+int car_fused_tile_steps(void);
+int car_fused_samples_parts(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
+                            int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,
+                            int P, int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val,
+                            float* part, void* stream);
 
 /* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
  *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).
@@ -186,6 +195,12 @@ int car_linear_x3(const float* X, int ldx, const float* packed, const float* bia
 int car_attend(const float* qa, const float* qb, int dq, const float* val, int D, int b, int V, int R, int P,
                const float* zprev, float zprev_scale, float* w_out, float* z_out, int ld_z, int reps,
                const float* pt, const float* poses, float* depth, int32_t* w_argmax, void* stream);
+/* The same round from precomputed logits [b*V,R,P] and per-step-group partial value sums `part` [b*V][R][ceil(P / tile_steps)][D]
+ * (car_fused_samples_parts): z_out = sum_g exp(m_g - M) / L part_g, with m_g the group's largest logit, M the ray's, L the softmax
+ * denominator — the same sum as car_attend's over the sample rows; w_out, depth and w_argmax exactly as car_attend computes them. */
+int car_attend_parts(const float* logit, const float* part, int tile_steps, int D, int b, int V, int R, int P, float* w_out,
+                     float* z_out, int ld_z, int reps, const float* pt, const float* poses, float* depth, int32_t* w_argmax,
+                     void* stream);
 
 /* ---- a15, per-sample half in one kernel (models.py:549-555):
  *     logit[row] = < Wr2 relu(Wr1[:,128:] g[row] + br1 + uh[ray(row)]) + br2 , qry[row] > / 16

@@ -439,6 +439,62 @@ def test_fused_path_ragged_sizes_against_the_oracle(R, P, b):
 
 
 
+@pytest.mark.parametrize("R,P,b", [(37, 13, 1), (131, 70, 2), (96, 32, 1), (48, 5, 1)])
+def test_first_round_partial_sums_equal_the_row_reduction(R, P, b):
+    """car_fused_samples_parts leaves sum_j exp(logit_j - m_g) e_j per (view, ray, group of 8 steps); car_attend_parts folds the groups —
+    against car_attend over the rows of e of the SAME forward (the workspace still holds e, the logits and the partial sums): the
+    softmax weights, depth and argmax bit for bit (they are computed the same way), the value average to fp32 rounding.  Ragged ray and
+    step counts: tiles of 24 rays x 8 steps with clamped duplicates past the end, a last step group of 1-7 live steps."""
+    from cross_attention_renderer_amd import _lib as L, synthetic as S
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    dev = torch.device("cuda:0")
+    H = 64
+    torch.manual_seed(0)
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).eval()
+    S.perturb_parameters(m, seed=4)
+    m.H = m.W = H
+    inp = S.stereo_scene(H, b=b, uv=C.select_rays(H, R), seed=7, alpha=0.35)
+    z = S.feature_maps(b, 2, H, seed=2)
+    with torch.no_grad():
+        md = m.to(dev)
+        out = md(to_device(inp, dev, cameras_on_host=True), z=[t.to(dev) for t in z], debug=True)
+    torch.cuda.synchronize()
+    eng, lib = md._engine, _lib()
+    assert eng.last_calls == 1
+    d = eng._dims(b, R, [t.to(dev) for t in z])
+    V, n = 2, 2 * b
+
+    def ws(name):
+        off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+        L.check(lib.car_workspace_find(ctypes.byref(d), name.encode(), ctypes.byref(off), ctypes.byref(cnt)), "car_workspace_find")
+        return eng._work[off.value:off.value + cnt.value]
+    e, logit, part, pt = ws("e"), ws("logit"), ws("part"), ws("pt")
+    ts = lib.car_fused_tile_steps()
+    assert part.numel() == n * R * (-(-P // ts)) * 576
+    poses = out["stages"]["poses"].to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    res = []
+    for parts in (False, True):
+        w = torch.empty(n, R, P, device=dev)
+        zz = torch.full((b * R, 576), float("nan"), device=dev)
+        depth = torch.empty(b, R, device=dev)
+        amax = torch.empty(n, R, dtype=torch.int32, device=dev)
+        if parts:
+            L.check(lib.car_attend_parts(_ptr(logit), _ptr(part), ts, 576, b, V, R, P, _ptr(w), _ptr(zz), 576, 1, _ptr(pt), _ptr(poses),
+                                         _ptr(depth), _ptr(amax), st), "car_attend_parts")
+        else:
+            L.check(lib.car_attend(_ptr(logit), None, 128, _ptr(e), 576, b, V, R, P, None, 0.0, _ptr(w), _ptr(zz), 576, 1, _ptr(pt),
+                                   _ptr(poses), _ptr(depth), _ptr(amax), st), "car_attend")
+        torch.cuda.synchronize()
+        res.append((w, zz, depth, amax))
+    (w0, z0, d0, a0), (w1, z1, d1, a1) = res
+    assert torch.equal(w0, w1) and torch.equal(d0, d1) and torch.equal(a0, a1)
+    assert torch.equal(w1, out["at_wt"])
+    assert torch.isfinite(z1).all()
+    scale = z0.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    assert ((z0 - z1).abs() / scale).max().item() < 2e-6
+
+
 def test_one_call_c_abi_without_second_round():
     """repeat_attention=False (models.py:547) through car_render_forward and the oracle at real widths."""
     from cross_attention_renderer_amd import synthetic as S
@@ -668,6 +724,67 @@ def test_forward_on_device_made_poses(name):
         print(f"device poses vs reference fixture {name} {k}: beyond 1e-4: {e['f1e-4']:.4f}, worst {e['max']:.2e}")
         assert e["f1e-4"] <= DEVICE_POSE_FRAC and e["max"] <= DEVICE_POSE_MAX, f"device poses vs reference fixture {k}: {e}"
     assert (np.asarray(out["valid_mask"]) == fx["out_valid_mask"]).all()
+
+
+@pytest.mark.parametrize("sizes", [((8, 8), (16, 16), (32, 32)), ((6, 10), (24, 40)), ((16, 16),), ((4, 4), (8, 8), (16, 16), (32, 32))])
+def test_merged_lattice_kernel_matches_grid_sample(sizes):
+    """car_merge_lattice (csrc/car_render.hip merge_kernel: one 16-lane group per node writes both padding modes, zero-weight taps are
+    out-of-range buffer loads) against torch's grid_sample of every level at the lattice nodes, summed: border and zeros padding,
+    interior, ring and corner nodes, several maps."""
+    import torch.nn.functional as F
+    from cross_attention_renderer_amd import _lib as L
+    lib = _lib()
+    dev = torch.device("cuda:0")
+    n_maps, C = 3, 576
+    g = torch.Generator().manual_seed(5)
+    levels = [torch.randn(n_maps, h, w, C, generator=g).to(dev) for h, w in sizes]
+    nl = len(levels)
+    ptrs = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in levels])
+    hs = (ctypes.c_int * nl)(*[h for h, _ in sizes])
+    wsz = (ctypes.c_int * nl)(*[w for _, w in sizes])
+    lh, lw, pad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.car_merge_lattice(ptrs, hs, wsz, nl, n_maps, None, ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(pad), st), "shape")
+    lat = torch.full((n_maps, 2, lh.value, lw.value, C), float("nan"), device=dev)
+    L.check(lib.car_merge_lattice(ptrs, hs, wsz, nl, n_maps, _ptr(lat), None, None, None, st), "car_merge_lattice")
+    torch.cuda.synchronize()
+    hm, wm = max(h for h, _ in sizes), max(w for _, w in sizes)
+    uy = torch.arange(lh.value, device=dev, dtype=torch.float64) - pad.value
+    ux = torch.arange(lw.value, device=dev, dtype=torch.float64) - pad.value
+    gy, gx = torch.meshgrid((uy + 1) / hm - 1, (ux + 1) / wm - 1, indexing="ij")
+    grid = torch.stack([gx, gy], dim=-1)[None].expand(n_maps, -1, -1, -1)
+    for mode, name in enumerate(("border", "zeros")):
+        want = sum(F.grid_sample(t.permute(0, 3, 1, 2).double(), grid, mode="bilinear", padding_mode=name, align_corners=False) for t in levels)
+        got = lat[:, mode].permute(0, 3, 1, 2).double()
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max().item() < 2e-5, (name, (got - want).abs().max().item())
+
+
+def test_project_maps_records_the_lattice_maximum():
+    """car_project_maps takes the largest |lattice value| inside the merge kernel (it used to be a second pass over the 2.5 GB): gmeta[0]
+    must be exactly the maximum of the lattice it wrote."""
+    from cross_attention_renderer_amd import synthetic as S
+    from cross_attention_renderer_amd.engine import RenderEngine
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    dev = torch.device("cuda:0")
+    H = 64
+    torch.manual_seed(0)
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=16, with_encoder=False).eval().to(dev)
+    m.H = m.W = H
+    eng = RenderEngine(m)
+    lib = eng.lib
+    for b, seed in ((1, 1), (3, 2)):
+        z = [t.to(dev) for t in S.feature_maps(b, 2, H, seed=seed)]
+        d = eng._dims(b, 48, z)
+        plan = eng._plan_for(d, dev)
+        pair, dp = eng._pair_for(plan, z, dev, 0, b, 48)
+        torch.cuda.synchronize()
+        off = lib.car_gmeta_offset(ctypes.byref(dp))
+        lh, lw, lpad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert lib.car_lattice_shape(ctypes.byref(dp), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(lpad)) == 0
+        lattice = pair[:b * 2 * 2 * lh.value * lw.value * 576]
+        assert torch.isfinite(lattice).all()
+        assert pair[off].item() == lattice.abs().max().item() > 0
 
 
 def test_lattice_beyond_the_fused_kernels_range_takes_the_stage_route():
