@@ -652,60 +652,68 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         for (int r = 0; r < 4; ++r) dot = fmaf(key[t][r], qv[t][r], dot);
     dot += __shfl_xor(dot, 16, 64);
     dot += __shfl_xor(dot, 32, 64);
+    // ---- first attention round, this workgroup's share (models.py:533-541): for each of its rays the step group's
+    //      sum_j exp(logit_j - m) e_j with m = max_j logit_j over the group's kTileSteps samples, read back from the rows of e this
+    //      workgroup has written (L2) — 1/kTileSteps of the bytes the attention launch would otherwise stream from HBM; that launch
+    //      (car_attend_parts) folds the groups of a ray together with exp(m - M) / L.  A wave owns kTileRays / kWaves rays; a 16-lane
+    //      group reads a whole 2304-byte row as nine float4 per lane, the wave's four groups take four rows at a time.
+    //      Every wave's stores of e were drained (vmcnt 0) in front of a chunk barrier layers ago, so the logits' hand-over barrier is
+    //      all the ordering the read-back needs (no wait for the qry / logit stores issued just before it); the row loads of ALL the
+    //      wave's rays are in flight together.
+    constexpr int kRaysPerWave = kTileRays / kWaves, kRowIts = kTileSteps / 4;
+    static_assert(kTileRays % kWaves == 0 && kTileSteps % 4 == 0, "partial sums: whole rays per wave, four rows at a time");
+    f32x4 xr[kRaysPerWave][kRowIts][kC / 64];
+    float pw[kRaysPerWave][kRowIts];
+    const int sub = lane & 15, grp = lane >> 4;
     if (live) {
         store_rows<kTD>(qv, a.qry + i * kD, q4);
         if (q4 == 0) a.logit[i] = dot / 16.0f;
     }
-    mark(6);
-    // ---- first attention round, this workgroup's share (models.py:533-541): for each of its rays the step group's
-    //      sum_j exp(logit_j - m) e_j with m = max_j logit_j over the group's kTileSteps samples, read back from the rows of e this
-    //      workgroup has just written (L2) — 1/kTileSteps of the bytes the attention launch would otherwise stream from HBM; that launch
-    //      (car_attend_parts) folds the groups of a ray together with exp(m - M) / L.  A wave owns kTileRays / kWaves rays; a 16-lane
-    //      group reads a whole 2304-byte row as nine float4 per lane, the wave's four groups take four rows at a time.
     if (a.part) {
-        constexpr int kRaysPerWave = kTileRays / kWaves, kRowIts = kTileSteps / 4;
-        static_assert(kTileRays % kWaves == 0 && kTileSteps % 4 == 0, "partial sums: whole rays per wave, four rows at a time");
         float* lgt = lds + kLdsG;                                      // the wave's g rows are dead: row (wave, s) keeps its logit in float 0
         if (q4 == 0) lgt[(wave * kRows + s) * 16] = live ? dot / 16.0f : -INFINITY;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's e / qry rows have reached L2 (same XCD, write-through L1)
-        __syncthreads();
-        const int sub = lane & 15, grp = lane >> 4;
+        __syncthreads();                                               // the qry / logit stores above stay in flight across it
         auto lgt_of = [&](int rr, int k) -> float {                    // logit of the tile's (ray rr, step k): inverse of tile_ray / tile_step
             const int w_ = (rr / kWaveRays) * kStepWaves + k / kWaveSteps, s_ = (rr % kWaveRays) + kWaveRays * (k % kWaveSteps);
             return lgt[(w_ * kRows + s_) * 16];
         };
-#pragma unroll 1
+#pragma unroll
         for (int rw = 0; rw < kRaysPerWave; ++rw) {
             const int rr = wave * kRaysPerWave + rw, ray_g = bun * kTileRays + rr;
-            if (ray_g >= a.R) break;                                   // wave-uniform
+            const int ray_c = ray_g < a.R ? ray_g : a.R - 1;           // a ray past the end: loads a live ray's rows, stores nothing
             float mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < kTileSteps; ++k) mx = fmaxf(mx, lgt_of(rr, k));
-            f32x4 x[kRowIts][kC / 64];
-            float pw[kRowIts];
 #pragma unroll
             for (int it = 0; it < kRowIts; ++it) {
                 const int k = 4 * it + grp, pp_k = pg * kTileSteps + k;
-                pw[it] = expf(lgt_of(rr, k) - mx);                     // a step past P carries -inf: weight 0 (its row is a duplicate of step P - 1)
-                const f32x4* rowp = reinterpret_cast<const f32x4*>(a.e + (((long)nn * a.R + ray_g) * a.P + (pp_k < a.P ? pp_k : a.P - 1)) * kC + 4 * sub);
+                pw[rw][it] = expf(lgt_of(rr, k) - mx);                 // a step past P carries -inf: weight 0 (its row is a duplicate of step P - 1)
+                const f32x4* rowp = reinterpret_cast<const f32x4*>(a.e + (((long)nn * a.R + ray_c) * a.P + (pp_k < a.P ? pp_k : a.P - 1)) * kC + 4 * sub);
 #pragma unroll
-                for (int j = 0; j < kC / 64; ++j) x[it][j] = __builtin_nontemporal_load(rowp + 16 * j);    // read once, written by other waves: past L1
+                for (int j = 0; j < kC / 64; ++j) xr[rw][it][j] = __builtin_nontemporal_load(rowp + 16 * j);   // read once, written by other waves: past L1
             }
+        }
+    }
+    mark(6);
+    if (a.part) {
+#pragma unroll
+        for (int rw = 0; rw < kRaysPerWave; ++rw) {
+            const int ray_g = bun * kTileRays + wave * kRaysPerWave + rw;
             float* out = a.part + (((long)nn * a.R + ray_g) * pgs + pg) * kC + 4 * sub;
 #pragma unroll
             for (int j = 0; j < kC / 64; ++j) {
-                f32x4 acc = x[0][j] * pw[0];
+                f32x4 acc = xr[rw][0][j] * pw[rw][0];
 #pragma unroll
                 for (int it = 1; it < kRowIts; ++it) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[c] = fmaf(pw[it], x[it][j][c], acc[c]);
+                    for (int c = 0; c < 4; ++c) acc[c] = fmaf(pw[rw][it], xr[rw][it][j][c], acc[c]);
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     acc[c] += __shfl_xor(acc[c], 16, 64);
                     acc[c] += __shfl_xor(acc[c], 32, 64);
                 }
-                if (grp == 0) *reinterpret_cast<f32x4*>(out + 64 * j) = acc;
+                if (grp == 0 && ray_g < a.R) *reinterpret_cast<f32x4*>(out + 64 * j) = acc;
             }
         }
     }

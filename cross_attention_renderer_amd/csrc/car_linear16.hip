@@ -126,7 +126,8 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
         for (int qs = 0; qs < NT / 2; ++qs) {
             const float* w0 = wl + (2 * qs * 2) * 256;
             mfma_pair(acc[2 * qs], acc[2 * qs + 1], w0, w0 + 512, bhi, blo);
-            if (qs < pieces_of(NT)) stream_issue_piece(nx, qs, lane, wave);
+            // nothing follows the last chunk: re-copying it onto itself would write the buffer this iteration's MFMAs are reading
+            if (qs < pieces_of(NT) && c + 1 < a.chunks) stream_issue_piece(nx, qs, lane, wave);
             __builtin_amdgcn_sched_barrier(0);
         }
         // the next chunk may outgrow the row's power of two: move the row (accumulators and scale) to the smaller one, exactly
@@ -193,8 +194,19 @@ __global__ void pack16x3_kernel(const float* __restrict__ W, int ldw, int K, int
 template <int NT>
 int launch16(const LinArgs& a, int groups, hipStream_t st) {
     const size_t lds_bytes = (size_t)2 * NT * kTile * sizeof(float);
-    hipError_t e = hipFuncSetAttribute((const void*)linear16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) { car_set_error("car_linear_x3: cannot reserve LDS: %s", hipGetErrorString(e)); return CAR_E_LAUNCH; }
+    // the LDS reservation is a per-device attribute of the kernel: set it once per (instance, device), not on each of the dozens of
+    // launches of a staged forward or training step
+    static bool reserved[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !reserved[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)linear16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) {
+            car_set_error("car_linear_x3: cannot reserve %zu bytes of LDS (a gfx950-class device has 160 KB per compute unit): %s", lds_bytes, hipGetErrorString(e));
+            return CAR_E_LAUNCH;
+        }
+        if (dev >= 0 && dev < 64) reserved[dev] = true;
+    }
     (void)hipGetLastError();
     hipLaunchKernelGGL(linear16_kernel<NT>, dim3((unsigned)(car_div_up(a.M, kGroupRows) * groups)), dim3(kThreads), lds_bytes, st, a);
     CAR_CHECK_LAUNCH("car_linear_x3");

@@ -373,7 +373,8 @@ class RenderEngine:
         return lh.value * lw.value * 576 * 4 < 2**31
 
     def _free_budget(self, device) -> int:
-        """85 % of what this engine could allocate now: free device memory, the caching allocator's idle blocks, its own workspace."""
+        """85 % of what this engine could allocate now: free device memory, the caching allocator's idle blocks, and its own workspace
+        (which every caller either re-uses in place or releases before it allocates against this figure)."""
         free, _ = torch.cuda.mem_get_info(device)
         cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
         mine = self._work.numel() * 4 if self._work is not None else 0
@@ -406,7 +407,14 @@ class RenderEngine:
         whole_cached = self._pair is not None and self._pair_key == (self._maps_key, self._plan_key, 0, b)
         pg = b
         if not whole_cached:
-            usable = self._free_budget(dev) + (self._pair.numel() * 4 if self._pair is not None else 0)
+            # what is live while a group renders: ONE lattice buffer (the previous group's is dropped before the next is allocated, below)
+            # and the workspace.  The cached buffer and workspace of an earlier forward count as available because both are released
+            # before this forward allocates (a stale workspace sized for another split would otherwise sit beside the new pair)
+            self._pair = None
+            self._pair_key = None
+            if pair_bytes(b) > (self._free_budget(dev)) // 2:
+                self._work = None                                      # grouped fallback: start from everything this engine can free
+            usable = self._free_budget(dev)
             if self.max_pair_bytes is not None:
                 usable = min(usable, 2 * int(self.max_pair_bytes))
             while pg > 1 and pair_bytes(pg) > usable // 2:
@@ -426,8 +434,14 @@ class RenderEngine:
         calls = 0
         d_last = None
         self.last_pair_groups = -(-b // pg)
+        pair = work = None
         for p0 in range(0, b, pg):
             p1 = min(b, p0 + pg)
+            if pg < b:
+                # several lattice groups (memory pressure): the previous group's buffer must be gone before the next one is allocated —
+                # _pair_for drops the engine's reference, this drops the loop's — and the workspace is re-sized against what is then free
+                pair = work = None
+                self._work = None
             pair, d_pair = self._pair_for(plan, z, dev, p0, p1, R)
             gmeta_ptr = pair.data_ptr() + 4 * lib.car_gmeta_offset(ctypes.byref(d_pair))
             budget = self._workspace_budget(dev)
@@ -514,12 +528,19 @@ class RenderEngine:
 
     # ------------------------------------------------------------------ kernels
     def linear(self, x: Tensor, ldx: int, layer: PackedLinear, y: Tensor, ldy: int, M: int, flags: int = 0):
-        if (self.linear_x3 and layer.x3 is not None and ldx % 4 == 0 and ldy % 4 == 0 and x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0
-                and M >= self.linear_x3_min_rows):
+        # linear_flags (the NO_GLDS A/B knob of car_linear) selects the fp32-pipe kernel for every layer: the split-fp16 kernel has no such
+        # variant, and an A/B run must not change arithmetic on some layers only
+        if (self.linear_x3 and not self.linear_flags and layer.x3 is not None and ldx % 4 == 0 and ldy % 4 == 0 and x.data_ptr() % 16 == 0
+                and y.data_ptr() % 16 == 0 and M >= self.linear_x3_min_rows):
             tiles, bias = layer.x3
-            _lib.check(self.lib.car_linear_x3(_ptr(x), ldx, _ptr(tiles), _ptr(bias), layer.K, layer.N, _ptr(y), ldy, M, flags, _stream()),
-                       "car_linear_x3")
-            return
+            rc = self.lib.car_linear_x3(_ptr(x), ldx, _ptr(tiles), _ptr(bias), layer.K, layer.N, _ptr(y), ldy, M, flags, _stream())
+            if rc == 0:
+                return
+            # the split-fp16 kernel could not be launched on this device (its 72 KB weight double buffer needs a gfx950-class LDS): the
+            # same layer on the fp32 matrix pipe from here on — another HIP kernel of the same library, never a host path
+            import warnings
+            warnings.warn(f"car_linear_x3 unavailable ({self.lib.car_last_error().decode()}): wide layers stay on car_linear")
+            self.linear_x3 = False
         _lib.check(self.lib.car_linear(_ptr(x), ldx, _ptr(layer.packed), layer.K, layer.N, _ptr(y), ldy, M,
                                        flags | self.linear_flags, _stream()), "car_linear")
 

@@ -175,8 +175,11 @@ int car_linear(const float* X, int ldx, const float* packed, int K, int N, float
 
 /* The same layer on the f16 matrix pipe (csrc/car_linear16.hip), for the stage entries' wide layers: fp16 hi / lo halves of both
  * operands, three products per term, fp32 accumulation — the fused kernel's arithmetic (fp32-class accuracy; car_linear's fp32 pipe
- * peaks at 157 TFLOP/s, this path at 2500 / 3).  The weights carry a power of two chosen by car_linear_x3_pack, every row of X one chosen
- * from its largest magnitude (a first pass over the row).  Y[M, N] = act(act_in(X[M, K]) W^T + bias (+ Y)), flags as car_linear; bias: N
+ * peaks at 157 TFLOP/s, this path at 2500 / 3).  The weights carry a power of two chosen by car_linear_x3_pack; every row of X carries
+ * one that follows the largest magnitude seen SO FAR along the row (32 columns at a time, after act_in): when a later chunk outgrows it
+ * the row's accumulators are multiplied by the ratio of the two powers — exact — so X is read once; a row whose leading chunks are all
+ * zero starts from the clamp (the powers of two live in [2^-90, 2^43], so bias * 2^43 * 2^shift stays inside fp32) and is moved down
+ * by the first non-zero chunk.  Y[M, N] = act(act_in(X[M, K]) W^T + bias (+ Y)), flags as car_linear; bias: N
  * floats or NULL (not folded into the pack).  N % 32 == 0, ldx % 4 == 0 (and >= K rounded up to 4), ldy % 4 == 0, X / Y / bias 16-byte
  * aligned; car_linear serves every other shape. */
 size_t car_linear_x3_packed_floats(int K, int N);
