@@ -32,7 +32,8 @@ The JSON line also carries
   pair_setup_ms, lattice_bytes, workspace_bytes, eval_mode : what the restructured path costs outside the timed region — the
                   once-per-stereo-pair projection of the pyramid onto its lattice, the memory it and the per-call workspace hold, and
                   the frame rate when every frame brings a new pair (the eval loop, eval_realestate10k.py:142-161);
-  rank_share    : one 8192-ray call per step (a rank's share of the frame at 8 GPUs) and the scaling it projects;
+  rank_share    : one call of 1/G of the frame per step (a rank's share at G = 2, 4, 8 GPUs) and the scaling each projects;
+  power         : socket power, shader clock and joules per frame, sampled while the timed loop's steps run a second time;
   pose_route    : what handing the cameras over on the GPU costs per frame (the download + synchronisation of the host pose route);
   cpu_baseline  : the CPU oracle (a port of the reference forward, validated against it) on this host's cores over a bounded
                   sample of the same workload.
@@ -331,21 +332,43 @@ def main():
         stages = model._engine.stage_times()
         model._engine.profile(False)
 
-        ev_ms = share = pose = None
+        ev_ms = share = pose = power = None
         if extras:
+            # the same K steps once more under a socket-power / shader-clock sampler (tools/power_sampler.py: amdsmi, 5 ms period, and the
+            # device's energy accumulator): what the chip's power management delivers under THIS workload, measured beside the timed
+            # loop instead of quoted from an earlier profile.  Kept out of the timed region so the sampler thread cannot touch `value`.
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from power_sampler import PowerSampler
+                with PowerSampler(interval=0.005) as ps:
+                    e_pw = timed_loop(model, frames, z, tile, None, args.steps, args.chunk_rays, None)
+                power = ps.summary()
+                power["ms_per_step"] = e_pw / args.steps * 1e3
+                if power.get("available"):
+                    w_mean = power.get("energy_mean_w", power["mean_w"])
+                    power["joule_per_frame"] = w_mean * e_pw / args.steps
+                    power["nanojoule_per_sample"] = w_mean * e_pw / args.steps / (nb * V * R * Pc) * 1e9
+                    power["note"] = ("socket power and shader clock sampled while the timed loop's K steps ran a second time (whole frame: fused kernel "
+                                     "+ attention + per-ray chains); the fused kernel alone by component: profiles/round5_fused_energy.md")
+            except Exception as exc:                                  # measurement plumbing must never cost the line
+                power = {"available": False, "error": repr(exc)}
             ev_ms = eval_mode(model, frames, z, tile, max(3, min(args.steps, 8)))
             if nb == 1 and args.chunk_rays >= R:
-                # a rank's share of this frame at 8 GPUs: one call of R / 8 rays per step, every step a new pose — what bounds the scaling
+                # a rank's share of this frame at G GPUs: one call of R / G rays per step, every step a new pose — what bounds the scaling
                 # of the banded frame before the (overlapped) all-gather
-                k8, rs = max(10, 2 * args.steps), R_frame // 8
-                fr8 = trajectory(k8, dev, (3 * R_frame // 8, 3 * R_frame // 8 + rs), args.cameras == "host", Hc, nb)
-                t8 = torch.empty(nb, rs, 5, device=dev)
-                render_frame(model, fr8[0], z, t8, 1 << 30)
-                e8 = timed_loop(model, fr8, z, t8, None, k8, 1 << 30, None)
-                share = {"rays_per_step": rs, "steps": k8, "ms_per_step": e8 / k8 * 1e3,
-                         "projected_scaling_8": (elapsed / args.steps) / (e8 / k8),
-                         "note": "one forward call of an eighth of the frame per step on ONE GPU (a new pose every step): frame time / this = the "
-                                 "scaling 8 ranks reach if the tile all-gather hides under the next frame; a projection, not a measurement on 8 GPUs"}
+                share = {}
+                for G in (2, 4, 8):
+                    kG, rs = max(10, 2 * args.steps), R_frame // G
+                    g0 = (3 * G // 8) * rs                                    # a band from the middle of the frame (rank 3 of 8, 1 of 4, 0 of 2)
+                    frG = trajectory(kG, dev, (g0, g0 + rs), args.cameras == "host", Hc, nb)
+                    tG = torch.empty(nb, rs, 5, device=dev)
+                    render_frame(model, frG[0], z, tG, 1 << 30)
+                    eG = timed_loop(model, frG, z, tG, None, kG, 1 << 30, None)
+                    share[f"projected_scaling_{G}"] = (elapsed / args.steps) / (eG / kG)
+                    share[f"ms_per_step_{G}"] = eG / kG * 1e3
+                share.update({"rays_per_step": R_frame // 8, "steps": kG, "ms_per_step": share["ms_per_step_8"],
+                              "note": "one forward call of 1/G of the frame per step on ONE GPU (a new pose every step), G = 2, 4, 8: frame time / this = the "
+                                      "scaling G ranks reach if the tile all-gather hides under the next frame; a projection, not a measurement on G GPUs"})
             if args.cameras == "host" and nb == 1 and args.chunk_rays >= R:
                 # the same frames with the WHOLE dict on the GPU (the reference scripts' call): host pose route, one download + sync per pose
                 kp = max(4, min(args.steps, 10))
@@ -416,7 +439,8 @@ def main():
             if part != 1.0 and pmc.get("source"):
                 pmc["source"] += f", scaled by {part:g} to this launch's share of the frame"
             roof = {"bound": "mfma", "limiter": pmc.get("limiter"), "kernel": f"fused_kernel on {int(samples)} samples (geometry, 4-tap gather of the per-texel-projected pyramid on its lattice, e, key, qry, logits; "
-                                                                  "f16 matrix pipe, fp16 hi/lo split x3)",
+                                                                  "f16 matrix pipe, fp16 hi/lo split x3; since round 5 the launch also reduces the first attention "
+                                                                  "round's value sums per 8-step group from L2 — about 4 % of its time, no matrix work, not counted in the flops)",
                     "achieved": flop / mean / 1e12, "peak": F16_MFMA_PEAK / 3 / 1e12, "unit": "TFLOP/s", "frac": flop / mean / (F16_MFMA_PEAK / 3),
                     "peak_note": "dense f16 MFMA peak 2500 / 3 products per fp32 term.  What keeps the kernel from it (limiter): MFMAs and ordinary "
                                  "vector instructions share a SIMD's issue, the A operands wait on LDS, the tap loads stall in the texture "
@@ -430,7 +454,10 @@ def main():
                     "live_fields": ["achieved", "frac", "frac_of_fp32_pipe_peak", "launches", "ms_per_launch", "flop_per_launch"],
                     "static_fields": ["limiter", "ta_busy", "mfma_busy", "valu_share", "l1_bytes", "traffic", "per_unit_unthrottled_frac"],
                     "static": "profiles/traffic.json: rocprofv3 --pmc passes of an earlier run of this kernel at config c2 (separate passes, not collected here; null for the other configs)",
-                    "launches": len(lat), "ms_per_launch": mean * 1e3, "flop_per_launch": flop}
+                    "launches": len(lat), "ms_per_launch": mean * 1e3, "flop_per_launch": flop,
+                    # the chip under this frame's mix, sampled beside the timed loop (null where the box offers no power interface)
+                    "sclk_mhz_live": None if not power else power.get("mean_sclk_mhz"), "socket_w_live": None if not power else power.get("energy_mean_w", power.get("mean_w"))}
+            roof["live_fields"] += ["sclk_mhz_live", "socket_w_live"]
         fr = prof.get("frame")
         hbm = None
         if fr and args.chunk_rays >= R and world == 1 and args.config == "c2":
@@ -466,6 +493,7 @@ def main():
                 "note": "every frame brings a new stereo pair (eval_realestate10k.py:142-161): car_project_maps runs before every frame; "
                         "get_z excluded as in the headline figure"},
             "rank_share": share,
+            "power": power,
             "pose_route": pose,
             "frame_per_rank": None if per_rank is None else {
                 "value": world * rays_step * per_rank[0] / per_rank[1], "unit": "rays/s", "steps": per_rank[0],

@@ -148,6 +148,10 @@ def test_bench_prints_one_line_with_the_contract_fields():
     assert g["pairs"] >= 20 and g["warmup_pairs"] >= 30 and g["ms_min"] <= g["ms"] <= g["ms_max"] and g["frac_min"] <= g["frac"] <= g["frac_max"]
     assert abs(g["spread"] - (g["ms_max"] - g["ms_min"]) / g["ms"]) < 1e-9
     assert d["rank_share"]["rays_per_step"] == 8192 and 1.0 < d["rank_share"]["projected_scaling_8"] <= 8.5
+    assert 1.0 < d["rank_share"]["projected_scaling_2"] <= 2.2 and d["rank_share"]["projected_scaling_2"] < d["rank_share"]["projected_scaling_4"] <= 4.3
+    pw = d["power"]                                                    # sampled beside the timed loop; a box without a power interface says so
+    assert "available" in pw and (not pw["available"] or (pw["mean_w"] > 50 and pw["samples"] >= 5 and pw["joule_per_frame"] > 0))
+    assert ("sclk_mhz_live" in r) and ("socket_w_live" in r)
     assert d["pose_route"]["download_and_sync_ms"] > 0 and d["pose_route"]["cameras_on_gpu_ms_per_step"] > 0
 
 
