@@ -2,7 +2,7 @@
 product kernel (variant 0) and the timing-only ablation variants of the development build (tools/build_dev.py; results of
 variants > 0 are wrong by construction):
   1 no tap loads | 2 no gather work | 3 = 2 + no weight DMA / barriers | 5 the source passes without their matrix work | 4 phase stamps | 20 where a wave waits inside a chunk
-  11 no chunk barrier (racy) | 12 = 3 + no A-operand reads | 13 no A-operand reads | 100 the PRODUCT library's kernel, timed the same way
+  11 no chunk barrier (racy) | 12 = 3 + no A-operand reads | 13 no A-operand reads | 100 the PRODUCT library's kernel, timed the same way | 101 the product launch with the first round's partial sums (what the forward issues)
   200 the wave-specialised kernel under evaluation (tools/probes/car_fused_ws.hip, development build only), compared bit for bit with 100
 (earlier rounds' probes — masked lanes, tap orders, deep tap rings, the full-lattice timing probe — are recorded in profiles/)
 Usage (GPU box): python tools/bench_fused.py [variants...]"""
@@ -105,6 +105,7 @@ def main():
             eng._pair.zero_()
         torch.cuda.synchronize()
     prod = lib.car_fused_samples                        # variant 100: the product library's kernel, timed the same way
+    prod_parts = lib.car_fused_samples_parts            # variant 101: the same launch as the forward issues it (with the first round's partial sums)
     outs = {}
     # power / occupancy probe: CAR_CU_MASK=n runs the launches on a stream restricted to n compute units (every (256 / n)-th one),
     # CAR_R=rays shrinks the launch with it
@@ -135,7 +136,7 @@ def main():
                     gmeta, wpt.data_ptr(), blob.data_ptr(),
                     bias.data_ptr(), 1, 2, Rk, bench.P, bench.H, bench.H, 0, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
                     pixel_val.data_ptr(), st)
-            rc = fn_sliced(v - 1000, *args) if v >= 1000 else prod(*args) if v == 100 else fn_ws(*args) if v == 200 else fn_w8[v - 201](*args) if 201 <= v < 260 else fn_base(*args) if v == 300 else fn(v, *args)
+            rc = fn_sliced(v - 1000, *args) if v >= 1000 else prod(*args) if v == 100 else prod_parts(*args[:-1], ws("part"), args[-1]) if v == 101 else fn_ws(*args) if v == 200 else fn_w8[v - 201](*args) if 201 <= v < 260 else fn_base(*args) if v == 300 else fn(v, *args)
             b_.record(ext) if ext is not None else b_.record()
             assert rc == 0, dev_lib.car_last_error()
             lat.append((a, b_))
