@@ -296,10 +296,15 @@ def test_round2_logit_kernel_matches_stage_kernels(name):
 
 
 def test_register_staged_weights_agree_with_lds_dma():
-    """A/B of the two weight-staging variants of the MFMA kernel on a whole forward."""
-    _, _, _, a = run_case("t1_c1", fuse_samples=False)
-    _, _, _, b_ = run_case("t1_c1", linear_flags=8, fuse_samples=False)
+    """A/B of the two weight-staging variants of the fp32-pipe MFMA kernel (car_linear) on a whole forward: every layer on car_linear in
+    both runs (the NO_GLDS knob keeps the split-fp16 kernel out anyway: engine.linear)."""
+    fp32_pipe = lambda e: setattr(e, "linear_x3", False)
+    _, _, _, a = run_case("t1_c1", fuse_samples=False, engine_setup=fp32_pipe)
+    _, _, _, b_ = run_case("t1_c1", linear_flags=8, fuse_samples=False, engine_setup=fp32_pipe)
     assert rel_err(a["rgb"], b_["rgb"]) < 1e-6
+    # and the knob alone must select the same kernels
+    _, _, _, c_ = run_case("t1_c1", linear_flags=8, fuse_samples=False)
+    assert torch.equal(b_["rgb"], c_["rgb"])
 
 
 # ----------------------------------------------------------------------------------------------------------
