@@ -10,7 +10,7 @@
 namespace {
 
 constexpr int kMaxSamples = CAR_MAX_VIEWS * 256;
-constexpr int kMaxSeg = 9;                       // widest row of the streaming value reduction: 9 x 64 channels
+constexpr int kMaxSeg = 14;                      // widest row of the streaming value reduction: 14 x 64 channels (864 = three views' 288: 13.5)
 
 __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -99,11 +99,11 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
         else return row_of(i);
     };
     // 3. z = sum_s w_s val[s] (+ scale * zprev), replicated `reps` times
-    if (D % 64 == 0 && D <= 64 * kMaxSeg) {
-        // Streaming form for wide rows: a 16-lane group reads a whole row as D/64 float4 loads (16 B per lane, the row's D*4
-        // bytes contiguous), the 16 groups of the workgroup take samples s = 16 it + group; every load instruction moves
-        // 1 KB and 4 iterations (4 x D/64 float4 per lane) are in flight.  Partial sums meet in LDS.
-        const int nseg = D / 64;
+    if (D % 4 == 0 && D >= 64 && D <= 64 * kMaxSeg) {
+        // Streaming form for wide rows: a 16-lane group reads a whole row as ceil(D/64) float4 loads (16 B per lane, the row's D*4
+        // bytes contiguous; the lanes past the end of a last, partial segment sit out), the 16 groups of the workgroup take samples
+        // s = 16 it + group; every load instruction moves up to 1 KB and 4 iterations are in flight.  Partial sums meet in LDS.
+        const int nseg = (D + 63) / 64;
         float4 part[kMaxSeg];
 #pragma unroll
         for (int j = 0; j < kMaxSeg; ++j) part[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
             const float* rowp = val + vrow_of(on ? sidx : NV - 1) * D + 4 * sub;
 #pragma unroll
             for (int j = 0; j < kMaxSeg; ++j) {
-                if (j < nseg) {
+                if (j < nseg && 64 * j + 4 * sub < D) {
                     // streamed once per round (19 GB per frame): non-temporal, so the rows do not displace what the next kernel reads
                     typedef float f32x4 __attribute__((ext_vector_type(4)));
                     const f32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rowp + 64 * j));

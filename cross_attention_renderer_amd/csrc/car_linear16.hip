@@ -9,6 +9,7 @@
 // A workgroup = 12 waves x 16 rows; a wave keeps NT tiles of 16 outputs (NT = 18: 288 columns, 72 accumulator registers; wider layers
 // run as column groups); the weight chunks (K = 32 x the group's columns) stream L2 -> LDS by LDS-DMA, double buffered.
 #include "car_common.h"
+#include "car_geom.h"
 
 namespace {
 
@@ -32,11 +33,16 @@ struct LinArgs {
     float* Y; int ldy;
     long M;
     int flags;
+    // GATHER (car_lattice_encode_linear): the rows of X are not read, they are MADE — row i = relu(four taps of the merged lattice of map
+    // (row_src[i] & 0x3fffffff), padding mode (row_src[i] >> 30) & 1, at row_grid[i] + the point term of row_pe[i]): car_encode.hip's
+    // encode_kernel, one 32-channel chunk at a time, straight into the B operands
+    const float* lattice; int lh, lw, lpad; float sx, sy;
+    const int* row_src; const float* row_grid; const float* row_pe; const float* wpt;
 };
 
-template <int NT>
+template <int NT, bool GATHER = false>
 __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][NT][512]
+    extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][NT][512] (+ GATHER: the [K][4] point / bias table)
     static_assert(kWaves * pieces_of(NT) <= 3 * 2 * NT, "stream_issue_piece wraps a piece index into the chunk with two subtractions");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,27 +69,75 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
 #pragma unroll
         for (int p = 0; p < pieces_of(NT); ++p) stream_issue_piece(n0, p, lane, wave);
     }
-    // this lane's eight values of chunk c: k = 32 c + 8 q4 .. + 7.  issue_x only issues the two loads (from a clamped, valid address);
+    // GATHER: the row's four lattice taps (north-west node, + one node, + one row, + both: car_lattice_taps never returns a node of the
+    // last column / row), its tap weights and point coordinates stay in registers for the whole kernel; the point / bias table goes to LDS
+    constexpr int kRaw = GATHER ? 8 : 2;
+    const float* tap[4] = {nullptr, nullptr, nullptr, nullptr};
+    float tw[4] = {0.f, 0.f, 0.f, 0.f}, pe[3] = {0.f, 0.f, 0.f};
+    const float* wtab = lds + 2 * NT * kTile;
+    if constexpr (GATHER) {
+        for (int k = tid; k < K; k += kThreads)
+            *reinterpret_cast<float4*>(lds + 2 * NT * kTile + 4 * k) = *reinterpret_cast<const float4*>(a.wpt + 4 * k);
+        const int src = a.row_src[lrow];
+        const int m = src & 0x3fffffff, mode = (src >> 30) & 1;
+        int node, flg;
+        car_lattice_taps(a.row_grid[2 * lrow], a.row_grid[2 * lrow + 1], a.lw, a.lh, a.lpad, a.sx, a.sy, &node, &flg, tw);
+        const bool dead = mode == 1 && (flg & 4);                      // zeros padding, on or beyond the outer ring: exactly zero
+        if (dead) { node = 0; tw[0] = tw[1] = tw[2] = tw[3] = 0.0f; }
+        const float* nw = a.lattice + ((long)(dead ? 0 : (m * 2 + mode)) * a.lh * a.lw + node) * K + 8 * q4;
+        tap[0] = nw; tap[1] = nw + K; tap[2] = nw + (long)a.lw * K; tap[3] = nw + (long)a.lw * K + K;
+        pe[0] = a.row_pe[4 * lrow]; pe[1] = a.row_pe[4 * lrow + 1]; pe[2] = a.row_pe[4 * lrow + 2];
+    }
+    // this lane's eight values of chunk c: k = 32 c + 8 q4 .. + 7.  issue_x only issues the loads (from clamped, valid addresses);
     // finish_x turns them into values (zeros beyond K, relu where the layer asks for it) when they are consumed — touching the loaded
     // registers at the load would put the memory latency in front of the chunk's MFMAs
-    auto issue_x = [&](int c, float4 (&raw)[2]) {
-        const int k0 = 32 * c + 8 * q4;
+    auto issue_x = [&](int c, float4 (&raw)[kRaw]) {
+        if constexpr (GATHER) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int kq = k0 + 4 * h;
-            raw[h] = *reinterpret_cast<const float4*>(xrow + (kq < K ? kq : 0));
+            for (int t = 0; t < 4; ++t) {
+                raw[2 * t] = *reinterpret_cast<const float4*>(tap[t] + 32 * c);
+                raw[2 * t + 1] = *reinterpret_cast<const float4*>(tap[t] + 32 * c + 4);
+            }
+        } else {
+            const int k0 = 32 * c + 8 * q4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kq = k0 + 4 * h;
+                raw[h] = *reinterpret_cast<const float4*>(xrow + (kq < K ? kq : 0));
+            }
         }
     };
-    auto finish_x = [&](int c, const float4 (&raw)[2], float (&x)[8]) {
+    auto finish_x = [&](int c, const float4 (&raw)[kRaw], float (&x)[8]) {
         const int k0 = 32 * c + 8 * q4;
+        if constexpr (GATHER) {
+            // encode_kernel's arithmetic, operation for operation (csrc/car_encode.hip): the four taps in the order nw, ne, sw, se, one fmaf
+            // each from zero; then + (fmaf(wz, pz, fmaf(wy, py, wx * px)) + b); relu
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int kq = k0 + 4 * h;
-            const float e[4] = {raw[h].x, raw[h].y, raw[h].z, raw[h].w};
+            for (int h = 0; h < 2; ++h) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float t = kq + i < K ? e[i] : 0.0f;
-                x[4 * h + i] = relu_in ? fmaxf(t, 0.0f) : t;
+                for (int t = 0; t < 4; ++t) {
+                    const float4 g = raw[2 * t + h];
+                    acc[0] = fmaf(tw[t], g.x, acc[0]); acc[1] = fmaf(tw[t], g.y, acc[1]);
+                    acc[2] = fmaf(tw[t], g.z, acc[2]); acc[3] = fmaf(tw[t], g.w, acc[3]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 wq = *reinterpret_cast<const float4*>(wtab + 4 * (k0 + 4 * h + i));     // (wx, wy, wz, b) of the channel
+                    const float pt = fmaf(wq.z, pe[2], fmaf(wq.y, pe[1], wq.x * pe[0])) + wq.w;
+                    x[4 * h + i] = fmaxf(acc[i] + pt, 0.0f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kq = k0 + 4 * h;
+                const float e[4] = {raw[h].x, raw[h].y, raw[h].z, raw[h].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = kq + i < K ? e[i] : 0.0f;
+                    x[4 * h + i] = relu_in ? fmaxf(t, 0.0f) : t;
+                }
             }
         }
     };
@@ -98,8 +152,9 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
     const float dW = a.down[0];
     float xc[8];
     {
-        float4 raw[2];
+        float4 raw[kRaw];
         issue_x(0, raw);
+        if constexpr (GATHER) __syncthreads();                         // the point / bias table is in LDS
         finish_x(0, raw, xc);
     }
     float mrun = fmaxf(row_max(xc), 1e-30f), p, pinv;
@@ -120,7 +175,7 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
         const float* wl = lds + (c & 1) * NT * kTile + 4 * lane;
         const NextChunk nx = chunk_desc(c + 1);
         const int cn = c + 1 < a.chunks ? c + 1 : c;
-        float4 rawn[2];
+        float4 rawn[kRaw];
         issue_x(cn, rawn);                                             // next chunk's rows: in flight under this chunk's MFMAs
 #pragma unroll
         for (int qs = 0; qs < NT / 2; ++qs) {
@@ -191,16 +246,16 @@ __global__ void pack16x3_kernel(const float* __restrict__ W, int ldw, int K, int
     }
 }
 
-template <int NT>
+template <int NT, bool GATHER = false>
 int launch16(const LinArgs& a, int groups, hipStream_t st) {
-    const size_t lds_bytes = (size_t)2 * NT * kTile * sizeof(float);
+    const size_t lds_bytes = (size_t)2 * NT * kTile * sizeof(float) + (GATHER ? (size_t)a.K * 4 * sizeof(float) : 0);
     // the LDS reservation is a per-device attribute of the kernel: set it once per (instance, device), not on each of the dozens of
     // launches of a staged forward or training step
     static bool reserved[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !reserved[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)linear16_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)linear16_kernel<NT, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) {
             car_set_error("car_linear_x3: cannot reserve %zu bytes of LDS (a gfx950-class device has 160 KB per compute unit): %s", lds_bytes, hipGetErrorString(e));
             return CAR_E_LAUNCH;
@@ -208,7 +263,7 @@ int launch16(const LinArgs& a, int groups, hipStream_t st) {
         if (dev >= 0 && dev < 64) reserved[dev] = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(linear16_kernel<NT>, dim3((unsigned)(car_div_up(a.M, kGroupRows) * groups)), dim3(kThreads), lds_bytes, st, a);
+    hipLaunchKernelGGL((linear16_kernel<NT, GATHER>), dim3((unsigned)(car_div_up(a.M, kGroupRows) * groups)), dim3(kThreads), lds_bytes, st, a);
     CAR_CHECK_LAUNCH("car_linear_x3");
     return CAR_OK;
 }
@@ -245,4 +300,33 @@ extern "C" int car_linear_x3(const float* X, int ldx, const float* packed, const
     if (tiles % 8 == 0) return launch16<8>(a, tiles / 8, st);
     if (tiles % 4 == 0) return launch16<4>(a, tiles / 4, st);
     return launch16<2>(a, tiles / 2, st);
+}
+
+// car_lattice_encode_rows followed by car_linear_x3 in ONE kernel (the three-view exchange, models.py:345-475 — engine._encode_three_views):
+// Y[rows, N] = act(relu(rows of the merged lattice + point term) W^T + bias).  The K = 576-wide first-layer rows are never written: every
+// 32-channel chunk is gathered into the lanes' B operands (the same arithmetic, operation for operation, as the two kernels it replaces).
+extern "C" int car_lattice_encode_linear(const float* lattice, int lat_h, int lat_w, int lat_pad, const int* row_src, const float* row_grid,
+                                         const float* row_pe, const float* wpt, int n_maps, long rows, const float* packed, const float* bias,
+                                         int K, int N, float* Y, int ldy, int flags, void* stream) {
+    CAR_REQUIRE(lattice && row_src && row_grid && row_pe && wpt && packed && Y, "car_lattice_encode_linear: null pointer");
+    CAR_REQUIRE(K == 576 && N % 32 == 0 && N > 0 && n_maps > 0 && rows > 0, "car_lattice_encode_linear: K must be 576 and N a multiple of 32 (got %d, %d)", K, N);
+    CAR_REQUIRE(lat_pad >= 2 && lat_h > 2 * lat_pad + 1 && lat_w > 2 * lat_pad + 1 && ((lat_h - 2 * lat_pad) & 1) && ((lat_w - 2 * lat_pad) & 1),
+                "car_lattice_encode_linear: bad lattice %d x %d, pad %d (car_merge_lattice)", lat_h, lat_w, lat_pad);
+    CAR_REQUIRE((long)n_maps * 2 * lat_h * lat_w < 2147483647L, "car_lattice_encode_linear: too many lattice nodes");
+    CAR_REQUIRE(ldy % 4 == 0 && ldy >= N && ((uintptr_t)Y & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) && ((uintptr_t)lattice & 15) == 0 && ((uintptr_t)wpt & 15) == 0,
+                "car_lattice_encode_linear: ldy = %d must be a multiple of 4 that holds a row; Y, bias, lattice and wpt 16-byte aligned", ldy);
+    CAR_REQUIRE(!(flags & CAR_LIN_RELU_IN), "car_lattice_encode_linear: the gathered rows are already rectified");
+    const int tiles = N / 16, ksteps = (K + 31) / 32;
+    LinArgs a{};
+    a.X = nullptr; a.ldx = 0; a.Wp = packed; a.tiles_total = tiles; a.bias = bias;
+    a.down = packed + (size_t)ksteps * tiles * kTile + 1;
+    a.K = K; a.chunks = ksteps; a.Y = Y; a.ldy = ldy; a.M = rows; a.flags = flags;
+    a.lattice = lattice; a.lh = lat_h; a.lw = lat_w; a.lpad = lat_pad;
+    a.sx = (float)((lat_w - 2 * lat_pad + 1) / 2); a.sy = (float)((lat_h - 2 * lat_pad + 1) / 2);
+    a.row_src = row_src; a.row_grid = row_grid; a.row_pe = row_pe; a.wpt = wpt;
+    hipStream_t st = (hipStream_t)stream;
+    if (tiles % 18 == 0) return launch16<18, true>(a, tiles / 18, st);
+    if (tiles % 8 == 0) return launch16<8, true>(a, tiles / 8, st);
+    if (tiles % 4 == 0) return launch16<4, true>(a, tiles / 4, st);
+    return launch16<2, true>(a, tiles / 2, st);
 }

@@ -182,7 +182,7 @@ __device__ __forceinline__ void merge_fma(float w, const mf32x4& v, mf32x2& lo, 
     hi = __builtin_elementwise_fma(w2, mf32x2{v[2], v[3]}, hi);
 }
 template <int NL>
-__global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a, unsigned* __restrict__ gmax) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) merge_kernel(const MergeArgs a, unsigned* __restrict__ gmax) {
     __shared__ float red[4];
     const int sub = threadIdx.x & 15;
     const long plane = (long)a.lh * a.lw;
@@ -206,7 +206,9 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a, unsigned*
         float* out0 = a.lat + (((long)m * 2 + 0) * plane + (long)jy * a.lw + jx) * kC + 4 * sub;
         float* out1 = out0 + plane * kC;
         const bool slow = __builtin_amdgcn_ballot_w64(second) != 0;   // wave-uniform
-#pragma unroll 1
+        // three channel steps per trip: a trip's loads (up to 36 per lane) are in flight together — with one step per trip the kernel
+        // spent its time waiting for nine dependent round trips per node
+#pragma unroll 3
         for (int j = 0; j < kC / 64; ++j) {
             mf32x2 a0l = {0.f, 0.f}, a0h = {0.f, 0.f}, a1l = {0.f, 0.f}, a1h = {0.f, 0.f};
             if (!slow) {                                               // one load per live tap serves both modes; every level's in flight together
@@ -244,10 +246,17 @@ __global__ void __launch_bounds__(256) merge_kernel(const MergeArgs a, unsigned*
         if (threadIdx.x == 0) atomicMax(gmax, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
     }
 }
-// grid-stride launch: every compute unit holds several workgroups, each walks the nodes 16 at a time
+// grid-stride launch: as many workgroups as the chip holds at once (three 4-wave workgroups per compute unit at this kernel's 168 registers: a grid
+// that needs a partial second helping of workgroups per compute unit ends on a half-empty chip), each walks the nodes 16 at a time
 inline unsigned merge_blocks(long nodes) {
-    const long want = (nodes + 15) / 16;
-    return (unsigned)(want < 2048 ? want : 2048);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    const long want = (nodes + 15) / 16, cap = 3L * cus;
+    return (unsigned)(want < cap ? want : cap);
 }
 // the merge over n_maps maps, in launches whose widest level stays below the 2 GiB a buffer load addresses
 int launch_merge(const float* const* levels, const int* hs, const int* ws, const int* rs, int n_levels, int lh, int lw, int pad, int n_maps,

@@ -97,6 +97,7 @@ class RenderEngine:
         # stage-by-stage pipeline of this module (A/B and stage tests)
         self.fuse_samples = True
         self.fuse_round2 = True        # staged route: round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
+        self.fuse_exchange = True      # three-view exchange: first + second layer in one kernel (car_lattice_encode_linear); False = two launches (A/B)
         # sizing of the one-call route (tests shrink them to force several calls)
         self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
         self.max_level_bytes: Optional[int] = None         # tests: lattice bytes of one call (forces scene groups); None = no limit
@@ -740,12 +741,24 @@ class RenderEngine:
                     rgrid[:, c, :, k] = grid
                     rpe[:, c, :, k, :3] = pe[:, o, :, c, :3]
                     k += 1
-            h1 = torch.empty(S * 3, C, **f32)
             L = len(gmaps)
             ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in gmaps])
             hs = (ctypes.c_int * L)(*[g.shape[1] for g in gmaps])
             ws = (ctypes.c_int * L)(*[g.shape[2] for g in gmaps])
             lat = self._exchange_lattice(gmaps, ptrs, hs, ws, n, C, dev)
+            layer2 = pk["query_encode_latent_2"]
+            if lat is not None and self.fuse_exchange and self.linear_x3 and not self.linear_flags and layer2.x3 is not None:
+                # first AND second exchange layer in one kernel: the lattice rows are gathered 32 channels at a time into the matrix pipe's
+                # operands, the 576-wide rows (2.3 KB x 3 S) are never written (csrc/car_linear16.hip, GATHER instance; bit-identical
+                # to the two launches below)
+                lattice, lh, lw, lpad = lat
+                tiles, bias2 = layer2.x3
+                enc = torch.empty(S * 3, C // 2, **f32)
+                _lib.check(self.lib.car_lattice_encode_linear(_ptr(lattice), lh, lw, lpad, _ptr(src), _ptr(rgrid), _ptr(rpe), _ptr(wpt), n, S * 3,
+                                                              _ptr(tiles), _ptr(bias2), C, C // 2, _ptr(enc), C // 2, 0, _stream()),
+                           "car_lattice_encode_linear")
+                return enc.view(S, 3 * (C // 2))
+            h1 = torch.empty(S * 3, C, **f32)
             if lat is not None:                                     # four taps of the merged lattice per row instead of twelve
                 lattice, lh, lw, lpad = lat
                 _lib.check(self.lib.car_lattice_encode_rows(_ptr(lattice), lh, lw, lpad, C, _ptr(src), _ptr(rgrid), _ptr(rpe), _ptr(wpt), n, S * 3,

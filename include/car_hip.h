@@ -130,6 +130,14 @@ int car_merge_lattice(const float* const* levels, const int* level_h, const int*
                       int* lat_h, int* lat_w, int* lat_pad, void* stream);
 int car_lattice_encode_rows(const float* lattice, int lat_h, int lat_w, int lat_pad, int Cg, const int* row_src, const float* row_grid,
                             const float* row_pe, const float* wpt, int n_maps, long rows, float* out, int ld_out, void* stream);
+/* car_lattice_encode_rows followed by car_linear_x3 (below) in ONE kernel, for the three-view exchange's second layer (models.py:333-341 on
+ * the rows of 345-475): Y[rows, N] = act(relu(lattice rows + point term) W^T + bias) — the 576-wide first-layer rows are gathered 32
+ * channels at a time straight into the matrix pipe's operands and never written (2.3 KB per row saved twice).  Same arithmetic, operation
+ * for operation, as the two entries it replaces (outputs bit-identical).  packed / bias / flags as car_linear_x3 (K = 576, N % 32 == 0);
+ * row_src / row_grid / row_pe / wpt as car_lattice_encode_rows. */
+int car_lattice_encode_linear(const float* lattice, int lat_h, int lat_w, int lat_pad, const int* row_src, const float* row_grid,
+                              const float* row_pe, const float* wpt, int n_maps, long rows, const float* packed, const float* bias,
+                              int K, int N, float* Y, int ldy, int flags, void* stream);
 
 /* ---- a6-a13 + logits of a14 in ONE kernel for the default configuration (V = 2, C = 576, hidden 128): geometry, the
  * per-texel-projected encode (car_gather_encode's arithmetic, with ALL pyramid levels summed once per stereo pair on their common

@@ -226,6 +226,45 @@ def case_tail_kernels(R, P, b, tail):
                                "car_round2_logits"), t, ["logit2"], tail)
 
 
+def case_exchange(rows, N, tail=True):
+    """car_lattice_encode_linear: lattice, row lists, point table, packed layer, bias, output."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(rows + N)
+    n_maps, C = 2, 576
+    sizes = ((8, 8), (16, 16), (32, 32))
+    levels = [torch.randn(n_maps, h, w, C, generator=g).to(dev) for h, w in sizes]
+    ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in levels])
+    hs = (ctypes.c_int * 3)(*[h for h, _ in sizes])
+    wsz = (ctypes.c_int * 3)(*[w for _, w in sizes])
+    lh, lw, pad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    L.check(lib.car_merge_lattice(ptrs, hs, wsz, 3, n_maps, None, ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(pad), stream()), "shape")
+    lat = torch.empty(n_maps * 2 * lh.value * lw.value * C, device=dev)
+    L.check(lib.car_merge_lattice(ptrs, hs, wsz, 3, n_maps, ctypes.c_void_p(lat.data_ptr()), None, None, None, stream()), "car_merge_lattice")
+    src = (torch.randint(0, n_maps, (rows,), generator=g) | (torch.randint(0, 2, (rows,), generator=g) << 30)).to(torch.int32)
+    src[-1] = (n_maps - 1) | (1 << 30)                              # the last row reads the last map's zeros lattice ...
+    grid = torch.rand(rows, 2, generator=g) * 2.8 - 1.4
+    grid[-1] = torch.tensor([0.999, 0.999])                         # ... next to its far corner
+    W = (torch.randn(N, C, generator=g) / C ** 0.5).to(dev)
+    tiles = torch.empty(lib.car_linear_x3_packed_floats(C, N), device=dev)
+    L.check(lib.car_linear_x3_pack(ctypes.c_void_p(W.data_ptr()), C, C, N, ctypes.c_void_p(tiles.data_ptr()), stream()), "pack")
+    torch.cuda.synchronize()
+    t = {"lat": lat, "src": src.to(dev), "grid": grid.to(dev), "pe": torch.tanh(torch.randn(rows, 4, generator=g)).to(dev),
+         "wpt": (torch.randn(C, 4, generator=g) * 0.1).to(dev), "tiles": tiles, "bias": torch.randn(N, generator=g).to(dev), "Y": torch.zeros(rows, N, device=dev)}
+    run_both(lambda p: L.check(lib.car_lattice_encode_linear(p("lat"), lh.value, lw.value, pad.value, p("src"), p("grid"), p("pe"), p("wpt"), n_maps, rows,
+                                                             p("tiles"), p("bias"), C, N, p("Y"), N, 0, stream()), "car_lattice_encode_linear"), t, ["Y"], tail)
+
+
+def case_attend(R, P, V, D, tail=True):
+    """car_attend on rows of D floats (864 = three views: the streaming reduction's last segment is half a wave wide)."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(R + P + D)
+    S = V * R * P
+    t = {"qa": torch.randn(S, 128, generator=g).to(dev), "qb": torch.randn(S, 128, generator=g).to(dev), "val": torch.randn(S, D, generator=g).to(dev),
+         "w": torch.zeros(S, device=dev), "z": torch.zeros(R, D, device=dev)}
+    run_both(lambda p: L.check(lib.car_attend(p("qa"), p("qb"), 128, p("val"), D, 1, V, R, P, None, 0.0, p("w"), p("z"), D, 1, None, None, None, None, stream()),
+                               "car_attend"), t, ["w", "z"], tail)
+
+
 CASES = {
     "x3_nt18": lambda tail: case_linear_x3(200, 576, 576, 2, tail),
     "x3_nt18_k579": lambda tail: case_linear_x3(4097, 579, 288, 0, tail),
@@ -245,6 +284,10 @@ CASES = {
     "fused_48_8_b2": lambda tail: case_fused(48, 8, 2, tail),
     "tail_37_13": lambda tail: case_tail_kernels(37, 13, 1, tail),
     "tail_96_32_b2": lambda tail: case_tail_kernels(96, 32, 2, tail),
+    "exchange_288": lambda tail: case_exchange(1000, 288, tail),
+    "exchange_ragged": lambda tail: case_exchange(193, 128, tail),
+    "attend_864": lambda tail: case_attend(37, 13, 3, 864, tail),
+    "attend_100": lambda tail: case_attend(20, 8, 2, 100, tail),
 }
 # families of cases (tools/oob_selfcheck.sh runs one family per process)
 FAMILIES = {
@@ -252,7 +295,8 @@ FAMILIES = {
     "linear": ["lin_579_576", "lin_16_128", "lin_128_3", "lin_7_5", "lin_glds_off"],
     "gather": ["gather_wave", "gather_quad", "gather_zeros"],
     "fused": ["fused_37_13", "fused_48_8_b2"],
-    "tail": ["tail_37_13", "tail_96_32_b2"],
+    "tail": ["tail_37_13", "tail_96_32_b2", "attend_864", "attend_100"],
+    "exchange": ["exchange_288", "exchange_ragged"],
 }
 
 if __name__ == "__main__":

@@ -765,6 +765,60 @@ def test_merged_lattice_kernel_matches_grid_sample(sizes):
         assert (got - want).abs().max().item() < 2e-5, (name, (got - want).abs().max().item())
 
 
+@pytest.mark.parametrize("rows,N", [(1000, 288), (4097, 288), (193, 128), (64, 32)])
+def test_fused_exchange_layers_equal_the_two_launches(rows, N):
+    """car_lattice_encode_linear (the gather-fed instance of csrc/car_linear16.hip) against car_lattice_encode_rows followed by car_linear_x3
+    on the same rows: bit-identical — border and zeros rows, points on / beyond the lattice's outer ring, several maps, ragged row counts."""
+    from cross_attention_renderer_amd import _lib as L
+    lib = _lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows + N)
+    n_maps, C = 3, 576
+    sizes = ((8, 8), (16, 16), (32, 32))
+    levels = [torch.randn(n_maps, h, w, C, generator=g).to(dev) for h, w in sizes]
+    ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in levels])
+    hs = (ctypes.c_int * 3)(*[h for h, _ in sizes])
+    wsz = (ctypes.c_int * 3)(*[w for _, w in sizes])
+    lh, lw, pad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.car_merge_lattice(ptrs, hs, wsz, 3, n_maps, None, ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(pad), st), "shape")
+    lat = torch.empty(n_maps, 2, lh.value, lw.value, C, device=dev)
+    L.check(lib.car_merge_lattice(ptrs, hs, wsz, 3, n_maps, _ptr(lat), None, None, None, st), "car_merge_lattice")
+    src = (torch.randint(0, n_maps, (rows,), generator=g) | (torch.randint(0, 2, (rows,), generator=g) << 30)).to(torch.int32).to(dev)
+    grid = (torch.rand(rows, 2, generator=g) * 2.8 - 1.4)
+    grid[0] = torch.tensor([1e10, -1e10]); grid[1] = torch.tensor([-1.0, 1.0]); grid[2] = torch.tensor([1.0, 1.0]); grid[3] = torch.tensor([float("nan"), 0.0])
+    grid = grid.to(dev)
+    pe = torch.tanh(torch.randn(rows, 4, generator=g)).to(dev)
+    wpt = (torch.randn(C, 4, generator=g) * 0.1).to(dev)
+    W = (torch.randn(N, C, generator=g) / C ** 0.5).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    tiles = torch.empty(lib.car_linear_x3_packed_floats(C, N), device=dev)
+    L.check(lib.car_linear_x3_pack(_ptr(W), C, C, N, _ptr(tiles), st), "pack")
+    h1 = torch.empty(rows, C, device=dev)
+    L.check(lib.car_lattice_encode_rows(_ptr(lat), lh.value, lw.value, pad.value, C, _ptr(src), _ptr(grid), _ptr(pe), _ptr(wpt), n_maps, rows, _ptr(h1), C, st),
+            "car_lattice_encode_rows")
+    for flags in (0, 2):
+        want = torch.empty(rows, N, device=dev)
+        L.check(lib.car_linear_x3(_ptr(h1), C, _ptr(tiles), _ptr(bias), C, N, _ptr(want), N, rows, flags, st), "car_linear_x3")
+        got = torch.full((rows, N), float("nan"), device=dev)
+        L.check(lib.car_lattice_encode_linear(_ptr(lat), lh.value, lw.value, pad.value, _ptr(src), _ptr(grid), _ptr(pe), _ptr(wpt), n_maps, rows, _ptr(tiles),
+                                              _ptr(bias), C, N, _ptr(got), N, flags, st), "car_lattice_encode_linear")
+        torch.cuda.synchronize()
+        assert torch.isfinite(want).all()
+        assert torch.equal(got, want), (flags, (got - want).abs().max().item())
+
+
+def test_three_view_route_with_fused_exchange_equals_two_launches():
+    """The n_view = 3 forward with the exchange's two layers fused (default) against the two-launch form: every output bit-identical."""
+    outs = []
+    for fuse in (True, False):
+        _, _, ora, out = run_case("t1_nview3", fuse_samples=False, engine_setup=lambda e, f=fuse: setattr(e, "fuse_exchange", f))
+        outs.append(out)
+    for k in ("rgb", "depth_ray", "at_wt", "valid_mask"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    _check_outputs(outs[0], lambda k: ora[k], "fused exchange vs oracle")
+
+
 def test_project_maps_records_the_lattice_maximum():
     """car_project_maps takes the largest |lattice value| inside the merge kernel (it used to be a second pass over the 2.5 GB): gmeta[0]
     must be exactly the maximum of the lattice it wrote."""

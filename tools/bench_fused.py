@@ -3,7 +3,6 @@ product kernel (variant 0) and the timing-only ablation variants of the developm
 variants > 0 are wrong by construction):
   1 no tap loads | 2 no gather work | 3 = 2 + no weight DMA / barriers | 5 the source passes without their matrix work | 4 phase stamps | 20 where a wave waits inside a chunk
   11 no chunk barrier (racy) | 12 = 3 + no A-operand reads | 13 no A-operand reads | 100 the PRODUCT library's kernel, timed the same way | 101 the product launch with the first round's partial sums (what the forward issues)
-  200 the wave-specialised kernel under evaluation (tools/probes/car_fused_ws.hip, development build only), compared bit for bit with 100
 (earlier rounds' probes — masked lanes, tap orders, deep tap rings, the full-lattice timing probe — are recorded in profiles/)
 Usage (GPU box): python tools/bench_fused.py [variants...]"""
 import ctypes
@@ -31,18 +30,6 @@ def main():
     fn_sliced = dev_lib.car_fused_samples_sliced         # variant 1000 + n: the launch cut into kernel launches of n sample groups each
     fn_sliced.restype = ctypes.c_int
     fn_sliced.argtypes = [ctypes.c_int] + _lib.SIGNATURES["car_fused_samples"][1]
-    fn_ws = getattr(dev_lib, "car_fused_samples_ws", None)
-    if fn_ws is not None:
-        fn_ws.restype = ctypes.c_int
-        fn_ws.argtypes = _lib.SIGNATURES["car_fused_samples"][1]
-    fn_w8 = {}                                           # variants 201..: compile-time variants of the 8-wave candidate (tools/build_w8.py)
-    for v_ in range(0, 40):
-        pth = os.path.join(ROOT, "tools", "_dev", f"libw8_{v_}.so")
-        if os.path.exists(pth):
-            f_ = ctypes.CDLL(pth).car_fused_samples_ws
-            f_.restype = ctypes.c_int
-            f_.argtypes = _lib.SIGNATURES["car_fused_samples"][1]
-            fn_w8[v_] = f_
     base_path = os.path.join(ROOT, "tools", "_dev", "libcar_base.so")          # variant 300: a saved earlier build of the product library
     fn_base = None
     if os.path.exists(base_path):
@@ -136,7 +123,7 @@ def main():
                     gmeta, wpt.data_ptr(), blob.data_ptr(),
                     bias.data_ptr(), 1, 2, Rk, bench.P, bench.H, bench.H, 0, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
                     pixel_val.data_ptr(), st)
-            rc = fn_sliced(v - 1000, *args) if v >= 1000 else prod(*args) if v == 100 else prod_parts(*args[:-1], ws("part"), args[-1]) if v == 101 else fn_ws(*args) if v == 200 else fn_w8[v - 201](*args) if 201 <= v < 260 else fn_base(*args) if v == 300 else fn(v, *args)
+            rc = fn_sliced(v - 1000, *args) if v >= 1000 else prod(*args) if v == 100 else prod_parts(*args[:-1], ws("part"), args[-1]) if v == 101 else fn_base(*args) if v == 300 else fn(v, *args)
             b_.record(ext) if ext is not None else b_.record()
             assert rc == 0, dev_lib.car_last_error()
             lat.append((a, b_))
@@ -203,25 +190,7 @@ def main():
             print(f"source passes, per wave and chunk (mean over {w8.shape[0]} waves, {n:.0f} chunks each; s_memtime ticks): "
                   f"9 x (A-operand reads + 6 MFMAs issued) {m(7):.0f}, DMA pieces {m(5):.0f}, affine {m(6):.0f}, blends incl. the wait for their taps {m(0):.0f}, "
                   f"h rows stored + tap loads issued {m(4):.0f}, chunk-end wait for the weight DMA {m(1):.0f}, barrier {m(2):.0f}")
-        if v == 210:                                       # 8-wave candidate with shader-clock sums per section of its chunk loop
-            nw = (2 * R * bench.P // 256) * 8
-            w10 = pixel_val.view(torch.int64)[: nw * 10].view(-1, 10).cpu().double()
-            n = w10[:, 7].mean().item()
-            m = lambda k: w10[:, k].mean().item() / n
-            print(f"8-wave candidate, per wave and chunk (mean over {w10.shape[0]} waves, {n:.0f} chunks; s_memtime ticks): 9 x (A reads + 12 MFMAs) {m(0):.0f}, DMA pieces {m(1):.0f}, "
-                  f"4 x gather_row (waits for its taps) {m(2):.0f}, 4 x tap issue {m(3):.0f}, B operands read + split {m(4):.0f}, vmcnt {m(5):.0f}, barrier {m(6):.0f}; "
-                  f"source passes {w10[:, 8].mean().item():.0f}, from there to the end {w10[:, 9].mean().item() - w10[:, 8].mean().item():.0f}")
-        if v == 200 and "CAR_WS_STAMP" in os.environ:      # development build with -DCAR_WS_STAMP: per-wave tick sums of the source passes
-            w4 = pixel_val.view(torch.int64)[: (2 * R * bench.P // 192) * 16 * 8].view(-1, 16, 8).cpu().double()
-            mw, gw_ = w4[:, :12, :3].mean(dim=(0, 1)) / 36, w4[:, 12:, :3].mean(dim=(0, 1)) / 36
-            phm = w4[:, :12, 3:].mean(dim=(0, 1))
-            print("   matrix wave phases (ticks): tables + geometry %.0f, source passes %.0f, key layer 1 (both halves) %.0f, rest %.0f, total %.0f" % (
-                phm[1] - phm[0], phm[2] - phm[1], phm[3] - phm[2], phm[4] - phm[3], phm[4] - phm[0]))
-            gx = w4[:, 12:, :].mean(dim=(0, 1)) / 36
-            print(f"   gather wave per period: finish (wait taps, blend, split, write) {gx[2]:.0f}, issue of 4 x 6 tap loads {gx[5]:.0f}")
-            print(f"   matrix wave per chunk: MFMA groups + DMA issue {mw[0]:.0f}, wait for own DMA {mw[2]:.0f}, barrier {mw[1]:.0f};  "
-                  f"gather wave per period: 6 row groups {gw_[0]:.0f}, barrier {gw_[1]:.0f}  (s_memtime ticks)")
-        if v in (0, 100, 200, 300) or v >= 1000 or 60 <= v <= 69 or 201 <= v < 260:    # keep the results: the development kernels must equal the product's bit for bit
+        if v in (0, 100, 101, 300) or v >= 1000 or 60 <= v <= 69:    # keep the results: the development kernels must equal the product's bit for bit
             outs[v] = [torch.empty(cnt_, device=dev).copy_(eng._work[o_:o_ + cnt_]) for o_, cnt_ in
                        [(lambda n_: (lib.car_workspace_find(ctypes.byref(d), n_.encode(), ctypes.byref(off), ctypes.byref(cnt)), (off.value, cnt.value))[1])(n_)
                         for n_ in ("e", "qry", "logit", "pt", "g")]]

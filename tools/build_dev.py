@@ -29,15 +29,6 @@ def build_dev() -> str:
             subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCAR_ABLATION", *extra, "-c", src, "-o", obj,
                                    "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS[unit]])
         objs.append(obj)
-    for unit in (os.environ.get("CAR_DEV_UNIT", "car_fused_v2.hip"),):                          # development-only units (kernels under evaluation): tools/probes/
-        src = os.path.join(ROOT, "tools", "probes", unit)
-        if not os.path.exists(src):
-            continue
-        obj = os.path.join(DEV_DIR, unit.replace(".hip", "_dev.o"))
-        if ge._stale(obj, [src] + headers) or not fresh:
-            subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra, "-c", src, "-o", obj,
-                                   "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS["car_fused.hip"]])
-        objs.append(obj)
     open(stamp, "w").write(" ".join(extra))
     if ge._stale(DEV_LIB, objs):
         subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", DEV_LIB, *objs])
