@@ -144,6 +144,8 @@ struct MergeArgs {
     int h[CAR_MAX_LEVELS], w[CAR_MAX_LEVELS], r[CAR_MAX_LEVELS];
     int n_levels, lh, lw, pad;
     long nodes;                       // maps of the launch * lh * lw
+    long per;                         // consecutive nodes per workgroup
+    int ny;                           // lattice rows a workgroup's nodes can span (its y-axis table)
     float* lat;                       // [maps][2][lh][lw][kC] of the launch's first map
 };
 typedef float mf32x4 __attribute__((ext_vector_type(4)));
@@ -154,15 +156,34 @@ constexpr unsigned kNoTap = 0xc0000000u;          // beyond any sliced level: th
 // outside the map) — kNoTap when neither needs it; wb the border weight of what that load returns, ws the zeros weight.  Should both
 // modes ever need DIFFERENT texels for one tap, `second` is set and (oz, wn) describe the extra load of the slow path.
 struct LevelTaps { unsigned ob[4], oz[4]; float wb[4], ws[4], wn[4]; bool second; };
-__device__ __forceinline__ LevelTaps level_taps(const MergeArgs& a, int l, int jx, int jy, int m, int sub) {
+// One axis of car_bilinear_taps_px (car_geom.h): the two clamped texel indices of texel coordinate i and their weights, a weight forced to
+// zero where its texel lies outside the level.  The 2-D weights are the products of the two axes' — the products car_bilinear_taps_px forms,
+// zero exactly where it masks — so a node's taps come from one entry per axis, level and padding mode: 2 (lw + rows) entries per level
+// instead of a page of arithmetic per node.
+struct AxisTap { int c0, c1; float w0, w1; };
+__device__ __forceinline__ AxisTap axis_tap(float i, int W, int mode) {
+    if (mode == 0) i = fminf(fmaxf(i, 0.0f), (float)(W - 1));
+    if (!(i > -4.0f)) i = -4.0f;
+    if (i > (float)W + 4.0f) i = (float)W + 4.0f;
+    const float f0 = floorf(i), f1 = f0 + 1.0f;
+    const int x0 = (int)f0, x1 = x0 + 1;
+    AxisTap t;
+    t.w0 = (x0 >= 0 && x0 < W) ? f1 - i : 0.0f;
+    t.w1 = (x1 >= 0 && x1 < W) ? i - f0 : 0.0f;
+    t.c0 = x0 < 0 ? 0 : (x0 >= W ? W - 1 : x0);
+    t.c1 = x1 < 0 ? 0 : (x1 >= W ? W - 1 : x1);
+    return t;
+}
+__device__ __forceinline__ float lattice_to_texel(int j, int pad, int r) { return (float)(j - pad + 1 - r) / (float)(2 * r); }
+__device__ __forceinline__ float4 axis_entry(const AxisTap& t) { return make_float4(__int_as_float(t.c0), __int_as_float(t.c1), t.w0, t.w1); }
+__device__ __forceinline__ AxisTap axis_of(const float4& e) { return AxisTap{__float_as_int(e.x), __float_as_int(e.y), e.z, e.w}; }
+// the level's four taps of both padding modes (xb / yb: border, xz / yz: zeros) -> what the node's loads and sums need
+__device__ __forceinline__ LevelTaps level_taps(const AxisTap& xb, const AxisTap& yb, const AxisTap& xz, const AxisTap& yz, int W, unsigned mbase, int sub) {
     LevelTaps T;
-    const float r2 = (float)(2 * a.r[l]);
-    const float ix = (float)(jx - a.pad + 1 - a.r[l]) / r2, iy = (float)(jy - a.pad + 1 - a.r[l]) / r2;
-    int tb[4], tz[4];
-    float wz[4];
-    car_bilinear_taps_px(ix, iy, a.w[l], a.h[l], 0, tb, T.wb);
-    car_bilinear_taps_px(ix, iy, a.w[l], a.h[l], 1, tz, wz);
-    const unsigned mbase = (unsigned)m * (unsigned)(a.h[l] * a.w[l]);
+    const int tb[4] = {yb.c0 * W + xb.c0, yb.c0 * W + xb.c1, yb.c1 * W + xb.c0, yb.c1 * W + xb.c1};
+    const int tz[4] = {yz.c0 * W + xz.c0, yz.c0 * W + xz.c1, yz.c1 * W + xz.c0, yz.c1 * W + xz.c1};
+    const float wz[4] = {xz.w0 * yz.w0, xz.w1 * yz.w0, xz.w0 * yz.w1, xz.w1 * yz.w1};
+    T.wb[0] = xb.w0 * yb.w0; T.wb[1] = xb.w1 * yb.w0; T.wb[2] = xb.w0 * yb.w1; T.wb[3] = xb.w1 * yb.w1;
     T.second = false;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -181,24 +202,55 @@ __device__ __forceinline__ void merge_fma(float w, const mf32x4& v, mf32x2& lo, 
     lo = __builtin_elementwise_fma(w2, mf32x2{v[0], v[1]}, lo);
     hi = __builtin_elementwise_fma(w2, mf32x2{v[2], v[3]}, hi);
 }
-template <int NL>
+// TAB: a workgroup owns `per` consecutive nodes (a few lattice rows) and keeps the axis entries of its columns and rows in LDS;
+// otherwise (lattices too wide for that) the nodes are dealt out 16 at a time and every node works its entries out itself.
+template <int NL, bool TAB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) merge_kernel(const MergeArgs a, unsigned* __restrict__ gmax) {
     __shared__ float red[4];
+    extern __shared__ __attribute__((aligned(16))) float4 tab[];       // TAB: x axis [NL][2 modes][lw], then y axis [NL][2][a.ny]
     const int sub = threadIdx.x & 15;
     const long plane = (long)a.lh * a.lw;
     __amdgpu_buffer_rsrc_t rs[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) rs[l] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[l]), 0, (int)a.bytes[l], 0x00027000);
+    const long first = TAB ? (long)blockIdx.x * a.per : (long)blockIdx.x * 16;
+    const long last = TAB ? (first + a.per < a.nodes ? first + a.per : a.nodes) : a.nodes;
+    const long stride = TAB ? 16 : (long)gridDim.x * 16;
+    const long row0 = first / a.lw;                                   // first lattice row (counted through the maps) of this workgroup
+    float4* ytab = tab + NL * 2 * a.lw;
+    if constexpr (TAB) {
+        for (int i = threadIdx.x; i < NL * 2 * a.lw; i += 256) {
+            const int l = i / (2 * a.lw), md = (i / a.lw) & 1, jx = i % a.lw;
+            tab[i] = axis_entry(axis_tap(lattice_to_texel(jx, a.pad, a.r[l]), a.w[l], md));
+        }
+        for (int i = threadIdx.x; i < NL * 2 * a.ny; i += 256) {
+            const int l = i / (2 * a.ny), md = (i / a.ny) & 1, jy = (int)((row0 + i % a.ny) % a.lh);
+            ytab[i] = axis_entry(axis_tap(lattice_to_texel(jy, a.pad, a.r[l]), a.h[l], md));
+        }
+        __syncthreads();
+    }
     float mx = 0.0f;
-    for (long node = (long)blockIdx.x * 16 + (threadIdx.x >> 4); node < a.nodes; node += (long)gridDim.x * 16) {
-        const int m = (int)(node / plane);
-        const int jy = (int)((node - m * plane) / a.lw), jx = (int)(node - m * plane - (long)jy * a.lw);
+    for (long node = first + (threadIdx.x >> 4); node < last; node += stride) {
+        const long row = node / a.lw;
+        const int m = (int)(row / a.lh);
+        const int jy = (int)(row - (long)m * a.lh), jx = (int)(node - row * a.lw);
+        auto taps_of = [&](int l) {
+            const unsigned mbase = (unsigned)m * (unsigned)(a.h[l] * a.w[l]);
+            if constexpr (TAB) {
+                const int ry = (int)(row - row0);
+                return level_taps(axis_of(tab[(l * 2 + 0) * a.lw + jx]), axis_of(ytab[(l * 2 + 0) * a.ny + ry]), axis_of(tab[(l * 2 + 1) * a.lw + jx]),
+                                  axis_of(ytab[(l * 2 + 1) * a.ny + ry]), a.w[l], mbase, sub);
+            } else {
+                const float ix = lattice_to_texel(jx, a.pad, a.r[l]), iy = lattice_to_texel(jy, a.pad, a.r[l]);
+                return level_taps(axis_tap(ix, a.w[l], 0), axis_tap(iy, a.h[l], 0), axis_tap(ix, a.w[l], 1), axis_tap(iy, a.h[l], 1), a.w[l], mbase, sub);
+            }
+        };
         unsigned ob[NL][4];
         float wb[NL][4], ws[NL][4];
         bool second = false;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            const LevelTaps T = level_taps(a, l, jx, jy, m, sub);
+            const LevelTaps T = taps_of(l);
 #pragma unroll
             for (int t = 0; t < 4; ++t) { ob[l][t] = T.ob[t]; wb[l][t] = T.wb[t]; ws[l][t] = T.ws[t]; }
             second = second || T.second;
@@ -206,8 +258,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         float* out0 = a.lat + (((long)m * 2 + 0) * plane + (long)jy * a.lw + jx) * kC + 4 * sub;
         float* out1 = out0 + plane * kC;
         const bool slow = __builtin_amdgcn_ballot_w64(second) != 0;   // wave-uniform
-        // three channel steps per trip: a trip's loads (up to 36 per lane) are in flight together — with one step per trip the kernel
-        // spent its time waiting for nine dependent round trips per node
+        // three channel steps per trip: a trip's loads (up to 36 per lane) are in flight together
 #pragma unroll 3
         for (int j = 0; j < kC / 64; ++j) {
             mf32x2 a0l = {0.f, 0.f}, a0h = {0.f, 0.f}, a1l = {0.f, 0.f}, a1h = {0.f, 0.f};
@@ -224,7 +275,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             } else {                                                   // never seen with the two padding rules of grid_sample; kept for safety
 #pragma unroll 1
                 for (int l = NL - 1; l >= 0; --l) {
-                    const LevelTaps T = level_taps(a, l, jx, jy, m, sub);
+                    const LevelTaps T = taps_of(l);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const mf32x4 v = __builtin_bit_cast(mf32x4, __builtin_amdgcn_raw_buffer_load_b128(rs[l], (int)T.ob[t], 256 * j, 0));
@@ -246,17 +297,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         if (threadIdx.x == 0) atomicMax(gmax, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
     }
 }
-// grid-stride launch: as many workgroups as the chip holds at once (three 4-wave workgroups per compute unit at this kernel's 168 registers: a grid
-// that needs a partial second helping of workgroups per compute unit ends on a half-empty chip), each walks the nodes 16 at a time
-inline unsigned merge_blocks(long nodes) {
+// as many workgroups as the chip holds at once (three 4-wave workgroups per compute unit at this kernel's 168 registers: a grid that
+// needs a partial second helping of workgroups per compute unit ends on a half-empty chip)
+inline long merge_resident_blocks() {
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
         hipDeviceProp_t p;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
     }
-    const long want = (nodes + 15) / 16, cap = 3L * cus;
-    return (unsigned)(want < cap ? want : cap);
+    return 3L * cus;
 }
 // the merge over n_maps maps, in launches whose widest level stays below the 2 GiB a buffer load addresses
 int launch_merge(const float* const* levels, const int* hs, const int* ws, const int* rs, int n_levels, int lh, int lw, int pad, int n_maps,
@@ -277,8 +327,24 @@ int launch_merge(const float* const* levels, const int* hs, const int* ws, const
         a.n_levels = n_levels; a.lh = lh; a.lw = lw; a.pad = pad;
         a.nodes = (long)nm * lh * lw;
         a.lat = lattice + (long)m0 * 2 * lh * lw * kC;
-        void (*kern)(const MergeArgs, unsigned*) = n_levels == 1 ? merge_kernel<1> : n_levels == 2 ? merge_kernel<2> : n_levels == 3 ? merge_kernel<3> : merge_kernel<4>;
-        hipLaunchKernelGGL(kern, dim3(merge_blocks(a.nodes)), dim3(256), 0, st, a, gmax);
+        // consecutive nodes per workgroup (a multiple of the 16 a workgroup takes per step), the rows they span, the tables' LDS
+        const long groups = (a.nodes + 15) / 16, resident = merge_resident_blocks();
+        long blocks = groups < resident ? groups : resident;
+        a.per = ((a.nodes + blocks - 1) / blocks + 15) / 16 * 16;
+        blocks = (a.nodes + a.per - 1) / a.per;
+        a.ny = (int)(a.per / lw) + 2;
+        const size_t tab_bytes = (size_t)n_levels * 2 * (lw + a.ny) * sizeof(float4);
+        const bool tables = tab_bytes <= 52 * 1024;                   // three workgroups per compute unit keep theirs in the 160 KB
+#define CAR_MERGE_KERNEL(T) (n_levels == 1 ? merge_kernel<1, T> : n_levels == 2 ? merge_kernel<2, T> : n_levels == 3 ? merge_kernel<3, T> : merge_kernel<4, T>)
+        void (*kern)(const MergeArgs, unsigned*) = tables ? CAR_MERGE_KERNEL(true) : CAR_MERGE_KERNEL(false);
+#undef CAR_MERGE_KERNEL
+        if (tables) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab_bytes) != hipSuccess) {
+                car_set_error("%s: cannot reserve %zu bytes of LDS", who, tab_bytes);
+                return CAR_E_LAUNCH;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), tables ? tab_bytes : 0, st, a, gmax);
     }
     CAR_CHECK_LAUNCH(who);
     return CAR_OK;
@@ -308,9 +374,11 @@ struct Plan {
     // offsets in floats.  latent_value ... lout_c: car_chain_pack tiles of the per-ray chains (car_raychain.hip; latent_value and lin_in
     // read their input rows from memory, the *_c layers the previous layer's accumulators); chain_scale: their powers of two;
     // mid_bias / tail_bias: their biases in consumption order
-    size_t steps, blob, fbias, wpt, r2w, r2b, proj[CAR_MAX_LEVELS], latent_value, lin_in, enc_c, qreh_c, lz_c[kBlocks], fc0_c[kBlocks],
+    size_t steps, blob, fbias, wpt, r2w, r2b, proj[CAR_MAX_LEVELS], proj16[CAR_MAX_LEVELS], latent_value, lin_in, enc_c, qreh_c, lz_c[kBlocks], fc0_c[kBlocks],
         fc1_c[kBlocks], lout_c, chain_scale, mid_bias, tail_bias, total;
 };
+// car_linear_x3 wants rows of whole float4s and a K worth its 32-wide chunks; narrower levels stay on car_linear
+inline bool level_on_f16_pipe(int c) { return c % 4 == 0 && c >= 32; }
 Plan plan_layout(const car_dims& d) {
     Plan p;
     size_t o = 0;
@@ -322,6 +390,8 @@ Plan plan_layout(const car_dims& d) {
     p.r2w = take(car_round2_packed_floats());
     p.r2b = take(car_round2_bias_floats());
     for (int l = 0; l < CAR_MAX_LEVELS; ++l) p.proj[l] = l < d.n_levels ? take(car_linear_packed_floats(d.level_c[l], kC)) : 0;
+    // the same slices for the split-fp16 kernel (car_linear_x3), which car_project_maps takes for the levels it serves
+    for (int l = 0; l < CAR_MAX_LEVELS; ++l) p.proj16[l] = (l < d.n_levels && level_on_f16_pipe(d.level_c[l])) ? take(car_linear_x3_packed_floats(d.level_c[l], kC)) : 0;
     p.latent_value = take(car_chain_packed_floats(kC, kE));
     p.lin_in = take(car_chain_packed_floats(kPhiIn, kD));
     p.enc_c = take(car_chain_packed_floats(kE, kD));
@@ -595,6 +665,8 @@ extern "C" int car_plan_build(const car_dims* dims, const car_weights* w, void* 
     int coff = 0;
     for (int l = 0; l < dims->n_levels; ++l) {
         CAR_TRY(car_linear_pack(w->query_encode_latent_w + coff, kC + 3, nullptr, dims->level_c[l], kC, base + p.proj[l], stream));
+        if (level_on_f16_pipe(dims->level_c[l]))
+            CAR_TRY(car_linear_x3_pack(w->query_encode_latent_w + coff, kC + 3, dims->level_c[l], kC, base + p.proj16[l], stream));
         coff += dims->level_c[l];
     }
     // the per-ray chains (car_raychain.hip), split-fp16 tiles; scale slots: 0 latent_value, 1 encode_latent, 2 query_repeat_embed[:, :128],
@@ -639,7 +711,12 @@ extern "C" int car_project_maps(const car_dims* dims, const void* plan, const fl
         CAR_REQUIRE(maps[l], "car_project_maps: level %d is null", l);
         const long M = (long)dims->b * dims->V * dims->level_h[l] * dims->level_w[l];
         float* gl = gmaps + level_offset(*dims, l);
-        CAR_TRY(car_linear(maps[l], dims->level_c[l], base + p.proj[l], dims->level_c[l], kC, gl, kC, M, 0, stream));
+        // G_l = W1[:, ch_l] F_l per texel: on the f16 matrix pipe with fp16 hi / lo operand halves (car_linear_x3: fp32-class accuracy at
+        // 2.3x the fp32 pipe's rate — the arithmetic of the staged route's engine._projected_maps) where the level's width allows it
+        if (level_on_f16_pipe(dims->level_c[l]) && ((uintptr_t)maps[l] & 15) == 0)
+            CAR_TRY(car_linear_x3(maps[l], dims->level_c[l], base + p.proj16[l], nullptr, dims->level_c[l], kC, gl, kC, M, 0, stream));
+        else
+            CAR_TRY(car_linear(maps[l], dims->level_c[l], base + p.proj[l], dims->level_c[l], kC, gl, kC, M, 0, stream));
         lv[l] = gl;
     }
     // the lattice, and in the same pass its largest magnitude (gmeta[0], zeroed above): it bounds h (the fused kernel scales its fp16
