@@ -32,6 +32,7 @@ The JSON line also carries
   pair_setup_ms, lattice_bytes, workspace_bytes, eval_mode : what the restructured path costs outside the timed region — the
                   once-per-stereo-pair projection of the pyramid onto its lattice, the memory it and the per-call workspace hold, and
                   the frame rate when every frame brings a new pair (the eval loop, eval_realestate10k.py:142-161);
+  first_round_ab: the same steps with the first attention round over the rows of e (rounds 1-4) instead of the fused kernel's partial sums;
   rank_share    : one call of 1/G of the frame per step (a rank's share at G = 2, 4, 8 GPUs) and the scaling each projects;
   power         : socket power, shader clock and joules per frame, sampled while the timed loop's steps run a second time;
   pose_route    : what handing the cameras over on the GPU costs per frame (the download + synchronisation of the host pose route);
@@ -332,8 +333,25 @@ def main():
         stages = model._engine.stage_times()
         model._engine.profile(False)
 
-        ev_ms = share = pose = power = None
+        ev_ms = share = pose = power = ab = None
         if extras:
+            # A/B of this round's change to the tail: the same K steps with the first attention round streaming the rows of e
+            # (CAR_PHASE_ROWS_FIRST_ROUND: the fused kernel without its partial sums + car_attend over e, the form of rounds 1-4)
+            eng.first_round_parts = False
+            render_frame(model, frames[0], z, tile, args.chunk_rays)
+            eng.profile(True)
+            e_rows = timed_loop(model, frames, z, tile, None, args.steps, args.chunk_rays, None)
+            st_rows = {}
+            for name, ms in eng.stage_times():
+                st_rows.setdefault(name, []).append(ms)
+            eng.profile(False)
+            eng.first_round_parts = True
+            render_frame(model, frames[0], z, tile, args.chunk_rays)
+            ab = {"rows_of_e": {"ms_per_step": e_rows / args.steps * 1e3, "stage_ms": {k: sum(v) / len(v) for k, v in st_rows.items()}},
+                  "partial_sums": {"ms_per_step": elapsed / args.steps * 1e3},
+                  "note": "first attention round over the rows of e (rounds 1-4; fused kernel without the partial-sum phase) against the default "
+                          "(partial sums per 8-step group left by the fused kernel): what the phase costs the fused kernel and saves the round"}
+
             # the same K steps once more under a socket-power / shader-clock sampler (tools/power_sampler.py: amdsmi, 5 ms period, and the
             # device's energy accumulator): what the chip's power management delivers under THIS workload, measured beside the timed
             # loop instead of quoted from an earlier profile.  Kept out of the timed region so the sampler thread cannot touch `value`.
@@ -455,9 +473,12 @@ def main():
                     "static_fields": ["limiter", "ta_busy", "mfma_busy", "valu_share", "l1_bytes", "traffic", "per_unit_unthrottled_frac"],
                     "static": "profiles/traffic.json: rocprofv3 --pmc passes of an earlier run of this kernel at config c2 (separate passes, not collected here; null for the other configs)",
                     "launches": len(lat), "ms_per_launch": mean * 1e3, "flop_per_launch": flop,
+                    # the same matrix work without the partial-sum phase (first_round_ab): the figure comparable with rounds 3-4
+                    "frac_without_partial_sums": None if not ab or "fused_samples" not in ab["rows_of_e"]["stage_ms"] else
+                    flop / (ab["rows_of_e"]["stage_ms"]["fused_samples"] * 1e-3) / (F16_MFMA_PEAK / 3),
                     # the chip under this frame's mix, sampled beside the timed loop (null where the box offers no power interface)
                     "sclk_mhz_live": None if not power else power.get("mean_sclk_mhz"), "socket_w_live": None if not power else power.get("energy_mean_w", power.get("mean_w"))}
-            roof["live_fields"] += ["sclk_mhz_live", "socket_w_live"]
+            roof["live_fields"] += ["sclk_mhz_live", "socket_w_live", "frac_without_partial_sums"]
         fr = prof.get("frame")
         hbm = None
         if fr and args.chunk_rays >= R and world == 1 and args.config == "c2":
@@ -493,6 +514,7 @@ def main():
                 "note": "every frame brings a new stereo pair (eval_realestate10k.py:142-161): car_project_maps runs before every frame; "
                         "get_z excluded as in the headline figure"},
             "rank_share": share,
+            "first_round_ab": ab,
             "power": power,
             "pose_route": pose,
             "frame_per_rank": None if per_rank is None else {

@@ -230,7 +230,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         __syncthreads();
     }
     float mx = 0.0f;
-    for (long node = first + (threadIdx.x >> 4); node < last; node += stride) {
+    // TAB: the 16 nodes of a step are 8 apart (node = chunk of 128 + class + 8 k), not neighbours: which taps of a level carry weight zero
+    // depends on the node's column modulo twice the level's factor — on a node's own texel centre three of four do — so the four nodes a
+    // wave-instruction serves now agree on it, and a tap none of them needs is an instruction whose lanes are ALL out of range: free.
+    // (Neighbouring nodes made almost every tap instruction partly live.)  The last, partial chunk of a workgroup is walked plainly.
+    const long n_mine = last > first ? last - first : 0, n_full = n_mine / 128 * 128;
+    const long steps = TAB ? (n_mine + 15) / 16 : 0;
+    for (long it = 0, node_gs = first + (threadIdx.x >> 4); TAB ? it < steps : node_gs < last; ++it, node_gs += stride) {
+        long node = node_gs;
+        if constexpr (TAB) {
+            const long base = it * 16;
+            const long local = base < n_full ? (base / 128) * 128 + (base % 128) / 16 + 8 * (threadIdx.x >> 4) : base + (threadIdx.x >> 4);
+            if (local >= n_mine) continue;
+            node = first + local;
+        }
         const long row = node / a.lw;
         const int m = (int)(row / a.lh);
         const int jy = (int)(row - (long)m * a.lh), jx = (int)(node - row * a.lw);
@@ -760,6 +773,7 @@ static int render_phases(const car_dims* dims, const void* plan, const car_input
     float* ws = static_cast<float*>(workspace);
     hipStream_t st = (hipStream_t)stream;
     const int b = d.b, V = d.V, R = d.R, P = d.P;
+    const bool rows_first = (phases & CAR_PHASE_ROWS_FIRST_ROUND) != 0;
     CAR_REQUIRE(!d.no_sample || in->steps, "car_render_forward: no_sample needs `steps` (the P depths along the query ray, models.py:221-222)");
     const float* steps = in->steps ? in->steps : pl + p.steps;
     const long BR = (long)b * R;
@@ -779,17 +793,25 @@ static int render_phases(const car_dims* dims, const void* plan, const car_input
     {   // a6-a13 + round-1 logits: the fused per-sample kernel
         Stage stage("fused_samples", st);
         const Lattice L = lattice_of(d);
-        CAR_TRY(car_fused_samples_parts(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->gmeta, pl + p.wpt, pl + p.blob,
-                                        pl + p.fbias, b, V, R, P, d.H, d.W, d.no_sample != 0, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt,
-                                        pixel_val, ws + w.part, stream));
+        if (rows_first)
+            CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->gmeta, pl + p.wpt, pl + p.blob,
+                                      pl + p.fbias, b, V, R, P, d.H, d.W, d.no_sample != 0, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
+        else
+            CAR_TRY(car_fused_samples_parts(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->gmeta, pl + p.wpt, pl + p.blob,
+                                            pl + p.fbias, b, V, R, P, d.H, d.W, d.no_sample != 0, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt,
+                                            pixel_val, ws + w.part, stream));
     }
     }
     if (!(phases & CAR_PHASE_RAYS)) return CAR_OK;
     {   // a14 + a16: attention round 1, depth read-out, argmax.  The value average comes from the per-step-group partial sums the
         // fused kernel left behind (an eighth of the rows of e), so e itself is streamed from HBM by the second round only
         Stage stage("attend_1", st);
-        CAR_TRY(car_attend_parts(ws + w.logit, ws + w.part, car_fused_tile_steps(), kC, b, V, R, P, at_wt, ws + w.ebar, kC, 1, ws + w.pt, in->poses,
-                                 depth, amax, stream));
+        if (rows_first)
+            CAR_TRY(car_attend(ws + w.logit, nullptr, kD, ws + w.e, kC, b, V, R, P, nullptr, 0.0f, at_wt, ws + w.ebar, kC, 1, ws + w.pt, in->poses,
+                               depth, amax, stream));
+        else
+            CAR_TRY(car_attend_parts(ws + w.logit, ws + w.part, car_fused_tile_steps(), kC, b, V, R, P, at_wt, ws + w.ebar, kC, 1, ws + w.pt, in->poses,
+                                     depth, amax, stream));
     }
     // weight-chunk tables of the two per-ray chains (car_raychain.hip): float offset inside the plan and tile count of every K = 32
     // chunk, in the order the kernels consume them
@@ -839,7 +861,8 @@ extern "C" int car_render_forward(const car_dims* dims, const void* plan, const 
 
 extern "C" int car_render_forward_phase(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
                                         void* workspace, size_t workspace_bytes, int phases, void* stream) {
-    CAR_REQUIRE(phases == CAR_PHASE_SAMPLES || phases == CAR_PHASE_RAYS || phases == (CAR_PHASE_SAMPLES | CAR_PHASE_RAYS),
-                "car_render_forward_phase: phases = %d (CAR_PHASE_SAMPLES, CAR_PHASE_RAYS or both)", phases);
+    const int which = phases & ~CAR_PHASE_ROWS_FIRST_ROUND;
+    CAR_REQUIRE(which == CAR_PHASE_SAMPLES || which == CAR_PHASE_RAYS || which == (CAR_PHASE_SAMPLES | CAR_PHASE_RAYS),
+                "car_render_forward_phase: phases = %d (CAR_PHASE_SAMPLES, CAR_PHASE_RAYS or both, optionally | CAR_PHASE_ROWS_FIRST_ROUND)", phases);
     return render_phases(dims, plan, in, out, workspace, workspace_bytes, phases, stream);
 }

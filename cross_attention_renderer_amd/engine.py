@@ -97,6 +97,9 @@ class RenderEngine:
         # stage-by-stage pipeline of this module (A/B and stage tests)
         self.fuse_samples = True
         self.fuse_round2 = True        # staged route: round-2 per-sample layer + logits in one kernel (csrc/car_round2.hip)
+        # one-call route: the first attention round folds the fused kernel's per-step-group partial sums (default); False = it streams
+        # the rows of e as in rounds 1-4 (CAR_PHASE_ROWS_FIRST_ROUND: A/B measurements and tests)
+        self.first_round_parts = True
         self.fuse_exchange = True      # three-view exchange: first + second layer in one kernel (car_lattice_encode_linear); False = two launches (A/B)
         # sizing of the one-call route (tests shrink them to force several calls)
         self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
@@ -481,8 +484,12 @@ class RenderEngine:
                     ci.gmeta = gmeta_ptr
                     ci.steps = steps.data_ptr()
                     co = _lib.CarOutputs(*[tgt[k].data_ptr() for k in order])
-                    _lib.check(lib.car_render_forward(ctypes.byref(d), _ptr(plan), ctypes.byref(ci), ctypes.byref(co),
-                                                      _ptr(work), work.numel() * 4, st), "car_render_forward")
+                    if self.first_round_parts:
+                        _lib.check(lib.car_render_forward(ctypes.byref(d), _ptr(plan), ctypes.byref(ci), ctypes.byref(co),
+                                                          _ptr(work), work.numel() * 4, st), "car_render_forward")
+                    else:
+                        _lib.check(lib.car_render_forward_phase(ctypes.byref(d), _ptr(plan), ctypes.byref(ci), ctypes.byref(co),
+                                                                _ptr(work), work.numel() * 4, 1 | 2 | 4, st), "car_render_forward_phase")
                     if not whole:
                         for k in order:
                             dst = out[k][:, 0] if k == "rgb" else out[k]

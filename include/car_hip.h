@@ -370,13 +370,17 @@ int car_render_forward(const car_dims* dims, const void* plan, const car_inputs*
  * CAR_PHASE_SAMPLES = rays + the fused per-sample kernel (matrix-pipe / power bound; writes e, qry, g, logit, pt into the workspace),
  * CAR_PHASE_RAYS = both attention rounds and the per-ray chains (HBM bound; reads them, writes the outputs).  The second phase of a
  * batch must be ordered after its first phase (an event) and use the same dims / inputs / outputs / workspace; batches with their own
- * workspaces are independent.  phases = both is car_render_forward. */
+ * workspaces are independent.  phases = both is car_render_forward.
+ * CAR_PHASE_ROWS_FIRST_ROUND (a flag OR-ed onto both phases of a batch): the first attention round streams the rows of e
+ * (car_fused_samples + car_attend, the form of rounds 1-4) instead of folding the fused kernel's per-step-group partial sums
+ * (car_fused_samples_parts + car_attend_parts, the default) — kept for A/B measurements and tests; same results to fp32 rounding. */
 #define CAR_PHASE_SAMPLES 1
 #define CAR_PHASE_RAYS 2
+#define CAR_PHASE_ROWS_FIRST_ROUND 4
 int car_render_forward_phase(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
                              void* workspace, size_t workspace_bytes, int phases, void* stream);
 /* Where a named intermediate lives inside the workspace after car_render_forward (tests, debugging, profiling): one of
- * "rays" "e" "qry" "g" "logit" "logit2" "pt" "at_wt2" "ebar" "z1" "uh".  Returns 0 and the float offset / count. */
+ * "rays" "e" "qry" "g" "logit" "logit2" "pt" "at_wt2" "ebar" "z1" "uh" "part".  Returns 0 and the float offset / count. */
 int car_workspace_find(const car_dims* dims, const char* name, size_t* offset_floats, size_t* n_floats);
 
 /* ---- stage timing (the reference's only hooks are record_function labels, resnet_block_fc.py:54, 139, and one time.time() pair,

@@ -149,6 +149,9 @@ def test_bench_prints_one_line_with_the_contract_fields():
     assert abs(g["spread"] - (g["ms_max"] - g["ms_min"]) / g["ms"]) < 1e-9
     assert d["rank_share"]["rays_per_step"] == 8192 and 1.0 < d["rank_share"]["projected_scaling_8"] <= 8.5
     assert 1.0 < d["rank_share"]["projected_scaling_2"] <= 2.2 and d["rank_share"]["projected_scaling_2"] < d["rank_share"]["projected_scaling_4"] <= 4.3
+    ab = d["first_round_ab"]
+    assert ab["rows_of_e"]["stage_ms"]["attend_1"] > 2 * d["stage_ms"]["attend_1"] and ab["rows_of_e"]["stage_ms"]["fused_samples"] < d["stage_ms"]["fused_samples"]
+    assert 0.0 < r["frac"] < r["frac_without_partial_sums"] < 1.0
     pw = d["power"]                                                    # sampled beside the timed loop; a box without a power interface says so
     assert "available" in pw and (not pw["available"] or (pw["mean_w"] > 50 and pw["samples"] >= 5 and pw["joule_per_frame"] > 0))
     assert ("sclk_mhz_live" in r) and ("socket_w_live" in r)

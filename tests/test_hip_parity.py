@@ -500,6 +500,18 @@ def test_first_round_partial_sums_equal_the_row_reduction(R, P, b):
     assert ((z0 - z1).abs() / scale).max().item() < 2e-6
 
 
+@pytest.mark.parametrize("name", ["t1_c1", "t1_no_sample", "t2_c2", "t2_c3"])
+def test_first_round_from_partial_sums_equals_the_row_form(name):
+    """The product route (first attention round over the fused kernel's partial sums) against CAR_PHASE_ROWS_FIRST_ROUND (the same round
+    over the rows of e, rounds 1-4): at_wt, depth_ray, valid_mask and the argmax bit for bit, rgb to fp32 rounding."""
+    c, fx, ora, a = run_case(name)
+    _, _, _, b_ = run_case(name, engine_setup=lambda e: setattr(e, "first_round_parts", False))
+    for k in ("at_wt", "depth_ray", "valid_mask", "at_wt_max", "pixel_val"):
+        assert torch.equal(a[k], b_[k]), k
+    assert rel_err(a["rgb"], b_["rgb"]) < 2e-6
+    _check_outputs(b_, lambda k: ora[k], "row form vs oracle")
+
+
 def test_one_call_c_abi_without_second_round():
     """repeat_attention=False (models.py:547) through car_render_forward and the oracle at real widths."""
     from cross_attention_renderer_amd import synthetic as S
