@@ -230,20 +230,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         __syncthreads();
     }
     float mx = 0.0f;
-    // TAB: the 16 nodes of a step are 8 apart (node = chunk of 128 + class + 8 k), not neighbours: which taps of a level carry weight zero
-    // depends on the node's column modulo twice the level's factor — on a node's own texel centre three of four do — so the four nodes a
-    // wave-instruction serves now agree on it, and a tap none of them needs is an instruction whose lanes are ALL out of range: free.
-    // (Neighbouring nodes made almost every tap instruction partly live.)  The last, partial chunk of a workgroup is walked plainly.
-    const long n_mine = last > first ? last - first : 0, n_full = n_mine / 128 * 128;
-    const long steps = TAB ? (n_mine + 15) / 16 : 0;
-    for (long it = 0, node_gs = first + (threadIdx.x >> 4); TAB ? it < steps : node_gs < last; ++it, node_gs += stride) {
-        long node = node_gs;
-        if constexpr (TAB) {
-            const long base = it * 16;
-            const long local = base < n_full ? (base / 128) * 128 + (base % 128) / 16 + 8 * (threadIdx.x >> 4) : base + (threadIdx.x >> 4);
-            if (local >= n_mine) continue;
-            node = first + local;
-        }
+    // Tried and dropped (round 5, tools/bench_merge.py): a wave's four nodes 8 apart, so that they agree on which taps carry weight zero and a
+    // dead tap is an instruction whose lanes are ALL out of range: 1.08 -> 1.5 ms (the wave's stores then fall on four distant rows); 64 lanes
+    // per node (1 KB contiguous per load / store instruction, the third step a quarter full): 1.15 -> 1.46 ms = the extra instructions.
+    for (long node = first + (threadIdx.x >> 4); node < last; node += stride) {
         const long row = node / a.lw;
         const int m = (int)(row / a.lh);
         const int jy = (int)(row - (long)m * a.lh), jx = (int)(node - row * a.lw);
