@@ -23,8 +23,7 @@ st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 _lib.check(lib.car_merge_lattice(ptrs, hs, ws, 3, n_maps, None, ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(pad), st), "shape")
 lat = torch.empty(n_maps * 2 * lh.value * lw.value * C, device=dev)
 ref = None
-for lanes in (sys.argv[1:] or ["16", "64", "16", "64"]):
-    os.environ["CAR_MERGE_LANES"] = lanes
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     ev = []
     for i in range(12):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -36,4 +35,4 @@ for lanes in (sys.argv[1:] or ["16", "64", "16", "64"]):
     ms = sorted(a.elapsed_time(b) for a, b in ev[2:])
     if ref is None:
         ref = lat.clone()
-    print(f"lanes per node {lanes}: median {ms[len(ms) // 2]:.3f} ms  min {ms[0]:.3f} ms  ({lat.numel() * 4 / ms[len(ms) // 2] / 1e9:.2f} TB/s written)  equal to the first: {torch.equal(lat, ref)}", flush=True)
+    print(f"car_merge_lattice: median {ms[len(ms) // 2]:.3f} ms  min {ms[0]:.3f} ms  ({lat.numel() * 4 / ms[len(ms) // 2] / 1e9:.2f} TB/s written)  equal to the first: {torch.equal(lat, ref)}", flush=True)
