@@ -172,6 +172,157 @@ int launch_wgrad_tile(const float* dY, int ldy, const float* X, int ldx, long M,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same product on the bf16 matrix pipe (round 5): dW = dY^T X as three v_mfma_f32_16x16x32_bf16 products of bf16 hi / lo halves of BOTH
+// operands (hi hi + hi lo + lo hi, fp32 accumulate).  Both operands are activations here — no pack-time scale to lean on — and bf16 keeps
+// fp32's exponent, so no power of two has to be agreed on per launch, block or row (what the split-fp16 attempt of round 4 spent its time on):
+// x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), both rounded to nearest, |r| <= 2^-18 |x|; the dropped lo lo term is 2^-18
+// relative.  Errors are rounding-like (unbiased), far inside the gradient tests' bound (2e-5 of the largest entry against fp64).
+// A = dY^T (16 outputs n x 32 rows m), B = X (32 rows x 16 inputs k): lane (l & 15, l >> 4) feeds column l & 15 of its operand with the 8
+// rows 8 (l >> 4) .. + 7 — a COLUMN of the row-major block, so the transpose happens when the block is staged: a thread takes 8 rows x 4
+// columns from memory (8 float4, coalesced along the row), splits them, and writes each column's 8 rows as ONE 16-byte word per half into
+// an LDS image [column][32 rows]; a wave's operand read is then 1 KB contiguous (conflict-free).  512 threads = 8 waves as 2 x 4 over a
+// 192 x 320 tile of dW (a wave: 96 x 80 = 6 x 5 blocks, 120 accumulator registers), (192 + 320) / 4 column quads x 4 row octets = exactly
+// one staging task per thread and 32-row block; the next block's loads fly under this block's MFMAs, LDS is double buffered (131 KB), one
+// barrier per block.  Row slabs meet in dW with fp32 atomics, as in the fp32-pipe kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
+constexpr int kW16Rows = 32, kW16N = 192, kW16K = 320, kW16Threads = 512;
+constexpr int kW16QuadsA = kW16N / 4, kW16Quads = (kW16N + kW16K) / 4;                 // 48 + 80 column quads
+static_assert(kW16Quads * (kW16Rows / 8) == kW16Threads, "one staging task per thread");
+constexpr int kW16PlaneA = kW16N * kW16Rows / 2, kW16PlaneB = kW16K * kW16Rows / 2;    // floats per (operand, half) plane: [column][32 rows] bf16
+constexpr int kW16Buf = 2 * (kW16PlaneA + kW16PlaneB);                                // floats per buffer: A hi | A lo | B hi | B lo
+
+__global__ void __launch_bounds__(kW16Threads) wgrad16_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, long M, int N,
+                                                              int K, int relu_x, long slab_rows, float* __restrict__ dW, int lddw, float* __restrict__ db) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];                       // [2][kW16Buf]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 2, wk = wave & 3;                                          // the wave's 96 x 80 corner of the tile
+    const int n0 = blockIdx.x * kW16N, k0 = blockIdx.y * kW16K;
+    const int Kb = db ? K + 1 : K;
+    const long m_begin = (long)blockIdx.z * slab_rows;
+    const long m_end = m_begin + slab_rows < M ? m_begin + slab_rows : M;
+    // staging task: column quad q of [dY's 48 | X's 80], row octet o of the 32-row block
+    const int q = tid >> 2, o = tid & 3;
+    const bool isA = q < kW16QuadsA;
+    const int c = isA ? 4 * q : 4 * (q - kW16QuadsA);                                 // first column inside the operand's tile
+    const float* src = isA ? dY : X;
+    const int ld = isA ? ldy : ldx, col0 = isA ? n0 + c : k0 + c;
+    const int colc = col0 < ld - 3 ? col0 : 0;                                         // clamped: always a readable float4
+    wf32x4 stage[8];
+    auto fetch = [&](long m) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const long row = m + 8 * o + r < m_end ? m + 8 * o + r : m_end - 1;
+            stage[r] = *reinterpret_cast<const wf32x4*>(src + row * ld + colc);
+        }
+    };
+    auto commit = [&](int buf, long m) {
+        float* plane = lds + buf * kW16Buf + (isA ? 0 : 2 * kW16PlaneA);
+        const int plane_floats = isA ? kW16PlaneA : kW16PlaneB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = col0 + i;
+            unsigned hi[8], lo[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float v = stage[r][i];
+                const bool in_rows = m + 8 * o + r < m_end;
+                if (isA) { if (!in_rows || col0 >= ld - 3 || col >= N) v = 0.0f; }
+                else if (col >= K) v = (col == K && db && in_rows) ? 1.0f : 0.0f;     // the bias column, then nothing
+                else if (!in_rows || col0 >= ld - 3) v = 0.0f;
+                else if (relu_x) v = fmaxf(v, 0.0f);
+                // both halves rounded to nearest: a truncated hi would leave residuals of x's own sign, and the dropped lo lo products a bias
+                hi[r] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
+                const float res = v - __uint_as_float(hi[r] << 16);                    // exact
+                lo[r] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)res);
+            }
+            const wu32x4 h4 = {hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16)};
+            const wu32x4 l4 = {lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16)};
+            float* dst = plane + ((c + i) * kW16Rows + 8 * o) / 2;                     // [column][32 rows] bf16: 16 floats per column
+            *reinterpret_cast<wu32x4*>(dst) = h4;
+            *reinterpret_cast<wu32x4*>(dst + plane_floats) = l4;
+        }
+    };
+    wf32x4 acc[6][5];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = wf32x4{0.f, 0.f, 0.f, 0.f};
+    const int nl = lane & 15, g = lane >> 4;
+    if (m_begin < m_end) { fetch(m_begin); commit(0, m_begin); }
+    __syncthreads();
+    int buf = 0;
+    for (long m = m_begin; m < m_end; m += kW16Rows) {
+        const bool more = m + kW16Rows < m_end;
+        if (more) fetch(m + kW16Rows);
+        const float* pa = lds + buf * kW16Buf + ((wn * 96 + nl) * kW16Rows + 8 * g) / 2;
+        const float* pb = lds + buf * kW16Buf + 2 * kW16PlaneA + ((wk * 80 + nl) * kW16Rows + 8 * g) / 2;
+        bf16x8 bh[5], bl[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pb + j * 16 * kW16Rows / 2));
+            bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pb + kW16PlaneB + j * 16 * kW16Rows / 2));
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pa + i * 16 * kW16Rows / 2));
+            const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pa + kW16PlaneA + i * 16 * kW16Rows / 2));
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) commit(buf ^ 1, m + kW16Rows);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // lane (nl, g) holds, of block (i, j): dW rows n = 16 i + 4 g + r (r = 0..3), column k = 16 j + nl
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int k = k0 + wk * 80 + 16 * j + nl;
+            if (k >= Kb) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 96 + 16 * i + 4 * g + r;
+                if (n >= N) continue;
+                if (k < K) atomicAdd(dW + (long)n * lddw + k, acc[i][j][r]);
+                else atomicAdd(db + n, acc[i][j][r]);
+            }
+        }
+}
+
+int launch_wgrad16(const float* dY, int ldy, const float* X, int ldx, long M, int N, int K, int flags, float* dW, int lddw, float* db, void* stream) {
+    const int Kb = db ? K + 1 : K;
+    const unsigned gx = car_div_up(N, kW16N), gy = car_div_up(Kb, kW16K);
+    long want = 256 / ((long)gx * gy);                                 // one 8-wave workgroup per compute unit
+    if (want < 1) want = 1;
+    long slab = (M + want - 1) / want;
+    slab = (slab + kW16Rows - 1) / kW16Rows * kW16Rows;
+    const unsigned gz = car_div_up(M, slab);
+    CAR_REQUIRE(gz <= 65535, "car_linear_wgrad: too many row slabs");
+    const size_t lds_bytes = (size_t)2 * kW16Buf * sizeof(float);
+    static bool reserved[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !reserved[dev]) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)wgrad16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e1 != hipSuccess) { car_set_error("car_linear_wgrad: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
+        if (dev >= 0 && dev < 64) reserved[dev] = true;
+    }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(wgrad16_kernel, dim3(gx, gy, gz), dim3(kW16Threads), lds_bytes, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K,
+                       (flags & CAR_LIN_RELU_IN) ? 1 : 0, slab, dW, lddw, db);
+    CAR_CHECK_LAUNCH("car_linear_wgrad");
+    return CAR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // One attention round, backward.  Forward (car_attend): w = softmax_s(logit_s) over the ray's V P samples, zbar = sum_s w_s val_s,
 // depth = clamp((inv_q sum_s w_s clamp(pt_s, +-100)).z, 0, 10).  Given dz [b R, D] (gradient of zbar) and optionally ddepth [b R]:
 //   a_s = <dz, val_s> + ddepth [0 < depth_pre < 10] inv_q[2, :3] . clamp(pt_s)          dlogit_s = w_s (a_s - sum_t w_t a_t)
@@ -353,7 +504,10 @@ extern "C" int car_linear_wgrad(const float* dY, int ldy, const float* X, int ld
     CAR_REQUIRE(dY && X && dW, "car_linear_wgrad: null pointer");
     CAR_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && lddw >= K, "car_linear_wgrad: bad sizes M=%ld N=%d K=%d", M, N, K);
     CAR_REQUIRE(ldy % 4 == 0 && ldx % 4 == 0, "car_linear_wgrad: row strides must be multiples of 4 floats (got %d, %d)", ldy, ldx);
-    // wide layers: the 192 x 320 workgroup tile; everything else the 128 x 128 one
+    // wide layers over many rows: the bf16 x 3 kernel (CAR_WGRAD_FP32 in flags keeps them on the fp32 pipe: A/B and tests); wide layers
+    // otherwise: the fp32 pipe's 192 x 320 workgroup tile; everything else its 128 x 128 one
+    if ((N > 128 || K + (db ? 1 : 0) > 128) && M >= 4096 && !(flags & CAR_WGRAD_FP32))
+        return launch_wgrad16(dY, ldy, X, ldx, M, N, K, flags, dW, lddw, db, stream);
     if (N > 128 || K + (db ? 1 : 0) > 128) return launch_wgrad_tile<3, 5>(dY, ldy, X, ldx, M, N, K, flags, dW, lddw, db, stream);
     return launch_wgrad_tile<2, 2>(dY, ldy, X, ldx, M, N, K, flags, dW, lddw, db, stream);
 }

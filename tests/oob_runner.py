@@ -265,6 +265,34 @@ def case_attend(R, P, V, D, tail=True):
                                "car_attend"), t, ["w", "z"], tail)
 
 
+def case_wgrad(M, N, K, flags, tail=True):
+    """car_linear_wgrad: dY, X read; dW, db accumulated (the bf16 x 3 kernel for wide layers over >= 4096 rows, else the fp32 pipe's)."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    ldy, ldx = (N + 3) // 4 * 4, (K + 3) // 4 * 4
+    t = {"dY": torch.randn(M, ldy, generator=g).to(dev), "X": torch.randn(M, ldx, generator=g).to(dev), "dW": torch.zeros(N, K, device=dev),
+         "db": torch.zeros(N, device=dev)}
+
+    def both(call_, t_, outs):
+        # atomics make the sums' order run-dependent: compare to rounding, keep the margin / NaN checks exact
+        plain = {k: v.clone() for k, v in t_.items()}
+        call_(lambda k: ctypes.c_void_p(plain[k].data_ptr()))
+        torch.cuda.synchronize()
+        guarded = {k: Guarded(v) for k, v in t_.items()}
+        call_(lambda k: ctypes.c_void_p(guarded[k].ptr))
+        torch.cuda.synchronize()
+        for k in outs:
+            a, b = plain[k], guarded[k].read()
+            assert torch.isfinite(b).all(), f"{k}: a NaN from outside an argument reached the result"
+            assert (a - b).abs().max().item() <= 1e-4 * a.abs().max().item(), k
+        for k in t_:
+            assert guarded[k].margins_intact(), f"{k}: bytes outside the argument were written"
+            if k not in outs:
+                assert torch.equal(t_[k], guarded[k].read()), f"{k}: an input was written"
+    both(lambda p: L.check(lib.car_linear_wgrad(p("dY"), ldy, p("X"), ldx, M, N, K, flags, p("dW"), K, p("db"), stream()), "car_linear_wgrad"),
+         t, ["dW", "db"])
+
+
 CASES = {
     "x3_nt18": lambda tail: case_linear_x3(200, 576, 576, 2, tail),
     "x3_nt18_k579": lambda tail: case_linear_x3(4097, 579, 288, 0, tail),
@@ -288,6 +316,10 @@ CASES = {
     "exchange_ragged": lambda tail: case_exchange(193, 128, tail),
     "attend_864": lambda tail: case_attend(37, 13, 3, 864, tail),
     "attend_100": lambda tail: case_attend(20, 8, 2, 100, tail),
+    "wgrad16_579": lambda tail: case_wgrad(4133, 576, 579, 1, tail),
+    "wgrad16_ragged": lambda tail: case_wgrad(4100, 200, 130, 0, tail),
+    "wgrad_fp32": lambda tail: case_wgrad(513, 576, 579, 0, tail),
+    "wgrad_small": lambda tail: case_wgrad(777, 3, 128, 1, tail),
 }
 # families of cases (tools/oob_selfcheck.sh runs one family per process)
 FAMILIES = {
@@ -297,6 +329,7 @@ FAMILIES = {
     "fused": ["fused_37_13", "fused_48_8_b2"],
     "tail": ["tail_37_13", "tail_96_32_b2", "attend_864", "attend_100"],
     "exchange": ["exchange_288", "exchange_ragged"],
+    "wgrad": ["wgrad16_579", "wgrad16_ragged", "wgrad_fp32", "wgrad_small"],
 }
 
 if __name__ == "__main__":

@@ -61,7 +61,10 @@ def test_wgrad_kernel_matches_torch():
     """car_linear_wgrad alone: dW += dY^T X, db += sum dY, ragged sizes, strides, the relu-on-load flag and accumulation."""
     lib, dev = _lib(), torch.device("cuda:0")
     g = torch.Generator().manual_seed(1)
-    for M, N, K, relu in ((1000, 128, 16, False), (777, 3, 128, True), (4099, 288, 576, False), (513, 576, 579, False), (64, 128, 144, True)):
+    # (4099, 288, 576), (8221, 576, 579), (5000, 128, 576), (4100, 200, 100): wide layers over >= 4096 rows -> the bf16 x 3 kernel (ragged
+    # tiles in both directions, the bias column at 579 = a tile's last live column); the rest: the fp32-pipe kernels
+    for M, N, K, relu in ((1000, 128, 16, False), (777, 3, 128, True), (4099, 288, 576, False), (513, 576, 579, False), (64, 128, 144, True),
+                          (8221, 576, 579, True), (5000, 128, 576, False), (4100, 200, 100, True)):
         ldy, ldx = N + (4 - N % 4) % 4 + 4, K + (4 - K % 4) % 4
         dy = torch.randn(M, ldy, generator=g).to(dev)
         x = torch.randn(M, ldx, generator=g).to(dev)
@@ -78,6 +81,30 @@ def test_wgrad_kernel_matches_torch():
         assert (dw[:, :K].double() - want_w).abs().max().item() <= 2e-5 * scale, (M, N, K)
         assert torch.equal(dw[:, K:], dw0[:, K:]), "columns beyond K were touched"
         assert (db.double() - want_b).abs().max().item() <= 2e-5 * want_b.abs().max().item(), (M, N, K)
+        # the same product kept on the fp32 matrix pipe (CAR_WGRAD_FP32 = 16): the two kernels agree to the same bound
+        dw2, db2 = dw0.clone(), db0.clone()
+        assert lib.car_linear_wgrad(_ptr(dy), ldy, _ptr(x), ldx, M, N, K, (1 if relu else 0) | 16, _ptr(dw2), K + 5, _ptr(db2), _stream()) == 0
+        torch.cuda.synchronize()
+        assert (dw2[:, :K].double() - want_w).abs().max().item() <= 2e-5 * scale, (M, N, K, "fp32 pipe")
+        assert (dw2 - dw).abs().max().item() <= 2e-5 * scale
+
+
+def test_wgrad_bf16_split_keeps_small_and_large_rows():
+    """The bf16 x 3 weight-gradient kernel on operands whose rows span twelve orders of magnitude (bf16 keeps fp32's exponent: no scale is
+    chosen anywhere) and on columns that cancel: the error stays rounding-like — 2e-5 of sum |dY||X| per entry against fp64."""
+    lib, dev = _lib(), torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 6000, 288, 576
+    dy = (torch.randn(M, N, generator=g) * torch.logspace(-8, 4, M).unsqueeze(1)).to(dev)
+    x = (torch.randn(M, K, generator=g) * torch.logspace(3, -6, M).unsqueeze(1)).to(dev)
+    x[:, :8] = 1.0                                                      # constant columns: entries that are sums with little cancellation
+    dw = torch.zeros(N, K, device=dev)
+    assert lib.car_linear_wgrad(_ptr(dy), N, _ptr(x), K, M, N, K, 0, _ptr(dw), K, None, _stream()) == 0, lib.car_last_error()
+    torch.cuda.synchronize()
+    want = dy.double().t() @ x.double()
+    bound = dy.double().abs().t() @ x.double().abs()
+    assert torch.isfinite(dw).all()
+    assert ((dw.double() - want).abs() / bound).max().item() <= 2e-5
 
 
 def test_gather_backward_is_the_adjoint_of_the_gather():
