@@ -484,3 +484,15 @@ def average_gradients(module, group=None) -> None:
                 p.grad.copy_(g)
             elif some:
                 p.grad = g.clone()
+
+
+def make_adam(params, lr: float, betas=(0.99, 0.999)):
+    """The reference's optimizer (Adam(lr, betas=(0.99, 0.999)), train_realestate10k.py:93) in torch's fused form where the installed torch
+    offers it for the parameters' device — the same update in one kernel instead of ten launches per step (3 ms of a 28 ms step) —,
+    the plain form otherwise.  The state dict has the same layout either way."""
+    import torch
+    params = list(params)
+    try:
+        return torch.optim.Adam(lr=lr, params=params, betas=betas, fused=True)
+    except (RuntimeError, TypeError, ValueError):
+        return torch.optim.Adam(lr=lr, params=params, betas=betas)

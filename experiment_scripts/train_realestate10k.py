@@ -39,6 +39,7 @@ def train(rank, opt):
     import torch
     import torch.distributed as dist
     from cross_attention_renderer_amd import harness, synthetic
+    from cross_attention_renderer_amd import training
     from cross_attention_renderer_amd.training import average_gradients, render_train
     if opt.lpips:
         raise SystemExit("--lpips needs the lpips package (not installed here)")
@@ -54,10 +55,10 @@ def train(rank, opt):
     z = None
     if model.encoder.__class__.__name__ == "EncoderNotBuilt":
         z = [t.to(dev).requires_grad_(True) for t in synthetic.feature_maps(b, opt.views, H, seed=1 + rank)]
-    optimizer = torch.optim.Adam(lr=opt.lr, params=params, betas=(0.99, 0.999))      # the reference's parameter group: what the checkpoint stores
+    optimizer = training.make_adam(params, opt.lr)                  # the reference's Adam and parameter group: what the checkpoint stores
     # the stand-in pyramid (no encoder built) is a per-rank leaf with an optimizer of its own, so that the saved 'optimizer' state matches
     # the reference's param groups
-    z_optimizer = torch.optim.Adam(lr=opt.lr, params=z, betas=(0.99, 0.999)) if z is not None else None
+    z_optimizer = training.make_adam(z, opt.lr) if z is not None else None
     if opt.depth and R % 1024:
         raise SystemExit("--depth: the reference's depth-variance term works on 32 x 32 pixel patches (loss_functions.py:112-127): "
                          "--query_sparsity must be a multiple of 1024")

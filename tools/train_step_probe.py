@@ -11,6 +11,7 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 from cross_attention_renderer_amd import harness, synthetic  # noqa: E402
+from cross_attention_renderer_amd import training  # noqa: E402
 from cross_attention_renderer_amd.training import render_train  # noqa: E402
 
 
@@ -22,8 +23,8 @@ def main():
     params = [p for p in model.parameters() if p.requires_grad]
     base = harness.to_device(synthetic.stereo_scene(H, b=b, seed=5), dev)          # cameras stay on the host
     z = [t.to(dev).requires_grad_(True) for t in synthetic.feature_maps(b, 2, H, seed=1)]
-    opt = torch.optim.Adam(lr=5e-5, params=params, betas=(0.99, 0.999))
-    zopt = torch.optim.Adam(lr=5e-5, params=z, betas=(0.99, 0.999))
+    opt = training.make_adam(params, 5e-5)
+    zopt = training.make_adam(z, 5e-5)
     grid = synthetic.pixel_grid(H, H).to(dev)
     g = torch.Generator(device=dev).manual_seed(1)
     gt = torch.rand(b, 1, R, 3, device=dev) * 2 - 1
