@@ -70,6 +70,10 @@ SIGNATURES = {
     "car_linear_packed_floats": (c_size_t, [c_int, c_int]),
     "car_linear_pack": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "car_linear": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_long, c_int, _P]),
+    "car_kq_tail_floats": (c_size_t, []),
+    "car_kq_bias_floats": (c_size_t, []),
+    "car_kq_pack": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "car_key_query_logits": (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, c_long, _P, _P, _P]),
     "car_attend": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P, _P, c_int, c_int,
                            _P, _P, _P, _P, _P]),
     "car_attend_parts": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),

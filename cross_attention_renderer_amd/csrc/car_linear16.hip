@@ -21,8 +21,12 @@ constexpr int pieces_of(int nt) { return (2 * nt + kWaves - 1) / kWaves; }
 
 #include "car_fused_mma.h"
 
-__device__ __forceinline__ constexpr int chunk_tile_offset(int) { return 0; }      // the fused kernel's chunk tables: not used here
-__device__ __forceinline__ constexpr int chunk_tiles(int) { return 0; }
+// The layer stream of this kernel addresses its chunks itself (chunk_desc below); the chunk table car_fused_mma.h asks for serves the KQ
+// instance's tail (car_key_query_logits): a blob of K2 = chunks 0, 1 (two K steps x 8 tiles each) | Q1 = chunk 2 (8 tiles) | Q2 = chunks 3, 4
+constexpr int kG_K2 = 0, kG_Q1 = 2, kG_Q2 = 3, kTailTiles = 72;
+__device__ __forceinline__ constexpr int chunk_tile_offset(int g) { return g <= 0 ? 0 : g == 1 ? 16 : g == 2 ? 32 : g == 3 ? 40 : 56; }
+__device__ __forceinline__ constexpr int chunk_tiles(int g) { return g == 2 ? 8 : 16; }
+constexpr int kTailBias = 2 * kD + 16;             // bk2 [128] | bq2 [128] | 2^-shift of K2, Q1, Q2 | (pack-time scratch)
 
 struct LinArgs {
     const float* X; int ldx;
@@ -38,9 +42,12 @@ struct LinArgs {
     // encode_kernel, one 32-channel chunk at a time, straight into the B operands
     const float* lattice; int lh, lw, lpad; float sx, sy;
     const int* row_src; const float* row_grid; const float* row_pe; const float* wpt;
+    // KQ (car_key_query_logits): the layer is key_map (relu behind it); its 128 outputs stay in the accumulators and run on through
+    // key_map_2, while query_embed / query_embed_2 run on the row's 16-float geometric query g; out come qry [M,128] and logit [M]
+    const float* g; const float* tail; const float* tail_bias; float* qry; float* logit;
 };
 
-template <int NT, bool GATHER = false>
+template <int NT, bool GATHER = false, bool KQ = false>
 __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][NT][512] (+ GATHER: the [K][4] point / bias table)
     static_assert(kWaves * pieces_of(NT) <= 3 * 2 * NT, "stream_issue_piece wraps a piece index into the chunk with two subtractions");
@@ -199,6 +206,61 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
         split8(xn, p, bhi, blo);
         stream_sync();
     }
+    if constexpr (KQ) {
+        // ---- key = Wk2 relu(k1) + bk2 ; qry = Wq2 relu(Wq1 g + bq1) + bq2 ; logit = <key, qry> / 16 (models.py:487-491, 529, 533): the fused
+        //      per-sample kernel's closing layers (csrc/car_fused.hip), fed by this kernel's accumulators instead of e's.  The tail's weight chunks
+        //      stream through the two 36 KB buffers that lie over this layer's own (done with: the loop's last barrier has passed).
+        static_assert(NT == kTD, "the key layer has 128 outputs");
+        float* lb = lds + 2 * kChunkTiles * kTile;                     // the tail's bias / scale table
+        for (int k = tid; k < kTailBias; k += kThreads) lb[k] = a.tail_bias[k];
+        stream_issue_all(a.tail, lds, kG_K2, lane, wave);
+        scale_acc<NT>(acc, dW * pinv);                                 // k1, true values (bias included)
+        const float* lsc = lb + 2 * kD;
+        float p2, p2inv;
+        pow2_scale(fmaxf(sample_max<kTD, true>(acc), 1e-30f), p2, p2inv);
+        stream_sync();                                                 // chunk 0 landed, the table is visible
+        f32x4 key[kTD];
+        init_bias<kTD>(key, lb, q4, p2 / lsc[0]);
+        chained_layer<kTD, true, 0, kG_K2>(key, acc, p2, a.tail, lds, lane, wave);
+        scale_acc<kTD>(key, lsc[0] * p2inv);
+        half8 ghi, glo;                                                // B operand of the layer fed by g (k = 16: folded bias)
+        {
+            const float* gl = a.g + lrow * 16 + 8 * (q4 & 1);
+            float gx8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gx8[k] = q4 < 2 ? gl[k] : (q4 == 2 && k == 0) ? 1.0f : 0.0f;
+            float m = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(gx8[k]));
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));                       // >= 1: the bias column
+            pow2_scale(m, p2, p2inv);
+            split8(gx8, p2, ghi, glo);
+        }
+        f32x4 t1[kTD], qv[kTD];
+#pragma unroll
+        for (int t = 0; t < kTD; ++t) t1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stream_issue_all(a.tail, lds, kG_Q1 + 1, lane, wave);
+        small_layer(t1, ghi, glo, lds + kLdsW + (kG_Q1 & 1) * kChunkTiles * kTile + 4 * lane);
+        stream_sync();
+        scale_acc<kTD>(t1, lsc[1] * p2inv);
+        pow2_scale(fmaxf(sample_max<kTD, true>(t1), 1e-30f), p2, p2inv);
+        init_bias<kTD>(qv, lb + kD, q4, p2 / lsc[2]);
+        chained_layer<kTD, true, 0, kG_Q2>(qv, t1, p2, a.tail, lds, lane, wave);
+        scale_acc<kTD>(qv, lsc[2] * p2inv);
+        float dot = 0.0f;
+#pragma unroll
+        for (int t = 0; t < kTD; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dot = fmaf(key[t][r], qv[t][r], dot);
+        dot += __shfl_xor(dot, 16, 64);
+        dot += __shfl_xor(dot, 32, 64);
+        if (row < a.M) {
+            store_rows<kTD>(qv, a.qry + row * kD, q4);
+            if (q4 == 0) a.logit[row] = dot / 16.0f;
+        }
+        return;
+    }
     if (row >= a.M) return;
     scale_acc<NT>(acc, dW * pinv);
     const bool relu_out = (a.flags & CAR_LIN_RELU_OUT) != 0, accum = (a.flags & CAR_LIN_ACCUM) != 0;
@@ -246,16 +308,17 @@ __global__ void pack16x3_kernel(const float* __restrict__ W, int ldw, int K, int
     }
 }
 
-template <int NT, bool GATHER = false>
+template <int NT, bool GATHER = false, bool KQ = false>
 int launch16(const LinArgs& a, int groups, hipStream_t st) {
-    const size_t lds_bytes = (size_t)2 * NT * kTile * sizeof(float) + (GATHER ? (size_t)a.K * 4 * sizeof(float) : 0);
+    const size_t lds_bytes = KQ ? (size_t)(2 * kChunkTiles * kTile + kTailBias) * sizeof(float)
+                                : (size_t)2 * NT * kTile * sizeof(float) + (GATHER ? (size_t)a.K * 4 * sizeof(float) : 0);
     // the LDS reservation is a per-device attribute of the kernel: set it once per (instance, device), not on each of the dozens of
     // launches of a staged forward or training step
     static bool reserved[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !reserved[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)linear16_kernel<NT, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)linear16_kernel<NT, GATHER, KQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) {
             car_set_error("car_linear_x3: cannot reserve %zu bytes of LDS (a gfx950-class device has 160 KB per compute unit): %s", lds_bytes, hipGetErrorString(e));
             return CAR_E_LAUNCH;
@@ -263,7 +326,7 @@ int launch16(const LinArgs& a, int groups, hipStream_t st) {
         if (dev >= 0 && dev < 64) reserved[dev] = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((linear16_kernel<NT, GATHER>), dim3((unsigned)(car_div_up(a.M, kGroupRows) * groups)), dim3(kThreads), lds_bytes, st, a);
+    hipLaunchKernelGGL((linear16_kernel<NT, GATHER, KQ>), dim3((unsigned)(car_div_up(a.M, kGroupRows) * groups)), dim3(kThreads), lds_bytes, st, a);
     CAR_CHECK_LAUNCH("car_linear_x3");
     return CAR_OK;
 }
@@ -329,4 +392,25 @@ extern "C" int car_lattice_encode_linear(const float* lattice, int lat_h, int la
     if (tiles % 8 == 0) return launch16<8, true>(a, tiles / 8, st);
     if (tiles % 4 == 0) return launch16<4, true>(a, tiles / 4, st);
     return launch16<2, true>(a, tiles / 2, st);
+}
+
+// key_map -> relu -> key_map_2, query_embed -> relu -> query_embed_2 and the first round's logits in ONE kernel for the stage route's
+// variants (n_view 1 / 3, no_latent_concat; models.py:487-491, 529, 533): the 128-wide k1, key and q1 rows are never written.
+//   e [M, Ce] (row stride lde): the per-sample features; packed_k1 / bias_k1: key_map as car_linear_x3_pack lays it out (K = Ce, N = 128);
+//   g [M, 16]: the geometric query; tail / tail_bias: car_kq_pack.  Out: qry [M, 128] (the second round reads it), logit [M].
+extern "C" size_t car_kq_tail_floats(void) { return (size_t)kTailTiles * kTile; }
+extern "C" size_t car_kq_bias_floats(void) { return (size_t)kTailBias; }
+extern "C" int car_key_query_logits(const float* e, int lde, const float* packed_k1, const float* bias_k1, int Ce, const float* g, const float* tail,
+                                    const float* tail_bias, long M, float* qry, float* logit, void* stream) {
+    CAR_REQUIRE(e && packed_k1 && bias_k1 && g && tail && tail_bias && qry && logit, "car_key_query_logits: null pointer");
+    CAR_REQUIRE(M > 0 && Ce > 0 && lde % 4 == 0 && lde >= ((Ce + 3) & ~3), "car_key_query_logits: bad sizes (Ce = %d, row stride %d)", Ce, lde);
+    CAR_REQUIRE(((uintptr_t)e & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)qry & 15) == 0 && ((uintptr_t)bias_k1 & 15) == 0,
+                "car_key_query_logits: e, g, qry and the bias must be 16-byte aligned");
+    const int ksteps = (Ce + 31) / 32;
+    LinArgs a{};
+    a.X = e; a.ldx = lde; a.Wp = packed_k1; a.tiles_total = kTD; a.bias = bias_k1;
+    a.down = packed_k1 + (size_t)ksteps * kTD * kTile + 1;
+    a.K = Ce; a.chunks = ksteps; a.Y = nullptr; a.ldy = 0; a.M = M; a.flags = 0;
+    a.g = g; a.tail = tail; a.tail_bias = tail_bias; a.qry = qry; a.logit = logit;
+    return launch16<kTD, false, true>(a, 1, (hipStream_t)stream);
 }

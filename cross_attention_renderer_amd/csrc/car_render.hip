@@ -615,6 +615,35 @@ extern "C" int car_fused_pack(const car_weights* w, float* blob_f, float* bias, 
     return CAR_OK;
 }
 
+// Packs key_map_2, query_embed and query_embed_2 for car_key_query_logits (csrc/car_linear16.hip, the stage route's key / query chain): the
+// fused kernel's operand formats — K2 and Q2 chained over the accumulator order of the layer before, Q1 standard with its bias folded in at
+// k = 16 — in the order the kernel streams them: K2 (32 tiles) | Q1 (8) | Q2 (32).  bias: bk2 [128] | bq2 [128] | 2^-shift of K2, Q1, Q2.
+extern "C" size_t car_kq_tail_floats(void);
+extern "C" size_t car_kq_bias_floats(void);
+extern "C" int car_kq_pack(const float* k2w, const float* k2b, const float* q1w, const float* q1b, const float* q2w, const float* q2b, float* tail,
+                           float* bias, void* stream) {
+    CAR_REQUIRE(k2w && k2b && q1w && q1b && q2w && q2b && tail && bias, "car_kq_pack: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)car_kq_bias_floats();
+    if (hipMemsetAsync(bias, 0, sizeof(float) * nb, st) != hipSuccess) { car_set_error("car_kq_pack: memset failed"); return CAR_E_LAUNCH; }
+    float* down = bias + 2 * kD;                                     // [0..2] 2^-shift of K2, Q1, Q2; [8..10] their 2^shift (pack-time scratch)
+    _Float16* blob = reinterpret_cast<_Float16*>(tail);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(layer_scale_kernel, dim3(1), dim3(1024), 0, st, k2w, kD, kD, kD, (const float*)nullptr, down + 8, down + 0);
+    hipLaunchKernelGGL(layer_scale_kernel, dim3(1), dim3(1024), 0, st, q1w, 16, kD, 16, q1b, down + 9, down + 1);
+    hipLaunchKernelGGL(layer_scale_kernel, dim3(1), dim3(1024), 0, st, q2w, kD, kD, kD, (const float*)nullptr, down + 10, down + 2);
+    hipLaunchKernelGGL(pack16_kernel, dim3(64), dim3(256), 0, st, k2w, kD, (const float*)nullptr, kD, kD, kTD, 4, 1, 0, down + 8, blob);
+    hipLaunchKernelGGL(pack16_kernel, dim3(16), dim3(256), 0, st, q1w, 16, q1b, kD, 16, kTD, 1, 0, 0, down + 9, blob + (size_t)32 * kTile16 * 2);
+    hipLaunchKernelGGL(pack16_kernel, dim3(64), dim3(256), 0, st, q2w, kD, (const float*)nullptr, kD, kD, kTD, 4, 1, 0, down + 10, blob + (size_t)40 * kTile16 * 2);
+    CAR_CHECK_LAUNCH("car_kq_pack");
+    if (hipMemcpyAsync(bias, k2b, sizeof(float) * kD, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(bias + kD, q2b, sizeof(float) * kD, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        car_set_error("car_kq_pack: bias copy failed");
+        return CAR_E_LAUNCH;
+    }
+    return CAR_OK;
+}
+
 // Packs query_repeat_embed (its local_coords half, columns 128..143 of the (128, 144) matrix `wr1`) and query_repeat_embed_2 for
 // csrc/car_round2.hip; same conventions as car_fused_pack.
 extern "C" int car_round2_pack(const float* wr1, const float* br1, const float* wr2, const float* br2, float* wpacked, float* bias, void* stream) {

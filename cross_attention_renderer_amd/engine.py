@@ -100,6 +100,9 @@ class RenderEngine:
         # one-call route: the first attention round folds the fused kernel's per-step-group partial sums (default); False = it streams
         # the rows of e as in rounds 1-4 (CAR_PHASE_ROWS_FIRST_ROUND: A/B measurements and tests)
         self.first_round_parts = True
+        self.fuse_kq = True            # staged route: key / query chains and the first round's logits in one kernel (car_key_query_logits); False = five launches (A/B)
+        self._kq = None
+        self._kq_key = None
         self.fuse_exchange = True      # three-view exchange: first + second layer in one kernel (car_lattice_encode_linear); False = two launches (A/B)
         # sizing of the one-call route (tests shrink them to force several calls)
         self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
@@ -296,6 +299,21 @@ class RenderEngine:
             _lib.check(lib.car_round2_pack(_ptr(f[0]), _ptr(f[1]), _ptr(f[2]), _ptr(f[3]), _ptr(w), _ptr(bz), _stream()), "car_round2_pack")
             self._round2, self._round2_key = (w, bz), key
         return self._round2
+
+    def _kq_weights(self, device):
+        """key_map_2, query_embed and query_embed_2 packed for the key / query chain kernel (car_kq_pack)."""
+        m = self.m
+        ps = (m.key_map_2.weight, m.key_map_2.bias, m.query_embed.weight, m.query_embed.bias, m.query_embed_2.weight, m.query_embed_2.bias)
+        key = tuple((t.data_ptr(), t._version) for t in ps) + (str(device),)
+        if key != self._kq_key:
+            lib = self.lib
+            f = [t.detach().to(device=device, dtype=torch.float32).reshape(t.shape[0], -1).contiguous() if t.dim() > 1
+                 else t.detach().to(device=device, dtype=torch.float32).contiguous() for t in ps]
+            tail = torch.empty(lib.car_kq_tail_floats(), device=device, dtype=torch.float32)
+            bias = torch.empty(lib.car_kq_bias_floats(), device=device, dtype=torch.float32)
+            _lib.check(lib.car_kq_pack(*[_ptr(t) for t in f], _ptr(tail), _ptr(bias), _stream()), "car_kq_pack")
+            self._kq, self._kq_key = (tail, bias), key
+        return self._kq
 
     # ------------------------------------------------------------------ the one-call route (default configuration)
     def _dims(self, b: int, R: int, z: List[Tensor]) -> "_lib.CarDims":
@@ -679,12 +697,24 @@ class RenderEngine:
         # a12: keys;  a13: geometric query.  The value projection (latent_value, no nonlinearity before the weighted sum)
         # commutes with the attention average: sum_s w_s (Wv e_s + bv) = Wv (sum_s w_s e_s) + bv because the softmax
         # weights of a ray sum to 1, so it is applied once per ray after the reduction instead of once per sample.
+        kmap = pk["key_map.kmajor" if kmajor else "key_map"]
+        q = torch.empty(S, 128, **f32)
+        if (self.fuse_kq and self.linear_x3 and not self.linear_flags and kmap.x3 is not None and kmap.N == 128 and m.hidden_dim == 128
+                and Ce % 4 == 0 and e.data_ptr() % 16 == 0 and S >= self.linear_x3_min_rows):
+            # key_map -> relu -> key_map_2, query_embed -> relu -> query_embed_2 and the first round's logits in one kernel: the 128-wide
+            # k1 / key / q1 rows are never written (csrc/car_linear16.hip, KQ instance)
+            tiles, bias_k1 = kmap.x3
+            tail, tail_bias = self._kq_weights(dev)
+            logit1 = torch.empty(S, **f32)
+            _lib.check(lib.car_key_query_logits(_ptr(e), Ce, _ptr(tiles), _ptr(bias_k1), Ce, _ptr(g), _ptr(tail), _ptr(tail_bias), S, _ptr(q),
+                                                _ptr(logit1), st), "car_key_query_logits")
+            return self._finish(inp, z, b, V, R, P, Ce, Dl, e, None, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug, kmajor,
+                                logit1=logit1)
         k1 = torch.empty(S, 128, **f32)
-        self.linear(e, Ce, pk["key_map.kmajor" if kmajor else "key_map"], k1, 128, S, RELU_OUT)
+        self.linear(e, Ce, kmap, k1, 128, S, RELU_OUT)
         key = torch.empty(S, 128, **f32)
         self.linear(k1, 128, pk["key_map_2"], key, 128, S)
         self.linear(g, 16, pk["query_embed"], k1, 128, S, RELU_OUT)
-        q = torch.empty(S, 128, **f32)
         self.linear(k1, 128, pk["query_embed_2"], q, 128, S)
 
         return self._finish(inp, z, b, V, R, P, Ce, Dl, e, key, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug, kmajor)
@@ -811,7 +841,7 @@ class RenderEngine:
         # channel index = ch*3 + k (torch.cat on dim 2 then flatten(1, 2), models.py:446)
         return enc.view(S, 3, C // 2).permute(0, 2, 1).contiguous().view(S, 3 * (C // 2))
 
-    def _finish(self, inp, z, b, V, R, P, Ce, Dl, e, key, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug, kmajor=False):
+    def _finish(self, inp, z, b, V, R, P, Ce, Dl, e, key, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug, kmajor=False, logit1=None):
         """Attention rounds, decoder and output dict of the staged route; ``g`` is the geometric
         query local_coords [S,16]."""
         m, lib = self.m, self.lib
@@ -829,8 +859,12 @@ class RenderEngine:
         amax = torch.empty(n, R, dtype=torch.int32, device=dev)
         rep = m.repeat_attention
         ebar = torch.empty(b * R, Ce, **f32)
-        _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt), _ptr(ebar),
-                                  Ce, 1, _ptr(pt), _ptr(poses), _ptr(depth), _ptr(amax), st), "car_attend")
+        if logit1 is not None:                             # the logits came out of car_key_query_logits
+            _lib.check(lib.car_attend(_ptr(logit1), None, 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt), _ptr(ebar),
+                                      Ce, 1, _ptr(pt), _ptr(poses), _ptr(depth), _ptr(amax), st), "car_attend")
+        else:
+            _lib.check(lib.car_attend(_ptr(key), _ptr(q), 128, _ptr(e), Ce, b, V, R, P, None, 0.0, _ptr(at_wt), _ptr(ebar),
+                                      Ce, 1, _ptr(pt), _ptr(poses), _ptr(depth), _ptr(amax), st), "car_attend")
         zrep = torch.empty(b * R, V * Dl, **f32)
         at_wt2 = None
         if rep:
@@ -852,6 +886,8 @@ class RenderEngine:
                                           _ptr(ebar), Ce, 1, None, None, None, None, st), "car_attend")
             else:
                 k1 = torch.empty(S, 128, **f32)
+                if key is None:
+                    key = torch.empty(S, 128, **f32)
                 self.linear(g, 16, pk["query_repeat_embed.g"], k1, 128, S)
                 _lib.check(lib.car_add_ray_bias_relu(_ptr(k1), _ptr(uh), b, V, R, P, 128, st), "car_add_ray_bias_relu")
                 self.linear(k1, 128, pk["query_repeat_embed_2"], key, 128, S)

@@ -196,6 +196,19 @@ int car_linear_x3_pack(const float* W, int ldw, int K, int N, float* packed, voi
 int car_linear_x3(const float* X, int ldx, const float* packed, const float* bias, int K, int N, float* Y, int ldy, long M, int flags,
                   void* stream);
 
+/* ---- a12 + a13 + the logits of a14 for the stage route's variants (n_view 1 / 3, no_latent_concat): key = key_map_2(relu(key_map(e))),
+ * qry = query_embed_2(relu(query_embed(g))), logit = <key, qry> / 16 (models.py:487-491, 529, 533) in ONE kernel — the gather-free instance of
+ * csrc/car_linear16.hip's layer (key_map over the rows of e, split fp16 x 3) whose 128 outputs stay in the accumulators and run through the
+ * fused per-sample kernel's closing layers; the 128-wide k1, key and q1 rows are never written.  e [M, Ce] (row stride lde, a multiple of 4),
+ * g [M, 16]; packed_k1 / bias_k1: key_map laid out by car_linear_x3_pack (K = Ce, N = 128) and its bias; tail [car_kq_tail_floats()] /
+ * tail_bias [car_kq_bias_floats()]: key_map_2, query_embed, query_embed_2 packed by car_kq_pack.  Out: qry [M, 128], logit [M]. */
+size_t car_kq_tail_floats(void);
+size_t car_kq_bias_floats(void);
+int car_kq_pack(const float* k2w, const float* k2b, const float* q1w, const float* q1b, const float* q2w, const float* q2b, float* tail,
+                float* bias, void* stream);
+int car_key_query_logits(const float* e, int lde, const float* packed_k1, const float* bias_k1, int Ce, const float* g, const float* tail,
+                         const float* tail_bias, long M, float* qry, float* logit, void* stream);
+
 /* ---- a14-a16: per-ray softmax attention over the V*P samples (models.py:532-594)
  * qa, qb [b*V,R,P,dq] (row stride dq): logit = <qa,qb>/16; with qb == NULL, qa is the precomputed logit [b*V,R,P]
  * (dq ignored).  val [b*V,R,P,D].

@@ -265,6 +265,25 @@ def case_attend(R, P, V, D, tail=True):
                                "car_attend"), t, ["w", "z"], tail)
 
 
+def case_kq(M, Ce, tail=True):
+    """car_key_query_logits: rows of e and g, the packed layers, qry and logit."""
+    lib = L.load()
+    g_ = torch.Generator().manual_seed(M + Ce)
+    rnd = lambda *sh: torch.randn(*sh, generator=g_).to(dev)
+    k1w = rnd(128, Ce) / Ce ** 0.5
+    tiles = torch.empty(lib.car_linear_x3_packed_floats(Ce, 128), device=dev)
+    L.check(lib.car_linear_x3_pack(ctypes.c_void_p(k1w.data_ptr()), Ce, Ce, 128, ctypes.c_void_p(tiles.data_ptr()), stream()), "pack")
+    tailw = torch.empty(lib.car_kq_tail_floats(), device=dev)
+    tb = torch.empty(lib.car_kq_bias_floats(), device=dev)
+    ws = [rnd(128, 128) / 11, rnd(128), rnd(128, 16) / 4, rnd(128), rnd(128, 128) / 11, rnd(128)]
+    L.check(lib.car_kq_pack(*[ctypes.c_void_p(t.data_ptr()) for t in ws], ctypes.c_void_p(tailw.data_ptr()), ctypes.c_void_p(tb.data_ptr()), stream()), "car_kq_pack")
+    torch.cuda.synchronize()
+    t = {"e": rnd(M, Ce), "tiles": tiles, "k1b": rnd(128), "g": rnd(M, 16), "tailw": tailw, "tb": tb, "qry": torch.zeros(M, 128, device=dev),
+         "logit": torch.zeros(M, device=dev)}
+    run_both(lambda p: L.check(lib.car_key_query_logits(p("e"), Ce, p("tiles"), p("k1b"), Ce, p("g"), p("tailw"), p("tb"), M, p("qry"), p("logit"), stream()),
+                               "car_key_query_logits"), t, ["qry", "logit"], tail)
+
+
 def case_wgrad(M, N, K, flags, tail=True):
     """car_linear_wgrad: dY, X read; dW, db accumulated (the bf16 x 3 kernel for wide layers over >= 4096 rows, else the fp32 pipe's)."""
     lib = L.load()
@@ -316,6 +335,8 @@ CASES = {
     "exchange_ragged": lambda tail: case_exchange(193, 128, tail),
     "attend_864": lambda tail: case_attend(37, 13, 3, 864, tail),
     "attend_100": lambda tail: case_attend(20, 8, 2, 100, tail),
+    "kq_864": lambda tail: case_kq(4099, 864, tail),
+    "kq_ragged": lambda tail: case_kq(193, 96, tail),
     "wgrad16_579": lambda tail: case_wgrad(4133, 576, 579, 1, tail),
     "wgrad16_ragged": lambda tail: case_wgrad(4100, 200, 130, 0, tail),
     "wgrad_fp32": lambda tail: case_wgrad(513, 576, 579, 0, tail),
@@ -328,7 +349,7 @@ FAMILIES = {
     "gather": ["gather_wave", "gather_quad", "gather_zeros"],
     "fused": ["fused_37_13", "fused_48_8_b2"],
     "tail": ["tail_37_13", "tail_96_32_b2", "attend_864", "attend_100"],
-    "exchange": ["exchange_288", "exchange_ragged"],
+    "exchange": ["exchange_288", "exchange_ragged", "kq_864", "kq_ragged"],
     "wgrad": ["wgrad16_579", "wgrad16_ragged", "wgrad_fp32", "wgrad_small"],
 }
 

@@ -836,6 +836,59 @@ def test_three_view_route_with_fused_exchange_equals_two_launches():
     _check_outputs(outs[0], lambda k: ora[k], "fused exchange vs oracle")
 
 
+@pytest.mark.parametrize("M,Ce", [(5000, 576), (4099, 864), (8192, 288), (193, 96)])
+def test_key_query_chain_kernel_matches_the_separate_layers(M, Ce):
+    """car_key_query_logits (key_map -> relu -> key_map_2, query_embed -> relu -> query_embed_2, <key, qry> / 16 in one kernel) against
+    fp64 matmuls of the same layers: qry and the logits at the fp32-class bound of the split-fp16 layers, ragged row counts, the widths of
+    the one-, two- and three-view routes."""
+    from cross_attention_renderer_amd import _lib as L
+    lib = _lib()
+    dev = torch.device("cuda:0")
+    g_ = torch.Generator().manual_seed(M + Ce)
+    rnd = lambda *sh: torch.randn(*sh, generator=g_)
+    e = (rnd(M, Ce) * torch.logspace(-3, 2, M).unsqueeze(1)).to(dev)            # rows of very different magnitude
+    gq = rnd(M, 16).to(dev)
+    k1w, k1b = (rnd(128, Ce) / Ce ** 0.5).to(dev), rnd(128).to(dev)
+    k2w, k2b = (rnd(128, 128) / 128 ** 0.5).to(dev), rnd(128).to(dev)
+    q1w, q1b = (rnd(128, 16) / 4).to(dev), rnd(128).to(dev)
+    q2w, q2b = (rnd(128, 128) / 128 ** 0.5).to(dev), rnd(128).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tiles = torch.empty(lib.car_linear_x3_packed_floats(Ce, 128), device=dev)
+    L.check(lib.car_linear_x3_pack(_ptr(k1w), Ce, Ce, 128, _ptr(tiles), st), "pack")
+    tail = torch.empty(lib.car_kq_tail_floats(), device=dev)
+    tb = torch.empty(lib.car_kq_bias_floats(), device=dev)
+    L.check(lib.car_kq_pack(_ptr(k2w), _ptr(k2b), _ptr(q1w), _ptr(q1b), _ptr(q2w), _ptr(q2b), _ptr(tail), _ptr(tb), st), "car_kq_pack")
+    qry = torch.full((M, 128), float("nan"), device=dev)
+    logit = torch.full((M,), float("nan"), device=dev)
+    L.check(lib.car_key_query_logits(_ptr(e), Ce, _ptr(tiles), _ptr(k1b), Ce, _ptr(gq), _ptr(tail), _ptr(tb), M, _ptr(qry), _ptr(logit), st),
+            "car_key_query_logits")
+    torch.cuda.synchronize()
+    d = lambda t: t.double()
+    k1 = torch.relu(d(e) @ d(k1w).T + d(k1b))
+    key = k1 @ d(k2w).T + d(k2b)
+    q = torch.relu(d(gq) @ d(q1w).T + d(q1b)) @ d(q2w).T + d(q2b)
+    want = (key * q).sum(1) / 16
+    qb = torch.relu(d(gq) @ d(q1w).T + d(q1b)).abs() @ d(q2w).abs().T + d(q2b).abs()
+    assert ((d(qry) - q).abs() / qb).max().item() < 4e-6
+    kb = k1.abs() @ d(k2w).abs().T + d(k2b).abs()
+    bound = (kb * q.abs()).sum(1) / 16 + (key.abs() * qb).sum(1) / 16
+    assert torch.isfinite(logit).all()
+    assert ((d(logit) - want).abs() / bound).max().item() < 8e-6
+
+
+@pytest.mark.parametrize("name", ["t1_nview1", "t1_nview3", "t1_no_latent_concat"])
+def test_staged_route_with_the_key_query_chain_kernel_equals_the_separate_layers(name):
+    """The stage route's default (car_key_query_logits) against its five-launch form: attention weights and rgb to fp32 rounding; both
+    against the oracle at the contract."""
+    c, fx, ora, a = run_case(name)
+    _, _, _, b_ = run_case(name, engine_setup=lambda e: setattr(e, "fuse_kq", False))
+    assert rel_err(a["at_wt"], b_["at_wt"]) < 1e-5
+    assert rel_err(a["rgb"], b_["rgb"]) < 2e-5
+    assert torch.equal(a["valid_mask"], b_["valid_mask"])
+    _check_outputs(b_, lambda k: ora[k], "five launches vs oracle")
+    _check_outputs(a, lambda k: ora[k], "key / query chain kernel vs oracle")
+
+
 def test_project_maps_records_the_lattice_maximum():
     """car_project_maps takes the largest |lattice value| inside the merge kernel (it used to be a second pass over the 2.5 GB): gmeta[0]
     must be exactly the maximum of the lattice it wrote."""
