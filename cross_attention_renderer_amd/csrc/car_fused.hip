@@ -84,6 +84,10 @@ struct FusedArgs {
     float* pt;
     float* pixel_val;
     float* part;               // [b*V][R][ceil(P / kTileSteps)][kC]: per (ray, step group) sum_j exp(logit_j - max_j logit) e_j, or NULL
+    // ROWS instance (car_fused_rows, the three-view exchange): explicit rows instead of the kernel's own geometry — row = sample * ncomp + comp
+    // gathers map (row_src & 0x3fffffff), padding mode (row_src >> 30) & 1 at row_grid [2] and adds the point term of row_pe [4]; a workgroup's 192
+    // rows are 24 rays x 8 steps of ONE (sample set, component): its rows share their map and padding mode
+    const int* row_src; const float* row_grid; const float* row_pe; int ncomp;
 };
 
 // chunk order:  W2 x18 (source 0) | W2 x18 (source 1) | K1 over e_1 x5 (2,2,2,2,1 K steps) | K1 over e_0 x5 | K2 x2 | Q1 | Q2 x2
@@ -125,7 +129,9 @@ __device__ __forceinline__ NextChunk next_chunk_w2(const float* __restrict__ blo
 // 22: every tap inside a 1 MB window of its lattice (L2 hits); 28: inside 32 nodes (L1 hits); 23: no weight DMA (barriers kept); 24 = 22 + 23;
 // 30-33: the weight DMA with cache-policy bits nt / sc1 / sc0 sc1 / sc0; 40-43: waves leaving the barrier apart, taps spread over the slots;
 // 50-53: the chunk loop without slot fences, vector / LDS instructions interleaved under the MFMAs by sched_group_barrier (results stay right)
-template <int ABL>
+// ROWS: one source pass over explicit rows, e_0 = W2 relu(h) + b2 written [row][kE], nothing else (the three-view exchange's two layers,
+// models.py:345-475 through engine._encode_three_views); the chunk loop is the product kernel's own
+template <int ABL, bool ROWS = false>
 __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -141,7 +147,9 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     // the tile's sample of (wave, row lane & 15): tile_ray / tile_step above; the 8 rows a tap instruction gathers are one step of
     // neighbouring rays (shared lattice rows)
     const int pgs = (a.P + kTileSteps - 1) / kTileSteps, bundles = (a.R + kTileRays - 1) / kTileRays;
-    const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
+    const int pg = blk % pgs, bun = (blk / pgs) % bundles;
+    const int nset = blk / (pgs * bundles);                            // ROWS: (sample set, component)
+    const int nn = ROWS ? nset / a.ncomp : nset, comp = ROWS ? nset % a.ncomp : 0;
     const int ray_i = bun * kTileRays + tile_ray(wave, s), pp = pg * kTileSteps + tile_step(wave, s);
     const bool live = ray_i < a.R && pp < a.P;
     const long i = ((long)nn * a.R + (ray_i < a.R ? ray_i : a.R - 1)) * a.P + (pp < a.P ? pp : a.P - 1);
@@ -174,6 +182,31 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     // ---- geometry: the 192 samples of the group are spread over the 192 lanes of waves 0-2 (one sample per lane, both source views),
     //      instead of every wave repeating its 16 samples in four lane groups: a third of the issue time on the critical path ----
     const int P = a.P, V = a.V;
+    int rows_mode = 0, rows_map = 0;                                   // ROWS: the workgroup's (map, padding mode)
+    if constexpr (ROWS) {
+        if (wave < kGroup / 64) {
+            const int sg = wave * 64 + lane, gwv = sg >> 4, gs = sg & 15;
+            const int g_ray = bun * kTileRays + tile_ray(gwv, gs), g_pp = pg * kTileSteps + tile_step(gwv, gs);
+            const long gi = ((long)nn * a.R + (g_ray < a.R ? g_ray : a.R - 1)) * a.P + (g_pp < a.P ? g_pp : a.P - 1);
+            const long row = gi * a.ncomp + comp;
+            const int mode = (a.row_src[row] >> 30) & 1;
+            int node, flags;
+            float w[4];
+            car_lattice_taps(a.row_grid[2 * row], a.row_grid[2 * row + 1], a.lw, a.lh, a.pad, a.sx, a.sy, &node, &flags, w);
+            const bool dead = mode == 1 && (flags & 4);
+            reinterpret_cast<unsigned*>(lds + kLdsTapB)[sg * 2 + 0] = dead ? kDeadTap : (unsigned)node * (unsigned)(kC * 4);
+            reinterpret_cast<unsigned*>(lds + kLdsTapB)[sg * 2 + 1] = kDeadTap;           // the loop's prefetch past the pass: no memory access
+            *reinterpret_cast<float4*>(lds + kLdsTapW + (sg * 2 + 0) * 4) =
+                dead ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(w[0] * hp, w[1] * hp, w[2] * hp, w[3] * hp);
+            *reinterpret_cast<float4*>(lds + kLdsTapW + (sg * 2 + 1) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + 0) * 4) = make_float4(a.row_pe[4 * row] * hp, a.row_pe[4 * row + 1] * hp, a.row_pe[4 * row + 2] * hp, 0.0f);
+            *reinterpret_cast<float4*>(lds + kLdsPe + (sg * 2 + 1) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const long gi0 = ((long)nn * a.R + (bun * kTileRays < a.R ? bun * kTileRays : a.R - 1)) * a.P + (pg * kTileSteps < a.P ? pg * kTileSteps : a.P - 1);
+        const int src0 = a.row_src[gi0 * a.ncomp + comp];              // uniform over the workgroup by construction of the row list
+        rows_map = __builtin_amdgcn_readfirstlane(src0 & 0x3fffffff);
+        rows_mode = __builtin_amdgcn_readfirstlane((src0 >> 30) & 1);
+    } else
     if (wave < kGroup / 64) {
         const int sg = wave * 64 + lane, gwv = sg >> 4, gs = sg & 15;     // sample sg belongs to row gs of matrix wave gwv
         const int g_ray = bun * kTileRays + tile_ray(gwv, gs), g_pp = pg * kTileSteps + tile_step(gwv, gs);
@@ -251,11 +284,11 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     // zero-padded lattice of view sv otherwise — one descriptor per source pass, 32-bit offsets inside it.
     const int v_own = nn % a.V, sc_own = nn / a.V;
     const long map_floats = (long)a.lh * a.lw * kC;
+    const long lat0 = ROWS ? ((long)rows_map * 2 + rows_mode) * map_floats : ((long)(sc_own * a.V + 0) * 2 + (v_own == 0 ? 0 : 1)) * map_floats;
+    const long lat1 = ROWS ? lat0 : ((long)(sc_own * a.V + 1) * 2 + (v_own == 1 ? 0 : 1)) * map_floats;
     const __amdgpu_buffer_rsrc_t rsrc[2] = {
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lattice + ((long)(sc_own * a.V + 0) * 2 + (v_own == 0 ? 0 : 1)) * map_floats), 0,
-                                          (int)a.map_bytes, 0x00027000),
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lattice + ((long)(sc_own * a.V + 1) * 2 + (v_own == 1 ? 0 : 1)) * map_floats), 0,
-                                          (int)a.map_bytes, 0x00027000)};
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lattice + lat0), 0, (int)a.map_bytes, 0x00027000),
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lattice + lat1), 0, (int)a.map_bytes, 0x00027000)};
     auto issue_row = [&](f32x4 (&tap)[4], int sv, int c, int it) {
         if constexpr (ABL == 1 || ABL == 2 || ABL == 3 || ABL == 12) return;
         const int chunk_off = 128 * c;                                 // the chunk's 32 channels: scalar offset, not range-checked
@@ -351,7 +384,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     half8 bhi, blo;
     read_b(bhi, blo);
 #pragma unroll 1
-    for (int sv = 0; sv < 2; ++sv) {
+    for (int sv = 0; sv < (ROWS ? 1 : 2); ++sv) {
         init_bias<kTE>(acc, lds + kLdsBias + kBiasE, q4, e_up);
 #pragma unroll 1
         for (int c = 0; c < kKS; ++c) {
@@ -503,10 +536,16 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
                     const int ray_r = bun * kTileRays + tile_ray(wave, rr), pp_r = pg * kTileSteps + tile_step(wave, rr);
                     const long i_r = ((long)nn * a.R + (ray_r < a.R ? ray_r : a.R - 1)) * a.P + (pp_r < a.P ? pp_r : a.P - 1);
                     const float4 v = *reinterpret_cast<const float4*>(stage + rr * kStageLd + 4 * qd);
+                    if constexpr (ROWS) *reinterpret_cast<float4*>(a.e + (i_r * a.ncomp + comp) * kE + 32 * m + 4 * qd) = v;
+                    else
                     *reinterpret_cast<float4*>(a.e + i_r * (2 * kE) + 32 * m + 4 * qd) = v;      // rows past the end: duplicates, same values
                 }
             }
         }
+    }
+    if constexpr (ROWS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the prefetched taps of a pass that does not exist
+        return;
     }
     // ---- k1 = Wk1 [e_0 ; e_1] + bk1: first the e_1 half, chained from the accumulators (each K step's two tiles are stored as soon
     //      as they are consumed); then the e_0 half, whose B operands come back from the output tensor (written by this wave one source
@@ -830,3 +869,34 @@ extern "C" int car_fused_samples_sliced(int nblk, const float* poses, const floa
     return CAR_OK;
 }
 #endif
+
+// The three-view exchange's two layers for explicit rows (models.py:345-475 through engine._encode_three_views): the ROWS instance of the fused
+// per-sample kernel — its source pass, one per (sample set, component), nothing behind it.  rows = n_sets * R * P * ncomp, row = sample * ncomp +
+// comp; e [rows][288].  lattice [n_maps][2][lat_h][lat_w][576] (car_merge_lattice), gmeta [1] = its largest magnitude; blob / bias / wpt:
+// car_fused_pack_rows.  Every 24-ray x 8-step tile of a (set, component) must share its (map, padding mode) — true for the exchange's row list.
+extern "C" int car_fused_rows(const float* lattice, int lat_h, int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob,
+                              const float* bias, const int* row_src, const float* row_grid, const float* row_pe, int n_sets, int R, int P, int ncomp,
+                              float* e, void* stream) {
+    CAR_REQUIRE(lattice && gmeta && wpt && blob && bias && row_src && row_grid && row_pe && e, "car_fused_rows: null pointer");
+    CAR_REQUIRE(n_sets > 0 && R > 0 && P > 0 && ncomp > 0, "car_fused_rows: bad sizes");
+    CAR_REQUIRE(lat_pad >= 2 && lat_h > 2 * lat_pad + 1 && lat_w > 2 * lat_pad + 1 && ((lat_h - 2 * lat_pad) & 1) && ((lat_w - 2 * lat_pad) & 1),
+                "car_fused_rows: bad lattice %d x %d, pad %d (car_merge_lattice)", lat_h, lat_w, lat_pad);
+    CAR_REQUIRE((long)lat_h * lat_w * (kC * 4) < kMaxMapBytes, "car_fused_rows: a lattice of %d x %d nodes exceeds 2 GiB per map and padding mode", lat_h, lat_w);
+    FusedArgs a{};
+    a.lattice = lattice; a.lh = lat_h; a.lw = lat_w; a.pad = lat_pad;
+    a.map_bytes = (unsigned)((long)lat_h * lat_w * (kC * 4));
+    a.sx = (float)((lat_w - 2 * lat_pad + 1) / 2); a.sy = (float)((lat_h - 2 * lat_pad + 1) / 2);
+    a.gmeta = gmeta; a.wpt = wpt; a.blob = blob; a.bias = bias;
+    a.b = n_sets; a.V = 1; a.R = R; a.P = P;
+    a.S = (long)n_sets * R * P;
+    a.e = e;
+    a.row_src = row_src; a.row_grid = row_grid; a.row_pe = row_pe; a.ncomp = ncomp;
+    const long groups = (long)n_sets * ncomp * car_div_up(R, kTileRays) * car_div_up(P, kTileSteps);
+    void (*kern)(const FusedArgs) = fused_kernel<0, true>;
+    hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    if (e1 != hipSuccess) { car_set_error("car_fused_rows: cannot reserve %zu bytes of LDS: %s", kLdsBytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a);
+    CAR_CHECK_LAUNCH("car_fused_rows");
+    return CAR_OK;
+}

@@ -615,6 +615,29 @@ extern "C" int car_fused_pack(const car_weights* w, float* blob_f, float* bias, 
     return CAR_OK;
 }
 
+// The first two point-MLP layers alone, for car_fused_rows (the three-view exchange): W2 in the fused kernel's operand tiles with its power
+// of two, b2 and the scales in the bias table, the [C][4] point / bias table of the first layer with its largest row sum.  Same formats
+// as car_fused_pack; the other layers' regions of blob / bias stay zero.
+extern "C" int car_fused_pack_rows(const float* w1, const float* b1, const float* w2, const float* b2, float* blob_f, float* bias, float* wpt, void* stream) {
+    CAR_REQUIRE(w1 && b1 && w2 && b2 && blob_f && bias && wpt, "car_fused_pack_rows: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(bias, 0, sizeof(float) * kBiasFloats, st) != hipSuccess) { car_set_error("car_fused_pack_rows: memset failed"); return CAR_E_LAUNCH; }
+    _Float16* blob = reinterpret_cast<_Float16*>(blob_f);
+    float* fdown = bias + kBiasScale;
+    float* pscale = bias + kBiasScale + 8;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(layer_scale_kernel, dim3(1), dim3(1024), 0, st, w2, kC, kE, kC, (const float*)nullptr, pscale + kLayerW2, fdown + kLayerW2);
+    hipLaunchKernelGGL(pack16_kernel, dim3(256), dim3(256), 0, st, w2, kC, (const float*)nullptr, kE, kC, kTE, kKS, 0, 0, pscale + kLayerW2,
+                       blob + (size_t)kOffW2 * kTile16 * 2);
+    hipLaunchKernelGGL(wpt_kernel, dim3(1), dim3(kC), 0, st, w1, b1, wpt, fdown + 5);
+    CAR_CHECK_LAUNCH("car_fused_pack_rows");
+    if (hipMemcpyAsync(bias + kBiasE, b2, sizeof(float) * kE, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        car_set_error("car_fused_pack_rows: bias copy failed");
+        return CAR_E_LAUNCH;
+    }
+    return CAR_OK;
+}
+
 // Packs key_map_2, query_embed and query_embed_2 for car_key_query_logits (csrc/car_linear16.hip, the stage route's key / query chain): the
 // fused kernel's operand formats — K2 and Q2 chained over the accumulator order of the layer before, Q1 standard with its bias folded in at
 // k = 16 — in the order the kernel streams them: K2 (32 tiles) | Q1 (8) | Q2 (32).  bias: bk2 [128] | bq2 [128] | 2^-shift of K2, Q1, Q2.

@@ -103,7 +103,12 @@ class RenderEngine:
         self.fuse_kq = True            # staged route: key / query chains and the first round's logits in one kernel (car_key_query_logits); False = five launches (A/B)
         self._kq = None
         self._kq_key = None
-        self.fuse_exchange = True      # three-view exchange: first + second layer in one kernel (car_lattice_encode_linear); False = two launches (A/B)
+        # three-view exchange, first + second layer: "rows" = the fused per-sample kernel's source pass over the rows (car_fused_rows, default);
+        # True = the gather-fed linear kernel (car_lattice_encode_linear); False = two launches (A/B partners)
+        self.fuse_exchange = "rows"
+        self._xlat_gmeta = None
+        self._xpack = None
+        self._xpack_key = None
         # sizing of the one-call route (tests shrink them to force several calls)
         self.max_workspace_bytes: Optional[int] = None     # None: 85 % of the free device memory
         self.max_level_bytes: Optional[int] = None         # tests: lattice bytes of one call (forces scene groups); None = no limit
@@ -299,6 +304,22 @@ class RenderEngine:
             _lib.check(lib.car_round2_pack(_ptr(f[0]), _ptr(f[1]), _ptr(f[2]), _ptr(f[3]), _ptr(w), _ptr(bz), _stream()), "car_round2_pack")
             self._round2, self._round2_key = (w, bz), key
         return self._round2
+
+    def _exchange_pack(self, device):
+        """query_encode_latent (its point columns and bias) and query_encode_latent_2 packed for car_fused_rows (car_fused_pack_rows)."""
+        m = self.m
+        ps = (m.query_encode_latent.weight, m.query_encode_latent.bias, m.query_encode_latent_2.weight, m.query_encode_latent_2.bias)
+        key = tuple((t.data_ptr(), t._version) for t in ps) + (str(device),)
+        if key != self._xpack_key:
+            lib = self.lib
+            f = [t.detach().to(device=device, dtype=torch.float32).reshape(t.shape[0], -1).contiguous() if t.dim() > 1
+                 else t.detach().to(device=device, dtype=torch.float32).contiguous() for t in ps]
+            blob = torch.zeros(lib.car_fused_blob_floats(), device=device, dtype=torch.float32)
+            bias = torch.empty(lib.car_fused_bias_floats(), device=device, dtype=torch.float32)
+            wpt = torch.empty(576 * 4, device=device, dtype=torch.float32)
+            _lib.check(lib.car_fused_pack_rows(*[_ptr(t) for t in f], _ptr(blob), _ptr(bias), _ptr(wpt), _stream()), "car_fused_pack_rows")
+            self._xpack, self._xpack_key = (blob, bias, wpt), key
+        return self._xpack
 
     def _kq_weights(self, device):
         """key_map_2, query_embed and query_embed_2 packed for the key / query chain kernel (car_kq_pack)."""
@@ -784,6 +805,17 @@ class RenderEngine:
             ws = (ctypes.c_int * L)(*[g.shape[2] for g in gmaps])
             lat = self._exchange_lattice(gmaps, ptrs, hs, ws, n, C, dev)
             layer2 = pk["query_encode_latent_2"]
+            if lat is not None and self.fuse_exchange == "rows" and not self.linear_flags and C == 576:
+                # the fused per-sample kernel's source pass over the exchange's rows (car_fused_rows): its gather machinery and W2 in one
+                # launch, e written [S, 3, 288]; the lattice's largest magnitude (the first layer's fp16 scale) is taken once per lattice
+                lattice, lh, lw, lpad = lat
+                if self._xlat_gmeta is None or self._xlat_gmeta[0] is not lattice:
+                    self._xlat_gmeta = (lattice, lattice.abs().max().reshape(1).contiguous())
+                blob, fbias, fwpt = self._exchange_pack(dev)
+                enc = torch.empty(S * 3, C // 2, **f32)
+                _lib.check(self.lib.car_fused_rows(_ptr(lattice), lh, lw, lpad, _ptr(self._xlat_gmeta[1]), _ptr(fwpt), _ptr(blob), _ptr(fbias), _ptr(src),
+                                                   _ptr(rgrid), _ptr(rpe), n, R, P, 3, _ptr(enc), _stream()), "car_fused_rows")
+                return enc.view(S, 3 * (C // 2))
             if lat is not None and self.fuse_exchange and self.linear_x3 and not self.linear_flags and layer2.x3 is not None:
                 # first AND second exchange layer in one kernel: the lattice rows are gathered 32 channels at a time into the matrix pipe's
                 # operands, the 576-wide rows (2.3 KB x 3 S) are never written (csrc/car_linear16.hip, GATHER instance; bit-identical

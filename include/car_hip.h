@@ -168,6 +168,15 @@ int car_fused_samples(const float* poses, const float* rays, const float* steps,
  * consecutive steps) in `part` [b*V][R][ceil(P / tile_steps)][576]: sum_j exp(logit_j - m) e_j over the group's samples, m their largest
  * logit — each workgroup reads the rows of e it has just written back from L2, an eighth of the bytes the attention launch would
  * otherwise stream from HBM.  car_attend_parts (below) folds a ray's groups together; models.py:533-541. */
+/* The kernel's source pass alone, over explicit rows (the three-view exchange, models.py:345-475): row = sample * ncomp + comp gathers the
+ * merged lattice of map (row_src & 0x3fffffff), padding mode (row_src >> 30) & 1 at row_grid [2], adds the point term of row_pe [4] (as
+ * car_lattice_encode_rows) and runs the second point-MLP layer: e [rows][288].  Samples are [n_sets][R][P]; every 24-ray x 8-step tile of one
+ * (set, comp) must share its (map, padding mode).  lattice: car_merge_lattice; gmeta [1]: its largest magnitude; blob / bias / wpt:
+ * car_fused_pack_rows(W1 [576][579], b1, W2 [288][576], b2, ...) with car_fused_blob_floats() / car_fused_bias_floats() / 576 * 4 floats. */
+int car_fused_pack_rows(const float* w1, const float* b1, const float* w2, const float* b2, float* blob, float* bias, float* wpt, void* stream);
+int car_fused_rows(const float* lattice, int lat_h, int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob,
+                   const float* bias, const int* row_src, const float* row_grid, const float* row_pe, int n_sets, int R, int P, int ncomp,
+                   float* e, void* stream);
 int car_fused_tile_steps(void);
 int car_fused_samples_parts(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
                             int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,

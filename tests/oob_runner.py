@@ -265,6 +265,43 @@ def case_attend(R, P, V, D, tail=True):
                                "car_attend"), t, ["w", "z"], tail)
 
 
+def case_fused_rows(R, P, nsets, tail=True):
+    """car_fused_rows: lattice, row lists, packed layers, e."""
+    lib = L.load()
+    g = torch.Generator().manual_seed(R + P + nsets)
+    n_maps, C, ncomp = 2, 576, 3
+    sizes = ((8, 8), (16, 16), (32, 32))
+    levels = [torch.randn(n_maps, h, w, C, generator=g).to(dev) for h, w in sizes]
+    ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in levels])
+    hs = (ctypes.c_int * 3)(*[h for h, _ in sizes])
+    wsz = (ctypes.c_int * 3)(*[w for _, w in sizes])
+    lh, lw, pad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    L.check(lib.car_merge_lattice(ptrs, hs, wsz, 3, n_maps, None, ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(pad), stream()), "shape")
+    lat = torch.empty(n_maps * 2 * lh.value * lw.value * C, device=dev)
+    L.check(lib.car_merge_lattice(ptrs, hs, wsz, 3, n_maps, ctypes.c_void_p(lat.data_ptr()), None, None, None, stream()), "car_merge_lattice")
+    rows = nsets * R * P * ncomp
+    src = torch.empty(nsets, R * P, ncomp, dtype=torch.int32)
+    for a_ in range(nsets):
+        for k in range(ncomp):
+            src[a_, :, k] = ((a_ + k) % n_maps) | ((1 if k else 0) << 30)
+    src[-1, :, -1] = (n_maps - 1) | (1 << 30)                      # the last set's last component: the LAST lattice of the buffer
+    grid = torch.rand(rows, 2, generator=g) * 2.6 - 1.3
+    grid[-1] = torch.tensor([0.999, 0.999])
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(dev)
+    blob = torch.zeros(lib.car_fused_blob_floats(), device=dev)
+    fb = torch.empty(lib.car_fused_bias_floats(), device=dev)
+    fwpt = torch.empty(C * 4, device=dev)
+    ws = [rnd(C, C + 3) * 0.05, rnd(C) * 0.1, rnd(C // 2, C) / 24, rnd(C // 2)]
+    L.check(lib.car_fused_pack_rows(*[ctypes.c_void_p(t.data_ptr()) for t in ws], ctypes.c_void_p(blob.data_ptr()), ctypes.c_void_p(fb.data_ptr()),
+                                    ctypes.c_void_p(fwpt.data_ptr()), stream()), "car_fused_pack_rows")
+    gmeta = lat.abs().max().reshape(1).contiguous()
+    torch.cuda.synchronize()
+    t = {"lat": lat, "gmeta": gmeta, "wpt": fwpt, "blob": blob, "bias": fb, "src": src.reshape(-1).to(dev), "grid": grid.to(dev),
+         "pe": torch.tanh(torch.randn(rows, 4, generator=g)).to(dev), "e": torch.zeros(rows, C // 2, device=dev)}
+    run_both(lambda p: L.check(lib.car_fused_rows(p("lat"), lh.value, lw.value, pad.value, p("gmeta"), p("wpt"), p("blob"), p("bias"), p("src"), p("grid"),
+                                                  p("pe"), nsets, R, P, ncomp, p("e"), stream()), "car_fused_rows"), t, ["e"], tail)
+
+
 def case_kq(M, Ce, tail=True):
     """car_key_query_logits: rows of e and g, the packed layers, qry and logit."""
     lib = L.load()
@@ -335,6 +372,7 @@ CASES = {
     "exchange_ragged": lambda tail: case_exchange(193, 128, tail),
     "attend_864": lambda tail: case_attend(37, 13, 3, 864, tail),
     "attend_100": lambda tail: case_attend(20, 8, 2, 100, tail),
+    "fused_rows": lambda tail: case_fused_rows(37, 13, 2, tail),
     "kq_864": lambda tail: case_kq(4099, 864, tail),
     "kq_ragged": lambda tail: case_kq(193, 96, tail),
     "wgrad16_579": lambda tail: case_wgrad(4133, 576, 579, 1, tail),
@@ -349,7 +387,7 @@ FAMILIES = {
     "gather": ["gather_wave", "gather_quad", "gather_zeros"],
     "fused": ["fused_37_13", "fused_48_8_b2"],
     "tail": ["tail_37_13", "tail_96_32_b2", "attend_864", "attend_100"],
-    "exchange": ["exchange_288", "exchange_ragged", "kq_864", "kq_ragged"],
+    "exchange": ["exchange_288", "exchange_ragged", "fused_rows", "kq_864", "kq_ragged"],
     "wgrad": ["wgrad16_579", "wgrad16_ragged", "wgrad_fp32", "wgrad_small"],
 }
 

@@ -825,6 +825,76 @@ def test_fused_exchange_layers_equal_the_two_launches(rows, N):
         assert torch.equal(got, want), (flags, (got - want).abs().max().item())
 
 
+@pytest.mark.parametrize("R,P,nsets", [(48, 16, 2), (37, 13, 3), (131, 8, 1)])
+def test_fused_rows_kernel_matches_the_two_exchange_layers(R, P, nsets):
+    """car_fused_rows (the fused per-sample kernel's source pass over explicit rows: tiles of 24 rays x 8 steps per (set, component), ragged ray
+    and step counts) against car_lattice_encode_rows + car_linear_x3 on the same rows — the split-fp16 first layer with one power of two per
+    launch against the fp32 gather: fp32 class, 5e-5 of the row's scale like the two-view routes' A/B."""
+    from cross_attention_renderer_amd import _lib as L
+    lib = _lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(R + P)
+    n_maps, C, ncomp = 3, 576, 3
+    sizes = ((8, 8), (16, 16), (32, 32))
+    levels = [torch.randn(n_maps, h, w, C, generator=g).to(dev) for h, w in sizes]
+    ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in levels])
+    hs = (ctypes.c_int * 3)(*[h for h, _ in sizes])
+    wsz = (ctypes.c_int * 3)(*[w for _, w in sizes])
+    lh, lw, pad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(lib.car_merge_lattice(ptrs, hs, wsz, 3, n_maps, None, ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(pad), st), "shape")
+    lat = torch.empty(n_maps, 2, lh.value, lw.value, C, device=dev)
+    L.check(lib.car_merge_lattice(ptrs, hs, wsz, 3, n_maps, _ptr(lat), None, None, None, st), "car_merge_lattice")
+    S = nsets * R * P
+    rows = S * ncomp
+    # one (map, padding mode) per (set, component), as the exchange's row list has it
+    src = torch.empty(nsets, R * P, ncomp, dtype=torch.int32)
+    for a_ in range(nsets):
+        for k in range(ncomp):
+            src[a_, :, k] = ((a_ + k) % n_maps) | ((1 if k else 0) << 30)
+    src = src.reshape(-1).to(dev)
+    grid = torch.rand(rows, 2, generator=g) * 2.6 - 1.3
+    grid[0] = torch.tensor([1e10, -1e10]); grid[1] = torch.tensor([-1.0, 1.0]); grid[5] = torch.tensor([float("nan"), 0.3])
+    grid = grid.to(dev)
+    pe = torch.tanh(torch.randn(rows, 4, generator=g)).to(dev)
+    w1 = torch.randn(C, C + 3, generator=g) * 0.05
+    b1 = torch.randn(C, generator=g) * 0.1
+    w2 = torch.randn(C // 2, C, generator=g) / C ** 0.5
+    b2 = torch.randn(C // 2, generator=g)
+    w1d, b1d, w2d, b2d = [t.to(dev).contiguous() for t in (w1, b1, w2, b2)]
+    wpt = torch.cat([w1[:, C:], b1[:, None]], dim=1).contiguous().to(dev)
+    tiles = torch.empty(lib.car_linear_x3_packed_floats(C, C // 2), device=dev)
+    L.check(lib.car_linear_x3_pack(_ptr(w2d), C, C, C // 2, _ptr(tiles), st), "pack")
+    h1 = torch.empty(rows, C, device=dev)
+    L.check(lib.car_lattice_encode_rows(_ptr(lat), lh.value, lw.value, pad.value, C, _ptr(src), _ptr(grid), _ptr(pe), _ptr(wpt), n_maps, rows, _ptr(h1), C, st),
+            "car_lattice_encode_rows")
+    want = torch.empty(rows, C // 2, device=dev)
+    L.check(lib.car_linear_x3(_ptr(h1), C, _ptr(tiles), _ptr(b2d), C, C // 2, _ptr(want), C // 2, rows, 0, st), "car_linear_x3")
+    blob = torch.zeros(lib.car_fused_blob_floats(), device=dev)
+    fb = torch.empty(lib.car_fused_bias_floats(), device=dev)
+    fwpt = torch.empty(C * 4, device=dev)
+    L.check(lib.car_fused_pack_rows(_ptr(w1d), _ptr(b1d), _ptr(w2d), _ptr(b2d), _ptr(blob), _ptr(fb), _ptr(fwpt), st), "car_fused_pack_rows")
+    gmeta = lat.abs().max().reshape(1).contiguous()
+    got = torch.full((rows, C // 2), float("nan"), device=dev)
+    L.check(lib.car_fused_rows(_ptr(lat), lh.value, lw.value, pad.value, _ptr(gmeta), _ptr(fwpt), _ptr(blob), _ptr(fb), _ptr(src), _ptr(grid), _ptr(pe),
+                               nsets, R, P, ncomp, _ptr(got), st), "car_fused_rows")
+    torch.cuda.synchronize()
+    assert torch.equal(fwpt.view(C, 4), wpt)
+    assert torch.isfinite(got).all() and torch.isfinite(want).all()
+    scale = want.abs().amax(dim=1, keepdim=True).clamp_min(1.0)
+    assert ((got - want).abs() / scale).max().item() < 5e-5
+
+
+def test_three_view_route_rows_kernel_against_the_other_forms():
+    """The n_view = 3 forward with the exchange on car_fused_rows (default) against the gather-fed linear kernel: fp32 rounding; against the oracle:
+    the contract."""
+    _, _, ora, a = run_case("t1_nview3", fuse_samples=False)
+    _, _, _, b_ = run_case("t1_nview3", fuse_samples=False, engine_setup=lambda e: setattr(e, "fuse_exchange", True))
+    assert rel_err(a["at_wt"], b_["at_wt"]) < 1e-5 and rel_err(a["rgb"], b_["rgb"]) < 2e-5
+    assert err_stats(a["stages"]["interp_val"], b_["stages"]["interp_val"])["max"] < 5e-5
+    _check_outputs(a, lambda k: ora[k], "rows kernel vs oracle")
+
+
 def test_three_view_route_with_fused_exchange_equals_two_launches():
     """The n_view = 3 forward with the exchange's two layers fused (default) against the two-launch form: every output bit-identical."""
     outs = []
