@@ -64,6 +64,7 @@ SIGNATURES = {
     "car_fused_bias_floats": (c_size_t, []),
     "car_fused_samples": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                   _P, _P, _P, _P, _P, _P, _P]),
+    "car_exchange_rows": (c_int, [_P, _P, _P, _P, c_int, c_int, c_long, c_int, c_int, _P, _P, _P, _P]),
     "car_fused_pack_rows": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "car_fused_rows": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "car_fused_tile_steps": (c_int, []),

@@ -180,6 +180,47 @@ extern "C" int car_project_points(const float* poses, const float* pts, int n_sc
     return CAR_OK;
 }
 
+namespace {
+// The row lists of the cross-view exchange for V > 2 context views (models.py:345-475 as engine._encode_three_views restates it): sample j of
+// context c carries V rows — component 0: its own features (map c, border padding, its own grid point, its point in frame c); component k >= 1,
+// for the other views o in ascending order: view o's features (zeros padding) where CONTEXT o's sample j — moved into frame c, projected with
+// view o's intrinsics — lands, with that point's encoding.  One thread per (scene, context, sample, component).
+__global__ void exchange_rows_kernel(const CarPose* __restrict__ poses, const float* __restrict__ pixel_val, const float* __restrict__ pt_in,
+                                     const float* __restrict__ ptenc, int V, long pts, int H, int W, long total, int* __restrict__ row_src,
+                                     float* __restrict__ row_grid, float* __restrict__ row_pe) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int k = (int)(idx % V);
+    const long sj = idx / V;                    // (scene, context, sample)
+    const long j = sj % pts;
+    const int n = (int)(sj / pts), c = n % V, sc = n / V;
+    const int o = k == 0 ? c : (k - 1 < c ? k - 1 : k);
+    const long so = ((long)(sc * V + o) * pts + j);                    // context o's sample j
+    float g2[2];
+    if (k == 0) { g2[0] = pixel_val[2 * so]; g2[1] = pixel_val[2 * so + 1]; }
+    else {
+        const float q[3] = {pt_in[(so * V + c) * 3], pt_in[(so * V + c) * 3 + 1], pt_in[(so * V + c) * 3 + 2]};
+        car_project_grid(poses[sc * V + o].kc, q, H, W, g2);
+    }
+    row_src[idx] = (sc * V + o) | (k == 0 ? 0 : (1 << 30));
+    row_grid[2 * idx] = g2[0]; row_grid[2 * idx + 1] = g2[1];
+    const float* pe = ptenc + (so * V + c) * 4;
+    row_pe[4 * idx] = pe[0]; row_pe[4 * idx + 1] = pe[1]; row_pe[4 * idx + 2] = pe[2]; row_pe[4 * idx + 3] = 0.0f;
+}
+}  // namespace
+
+extern "C" int car_exchange_rows(const float* poses, const float* pixel_val, const float* pt_in, const float* ptenc, int n_scenes, int V, long pts,
+                                 int H, int W, int* row_src, float* row_grid, float* row_pe, void* stream) {
+    CAR_REQUIRE(poses && pixel_val && pt_in && ptenc && row_src && row_grid && row_pe, "car_exchange_rows: null pointer");
+    CAR_REQUIRE(n_scenes > 0 && V > 1 && V <= CAR_MAX_VIEWS && pts > 0 && H > 1 && W > 1, "car_exchange_rows: bad sizes");
+    const long total = (long)n_scenes * V * pts * V;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(exchange_rows_kernel, dim3(car_div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, (const CarPose*)poses, pixel_val, pt_in,
+                       ptenc, V, pts, H, W, total, row_src, row_grid, row_pe);
+    CAR_CHECK_LAUNCH("car_exchange_rows");
+    return CAR_OK;
+}
+
 extern "C" int car_finalize(const float* rays, const float* rgb_in, int ld_in, int b, int V, int R, float* rgb,
                             float* valid, void* stream) {
     CAR_REQUIRE(rays && rgb_in && rgb && valid, "car_finalize: null pointer");

@@ -777,28 +777,12 @@ class RenderEngine:
             # 3 S rows — two thirds of this variant's FLOPs — becomes one gather over the projected pyramid with an explicit row list
             gmaps, wpt = self._projected_maps(maps, dev)
             n = b * V
+            # the row lists (map | padding mode, grid point, point encoding per (sample, component)) in one launch (car_exchange_rows)
             src = torch.empty(b, V, pts, 3, dtype=torch.int32, device=dev)
             rgrid = torch.empty(b, V, pts, 3, 2, **f32)
-            rpe = torch.zeros(b, V, pts, 3, 4, **f32)
-            pe = ptenc.view(b, V, pts, V, 4)
-            pin = pt_in.view(b, V, pts, V, 3)
-            sc = torch.arange(b, device=dev, dtype=torch.int32).view(b, 1)
-            grid = torch.empty(b, pts, 2, **f32)
-            pv = pixel_val.view(b, V, pts, 2)
-            for c in range(V):
-                src[:, c, :, 0] = sc * V + c                              # own features, border padding (mode 0)
-                rgrid[:, c, :, 0] = pv[:, c]
-                rpe[:, c, :, 0, :3] = pe[:, c, :, c, :3]
-                k = 1
-                for o in range(V):
-                    if o == c:
-                        continue
-                    q = pin[:, o, :, c, :].contiguous()
-                    _lib.check(self.lib.car_project_points(_ptr(poses), _ptr(q), b, pts, V, o, H, W, _ptr(grid), _stream()), "car_project_points")
-                    src[:, c, :, k] = (sc * V + o) | (1 << 30)            # view o's features, zeros padding (mode 1)
-                    rgrid[:, c, :, k] = grid
-                    rpe[:, c, :, k, :3] = pe[:, o, :, c, :3]
-                    k += 1
+            rpe = torch.empty(b, V, pts, 3, 4, **f32)
+            _lib.check(self.lib.car_exchange_rows(_ptr(poses), _ptr(pixel_val), _ptr(pt_in), _ptr(ptenc), b, V, pts, H, W, _ptr(src), _ptr(rgrid),
+                                                  _ptr(rpe), _stream()), "car_exchange_rows")
             L = len(gmaps)
             ptrs = (ctypes.c_void_p * L)(*[g.data_ptr() for g in gmaps])
             hs = (ctypes.c_int * L)(*[g.shape[1] for g in gmaps])

@@ -173,6 +173,11 @@ int car_fused_samples(const float* poses, const float* rays, const float* steps,
  * car_lattice_encode_rows) and runs the second point-MLP layer: e [rows][288].  Samples are [n_sets][R][P]; every 24-ray x 8-step tile of one
  * (set, comp) must share its (map, padding mode).  lattice: car_merge_lattice; gmeta [1]: its largest magnitude; blob / bias / wpt:
  * car_fused_pack_rows(W1 [576][579], b1, W2 [288][576], b2, ...) with car_fused_blob_floats() / car_fused_bias_floats() / 576 * 4 floats. */
+/* The exchange's row lists on the device: for samples [n_scenes*V][pts] with car_sample_setup's pixel_val [.,2], pt_in [.,V,3] (the point in every
+ * context frame) and ptenc [.,V,4] (its tanh encoding), row (sample, k) = component k of sample: k = 0 own view (border padding, own grid point),
+ * k >= 1 the other views o in ascending order (zeros padding) at the projection of CONTEXT o's sample of the same index moved into the sample's frame. */
+int car_exchange_rows(const float* poses, const float* pixel_val, const float* pt_in, const float* ptenc, int n_scenes, int V, long pts, int H,
+                      int W, int* row_src, float* row_grid, float* row_pe, void* stream);
 int car_fused_pack_rows(const float* w1, const float* b1, const float* w2, const float* b2, float* blob, float* bias, float* wpt, void* stream);
 int car_fused_rows(const float* lattice, int lat_h, int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob,
                    const float* bias, const int* row_src, const float* row_grid, const float* row_pe, int n_sets, int R, int P, int ncomp,

@@ -885,6 +885,49 @@ def test_fused_rows_kernel_matches_the_two_exchange_layers(R, P, nsets):
     assert ((got - want).abs() / scale).max().item() < 5e-5
 
 
+def test_exchange_row_lists_match_their_definition():
+    """car_exchange_rows against the row lists written out with torch indexing and car_project_points (the form engine._encode_three_views
+    used to build them in, ~40 launches): bit-identical."""
+    from cross_attention_renderer_amd import _lib as L
+    lib = _lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    b, V, pts, H = 2, 3, 500, 64
+    poses = torch.randn(b * V, 96, generator=g).to(dev)
+    poses[:, :] = poses.abs() + 0.5                                    # intrinsics well away from zero
+    pixel_val = (torch.rand(b * V, pts, 2, generator=g) * 2 - 1).to(dev)
+    pt_in = (torch.randn(b * V, pts, V, 3, generator=g) + torch.tensor([0.0, 0.0, 3.0])).to(dev).contiguous()
+    ptenc = torch.tanh(torch.randn(b * V * pts * V, 4, generator=g)).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    src = torch.empty(b, V, pts, 3, dtype=torch.int32, device=dev)
+    rgrid = torch.empty(b, V, pts, 3, 2, device=dev)
+    rpe = torch.zeros(b, V, pts, 3, 4, device=dev)
+    pe, pin, pv = ptenc.view(b, V, pts, V, 4), pt_in.view(b, V, pts, V, 3), pixel_val.view(b, V, pts, 2)
+    sc = torch.arange(b, device=dev, dtype=torch.int32).view(b, 1)
+    grid = torch.empty(b, pts, 2, device=dev)
+    for c in range(V):
+        src[:, c, :, 0] = sc * V + c
+        rgrid[:, c, :, 0] = pv[:, c]
+        rpe[:, c, :, 0, :3] = pe[:, c, :, c, :3]
+        k = 1
+        for o in range(V):
+            if o == c:
+                continue
+            q = pin[:, o, :, c, :].contiguous()
+            L.check(lib.car_project_points(_ptr(poses), _ptr(q), b, pts, V, o, H, H, _ptr(grid), st), "car_project_points")
+            src[:, c, :, k] = (sc * V + o) | (1 << 30)
+            rgrid[:, c, :, k] = grid
+            rpe[:, c, :, k, :3] = pe[:, o, :, c, :3]
+            k += 1
+    s2 = torch.empty_like(src)
+    g2 = torch.full_like(rgrid, float("nan"))
+    p2 = torch.full_like(rpe, float("nan"))
+    L.check(lib.car_exchange_rows(_ptr(poses), _ptr(pixel_val), _ptr(pt_in), _ptr(ptenc), b, V, pts, H, H, _ptr(s2), _ptr(g2), _ptr(p2), st), "car_exchange_rows")
+    torch.cuda.synchronize()
+    assert torch.equal(s2, src) and torch.equal(p2, rpe)
+    assert torch.equal(torch.nan_to_num(g2, nan=7.0), torch.nan_to_num(rgrid, nan=7.0))
+
+
 def test_three_view_route_rows_kernel_against_the_other_forms():
     """The n_view = 3 forward with the exchange on car_fused_rows (default) against the gather-fed linear kernel: fp32 rounding; against the oracle:
     the contract."""
