@@ -40,6 +40,21 @@ def test_bad_arguments_return_codes_not_crashes(lib):
         _lib.check(-1, "probe")
 
 
+def test_round5_entries_validate_their_arguments(lib):
+    """The entries added in round 5 return codes (never abort) on null pointers and impossible shapes, and report their sizes without a GPU."""
+    assert lib.car_fused_tile_steps() == 8
+    assert lib.car_kq_tail_floats() == 72 * 512 and lib.car_kq_bias_floats() == 2 * 128 + 16
+    assert lib.car_attend_parts(None, None, 8, 576, 1, 2, 8, 8, None, None, 576, 1, None, None, None, None, None) == -1
+    assert b"null pointer" in lib.car_last_error()
+    assert lib.car_fused_samples_parts(*([None] * 4), 521, 521, 5, *([None] * 4), 1, 2, 8, 8, 256, 256, 0, *([None] * 7), None) == -1
+    assert lib.car_lattice_encode_linear(None, 37, 37, 5, None, None, None, None, 1, 16, None, None, 576, 288, None, 288, 0, None) == -1
+    assert lib.car_fused_rows(None, 37, 37, 5, *([None] * 7), 1, 8, 8, 3, None, None) == -1
+    assert lib.car_key_query_logits(None, 576, None, None, 576, None, None, None, 16, None, None, None) == -1
+    assert lib.car_kq_pack(*([None] * 9)) == -1 and lib.car_fused_pack_rows(*([None] * 8)) == -1
+    assert lib.car_exchange_rows(None, None, None, None, 1, 3, 8, 64, 64, None, None, None, None) == -1
+    assert lib.car_linear_wgrad(None, 4, None, 4, 8, 4, 4, 16, None, 4, None, None) == -1
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "cross_attention_renderer_amd")
     for dirpath, _, files in os.walk(pkg):
