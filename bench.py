@@ -64,8 +64,11 @@ H, P = 256, 64                     # the headline configuration's sizes (module-
 FP32_MFMA_PEAK = 157.3e12          # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md)
 F16_MFMA_PEAK = 2.5e15             # v_mfma_f32_32x32x16_f16, dense (never the 2:1-sparse marketing figure)
 HBM_PEAK = 8.0e12
-# matrix-pipe MACs per sample of csrc/car_fused.hip: 2 x 576x288 (e), 576x128 + 128x128 (key), 16x128 + 128x128 (qry); independent of P
+# ALGORITHMIC matrix-pipe MACs per sample of the path the fused kernel covers (models.py:333-344, 487-491, 529): 2 x 576x288 (e), 576x128 +
+# 128x128 (key), 16x128 + 128x128 (qry); independent of P.  Since round 6 the kernel EXECUTES 128x128 fewer (key_map_2 and query_embed_2 are
+# folded into one layer, car_fused_layout.h): FUSED_MACS_EXECUTED; the roofline's `achieved` keeps the algorithmic count, as in every round.
 FUSED_MACS = 2 * 576 * 288 + 576 * 128 + 128 * 128 + 16 * 128 + 128 * 128
+FUSED_MACS_EXECUTED = FUSED_MACS - 128 * 128
 
 
 def build_model(device, P_=None, H_=None):
@@ -457,7 +460,7 @@ def main():
                     pmc[k] = pmc[k] * part
             if part != 1.0 and pmc.get("source"):
                 pmc["source"] += f", scaled by {part:g} to this launch's share of the frame"
-            roof = {"bound": "mfma", "limiter": pmc.get("limiter"), "kernel": f"fused_kernel on {int(samples)} samples (geometry, 4-tap gather of the per-texel-projected pyramid on its lattice, e, key, qry, logits; "
+            roof = {"bound": "mfma", "limiter": pmc.get("limiter"), "kernel": f"fused_kernel on {int(samples)} samples (geometry, 4-tap gather of the per-texel-projected pyramid on its lattice, e, key_map, query_embed, the first round's logits as a bilinear form; "
                                                                   "f16 matrix pipe, fp16 hi/lo split x3; since round 5 the launch also reduces the first attention "
                                                                   "round's value sums per 8-step group from L2 — about 4 % of its time, no matrix work, not counted in the flops)",
                     "achieved": flop / mean / 1e12, "peak": F16_MFMA_PEAK / 3 / 1e12, "unit": "TFLOP/s", "frac": flop / mean / (F16_MFMA_PEAK / 3),
@@ -470,10 +473,14 @@ def main():
                     "per_unit_unthrottled_frac": pmc.get("per_unit_unthrottled_frac"),
                     "traffic": pmc.get("bytes_per_launch"), "traffic_source": pmc.get("source"),
                     # which of these fields this run measured and which it copied from the committed counter passes
-                    "live_fields": ["achieved", "frac", "frac_of_fp32_pipe_peak", "launches", "ms_per_launch", "flop_per_launch"],
+                    "live_fields": ["achieved", "frac", "frac_executed", "frac_of_fp32_pipe_peak", "launches", "ms_per_launch", "flop_per_launch", "flop_executed_per_launch"],
                     "static_fields": ["limiter", "ta_busy", "mfma_busy", "valu_share", "l1_bytes", "traffic", "per_unit_unthrottled_frac"],
                     "static": "profiles/traffic.json: rocprofv3 --pmc passes of an earlier run of this kernel at config c2 (separate passes, not collected here; null for the other configs)",
                     "launches": len(lat), "ms_per_launch": mean * 1e3, "flop_per_launch": flop,
+                    # what the kernel executes since round 6: key_map_2 and query_embed_2 folded into ONE 128 x 128 layer (the logit is a
+                    # bilinear form of the two hidden vectors): 16 384 of the 440 320 algorithmic MACs per sample are not issued
+                    "flop_executed_per_launch": 2.0 * samples * FUSED_MACS_EXECUTED,
+                    "frac_executed": 2.0 * samples * FUSED_MACS_EXECUTED / mean / (F16_MFMA_PEAK / 3),
                     # the same matrix work without the partial-sum phase (first_round_ab): the figure comparable with rounds 3-4
                     "frac_without_partial_sums": None if not ab or "fused_samples" not in ab["rows_of_e"]["stage_ms"] else
                     flop / (ab["rows_of_e"]["stage_ms"]["fused_samples"] * 1e-3) / (F16_MFMA_PEAK / 3),

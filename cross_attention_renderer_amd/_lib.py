@@ -63,13 +63,13 @@ SIGNATURES = {
     "car_fused_blob_floats": (c_size_t, []),
     "car_fused_bias_floats": (c_size_t, []),
     "car_fused_samples": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                  _P, _P, _P, _P, _P, _P, _P]),
+                                  _P, _P, _P, _P, _P, _P]),
     "car_exchange_rows": (c_int, [_P, _P, _P, _P, c_int, c_int, c_long, c_int, c_int, _P, _P, _P, _P]),
     "car_fused_pack_rows": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "car_fused_rows": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "car_fused_tile_steps": (c_int, []),
     "car_fused_samples_parts": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                        _P, _P, _P, _P, _P, _P, _P, _P]),
+                                        _P, _P, _P, _P, _P, _P, _P]),
     "car_linear_packed_floats": (c_size_t, [c_int, c_int]),
     "car_linear_pack": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "car_linear": (c_int, [_P, c_int, _P, c_int, c_int, _P, c_int, c_long, c_int, _P]),
@@ -83,6 +83,10 @@ SIGNATURES = {
     "car_round2_packed_floats": (c_size_t, []),
     "car_round2_bias_floats": (c_size_t, []),
     "car_round2_logits": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "car_round2q_packed_floats": (c_size_t, []),
+    "car_round2q_bias_floats": (c_size_t, []),
+    "car_round2_logits_from_g": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "car_round2q_pack": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "car_fused_pack": (c_int, [ctypes.POINTER(CarWeights), _P, _P, _P, _P]),
     "car_round2_pack": (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "car_add_ray_bias_relu": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

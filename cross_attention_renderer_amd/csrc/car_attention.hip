@@ -216,6 +216,8 @@ extern "C" int car_attend_parts(const float* logit, const float* part, int tile_
                                 void* stream) {
     CAR_REQUIRE(logit && part && w_out && z_out, "car_attend_parts: null pointer");
     CAR_REQUIRE(b > 0 && V > 0 && V <= CAR_MAX_VIEWS && R > 0 && P > 0 && V * P <= kMaxSamples, "car_attend_parts: bad sizes");
+    CAR_REQUIRE(tile_steps == car_fused_tile_steps(), "car_attend_parts: tile_steps = %d, but `part` is made in groups of car_fused_tile_steps() = %d steps",
+                tile_steps, car_fused_tile_steps());
     CAR_REQUIRE(tile_steps >= 4 && D > 0 && reps >= 1 && ld_z >= reps * D, "car_attend_parts: bad widths D=%d tile_steps=%d", D, tile_steps);
     CAR_REQUIRE(!pt || (poses && depth), "car_attend_parts: pt needs poses and depth");
     (void)hipGetLastError();

@@ -3,7 +3,8 @@
 // chunk a FOUR-tap gather of the per-texel projected pyramid: the first point-MLP layer is applied once per texel and ALL levels are
 // summed once per stereo pair on the integer lattice their texel centres share (car_geom.h car_lattice_taps), so
 // grid_sample over three levels is one bilinear lookup ->
-// e_s = W2 relu(h_s) + b2 for both source views -> k1 = Wk1 [e_0 ; e_1] -> key -> qry -> logit = <key, qry>/16.  Every layer
+// e_s = W2 relu(h_s) + b2 for both source views -> k1 = Wk1 [e_0 ; e_1] -> logit = <key, qry>/16 as a bilinear form of relu(k1) and
+// relu(query_embed(g)) (one folded 128 x 128 layer, car_fused_layout.h; neither key nor qry is formed).  Every layer
 // runs on the f16 matrix pipe as three v_mfma_f32_16x16x32_f16 products of fp16 hi/lo operand halves (car_fused_mma.h); a
 // layer's accumulators are the next layer's B operands.
 //
@@ -78,7 +79,6 @@ struct FusedArgs {
     long S;
     int blk0;                  // first sample group of this launch (0 except in the development build's partial launches)
     float* e;
-    float* qry;
     float* g;
     float* logit;
     float* pt;
@@ -90,22 +90,21 @@ struct FusedArgs {
     const int* row_src; const float* row_grid; const float* row_pe; int ncomp;
 };
 
-// chunk order:  W2 x18 (source 0) | W2 x18 (source 1) | K1 over e_1 x5 (2,2,2,2,1 K steps) | K1 over e_0 x5 | K2 x2 | Q1 | Q2 x2
+// chunk order:  W2 x18 (source 0) | W2 x18 (source 1) | K1 over e_1 x5 (2,2,2,2,1 K steps) | K1 over e_0 x5 | Q1 | M x2
 constexpr int kChK1 = 5;
-constexpr int kG_W2b = kKS, kG_K1b = 2 * kKS, kG_K1a = kG_K1b + kChK1, kG_K2 = kG_K1a + kChK1, kG_Q1 = kG_K2 + 2, kG_Q2 = kG_Q1 + 1;
-static_assert(kG_Q2 + 2 == kNumChunks, "chunk count");
+constexpr int kG_W2b = kKS, kG_K1b = 2 * kKS, kG_K1a = kG_K1b + kChK1, kG_Q1 = kG_K1a + kChK1, kG_M = kG_Q1 + 1;
+static_assert(kG_M + 2 == kNumChunks, "chunk count");
 __device__ __forceinline__ constexpr int chunk_tile_offset(int g) {
     if (g < kG_W2b) return kOffW2 + g * kTE;
     if (g < kG_K1b) return kOffW2 + (g - kG_W2b) * kTE;
     if (g < kG_K1a) return kOffK1 + 9 * kTD + (g - kG_K1b) * 2 * kTD;
-    if (g < kG_K2) return kOffK1 + (g - kG_K1a) * 2 * kTD;
-    if (g < kG_Q1) return kOffK2 + (g - kG_K2) * 2 * kTD;
-    if (g < kG_Q2) return kOffQ1;
-    return kOffQ2 + (g - kG_Q2) * 2 * kTD;
+    if (g < kG_Q1) return kOffK1 + (g - kG_K1a) * 2 * kTD;
+    if (g < kG_M) return kOffQ1;
+    return kOffM + (g - kG_M) * 2 * kTD;
 }
 __device__ __forceinline__ constexpr int chunk_tiles(int g) {
     if (g < kG_K1b) return kTE;
-    if (g == kG_K1a - 1 || g == kG_K2 - 1 || g == kG_Q1) return kTD;                      // odd last K1 step, Q1
+    if (g == kG_K1a - 1 || g == kG_Q1 - 1 || g == kG_Q1) return kTD;                      // odd last K1 step, Q1
     return 2 * kTD;
 }
 // the chunk after g inside the two source passes (g + 1 in [1, 36]): selects only, no branch tree in the hot loop
@@ -147,8 +146,18 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     // the tile's sample of (wave, row lane & 15): tile_ray / tile_step above; the 8 rows a tap instruction gathers are one step of
     // neighbouring rays (shared lattice rows)
     const int pgs = (a.P + kTileSteps - 1) / kTileSteps, bundles = (a.R + kTileRays - 1) / kTileRays;
+#if !defined(CAR_WG_ORDER) || CAR_WG_ORDER == 0
     const int pg = blk % pgs, bun = (blk / pgs) % bundles;
     const int nset = blk / (pgs * bundles);                            // ROWS: (sample set, component)
+#else
+    // development build (profiles/round6_fused_closing.md): other orders of the workgroups inside an XCD's band, judged by FETCH_SIZE
+    const int nsets = ROWS ? a.b * a.ncomp : a.b * a.V;
+#if CAR_WG_ORDER == 1                                                  // (ray tile, view, step group): a tile's 2 x 8 workgroups are neighbours
+    const int pg = blk % pgs, nset = (blk / pgs) % nsets, bun = blk / (pgs * nsets);
+#else                                                                  // 2: (step group, view, ray tile): an XCD runs neighbouring ray tiles at ONE step group
+    const int pg = blk / (nsets * bundles), nset = (blk / bundles) % nsets, bun = blk % bundles;
+#endif
+#endif
     const int nn = ROWS ? nset / a.ncomp : nset, comp = ROWS ? nset % a.ncomp : 0;
     const int ray_i = bun * kTileRays + tile_ray(wave, s), pp = pg * kTileSteps + tile_step(wave, s);
     const bool live = ray_i < a.R && pp < a.P;
@@ -650,15 +659,10 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         }
     }
     mark(8);
-    scale_acc<kTD>(k1, lsc[kLayerK1] * pinv);
-    f32x4 key[kTD];
-    pow2_scale(fmaxf(sample_max<kTD, true>(k1), 1e-30f), p, pinv);
-    init_bias<kTD>(key, lds + kLdsBias + kBiasK2, q4, p / lsc[kLayerK2]);
-    chained_layer<kTD, true, ABL, kG_K2>(key, k1, p, a.blob, lds, lane, wave);
-    scale_acc<kTD>(key, lsc[kLayerK2] * pinv);
-
+    scale_acc<kTD>(k1, lsc[kLayerK1] * pinv);                          // k1 = key_map([e_0 ; e_1]); r = relu(k1) is used straight from these registers
     mark(5);
-    // ---- qry = Wq2 relu(Wq1 g + bq1) + bq2 ;  logit = <key, qry>/16 ---------------------------------------------------
+    // ---- logit = <key, qry> / 16 as the bilinear form r^T (M x + v) + u^T x + c of r = relu(k1) and x = relu(Wq1 g + bq1)
+    //      (car_fused_layout.h): one 128 x 128 layer instead of key_map_2 and query_embed_2 ------------------------------------------
     half8 ghi, glo;                                                    // B operand of the layer fed by g (k = 16: folded bias)
     {
         const float* gl = lds + kLdsG + (wave * kRows + s) * 16 + 8 * (q4 & 1);
@@ -673,7 +677,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         pow2_scale(m, p, pinv);
         split8(gx8, p, ghi, glo);
     }
-    f32x4 t1[kTD], qv[kTD];
+    f32x4 t1[kTD], mt[kTD];
 #pragma unroll
     for (int t = 0; t < kTD; ++t) t1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     stream_issue_all<ABL>(a.blob, lds, kG_Q1 + 1, lane, wave);
@@ -681,23 +685,30 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     stream_sync<ABL>();
     scale_acc<kTD>(t1, lsc[kLayerQ1] * pinv);
     pow2_scale(fmaxf(sample_max<kTD, true>(t1), 1e-30f), p, pinv);
-    init_bias<kTD>(qv, lds + kLdsBias + kBiasQ2, q4, p / lsc[kLayerQ2]);
-    chained_layer<kTD, true, ABL, kG_Q2>(qv, t1, p, a.blob, lds, lane, wave);
-    scale_acc<kTD>(qv, lsc[kLayerQ2] * pinv);
+    init_bias<kTD>(mt, lds + kLdsBias + kBiasV, q4, p / lsc[kLayerM]);
+    chained_layer<kTD, true, ABL, kG_M>(mt, t1, p, a.blob, lds, lane, wave);
+    scale_acc<kTD>(mt, lsc[kLayerM] * pinv);                           // M x + v
     float dot = 0.0f;
 #pragma unroll
-    for (int t = 0; t < kTD; ++t)
+    for (int t = 0; t < kTD; ++t) {
+        const float4 u4 = *reinterpret_cast<const float4*>(lds + kLdsBias + kBiasU + 16 * t + 4 * q4);
+        const float uu[4] = {u4.x, u4.y, u4.z, u4.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dot = fmaf(key[t][r], qv[t][r], dot);
+        for (int r = 0; r < 4; ++r) {
+            dot = fmaf(fmaxf(k1[t][r], 0.0f), mt[t][r], dot);
+            dot = fmaf(uu[r], fmaxf(t1[t][r], 0.0f), dot);
+        }
+    }
     dot += __shfl_xor(dot, 16, 64);
     dot += __shfl_xor(dot, 32, 64);
+    dot += lds[kLdsBias + kBiasConst];
     // ---- first attention round, this workgroup's share (models.py:533-541): for each of its rays the step group's
     //      sum_j exp(logit_j - m) e_j with m = max_j logit_j over the group's kTileSteps samples, read back from the rows of e this
     //      workgroup has written (L2) — 1/kTileSteps of the bytes the attention launch would otherwise stream from HBM; that launch
     //      (car_attend_parts) folds the groups of a ray together with exp(m - M) / L.  A wave owns kTileRays / kWaves rays; a 16-lane
     //      group reads a whole 2304-byte row as nine float4 per lane, the wave's four groups take four rows at a time.
     //      Every wave's stores of e were drained (vmcnt 0) in front of a chunk barrier layers ago, so the logits' hand-over barrier is
-    //      all the ordering the read-back needs (no wait for the qry / logit stores issued just before it); the row loads of ALL the
+    //      all the ordering the read-back needs (no wait for the logit stores issued just before it); the row loads of ALL the
     //      wave's rays are in flight together.
     constexpr int kRaysPerWave = kTileRays / kWaves, kRowIts = kTileSteps / 4;
     static_assert(kTileRays % kWaves == 0 && kTileSteps % 4 == 0, "partial sums: whole rays per wave, four rows at a time");
@@ -705,13 +716,12 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     float pw[kRaysPerWave][kRowIts];
     const int sub = lane & 15, grp = lane >> 4;
     if (live) {
-        store_rows<kTD>(qv, a.qry + i * kD, q4);
         if (q4 == 0) a.logit[i] = dot / 16.0f;
     }
     if (a.part) {
         float* lgt = lds + kLdsG;                                      // the wave's g rows are dead: row (wave, s) keeps its logit in float 0
         if (q4 == 0) lgt[(wave * kRows + s) * 16] = live ? dot / 16.0f : -INFINITY;
-        __syncthreads();                                               // the qry / logit stores above stay in flight across it
+        __syncthreads();                                               // the logit stores above stay in flight across it
         auto lgt_of = [&](int rr, int k) -> float {                    // logit of the tile's (ray rr, step k): inverse of tile_ray / tile_step
             const int w_ = (rr / kWaveRays) * kStepWaves + k / kWaveSteps, s_ = (rr % kWaveRays) + kWaveRays * (k % kWaveSteps);
             return lgt[(w_ * kRows + s_) * 16];
@@ -773,9 +783,9 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
 
 int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w, int lat_pad,
                  const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P, int H, int W, int no_sample, float* e,
-                 float* qry, float* g, float* logit, float* pt, float* pixel_val, float* part, void* stream) {
+                 float* g, float* logit, float* pt, float* pixel_val, float* part, void* stream) {
     CAR_REQUIRE(poses && rays && steps && lattice && gmeta && wpt && blob && bias, "car_fused_samples: null input");
-    CAR_REQUIRE(e && qry && g && logit && pt && pixel_val, "car_fused_samples: null output");
+    CAR_REQUIRE(e && g && logit && pt && pixel_val, "car_fused_samples: null output");
     CAR_REQUIRE(V == 2, "car_fused_samples: built for V = 2 (got %d)", V);
     CAR_REQUIRE(b > 0 && R > 0 && P > 0 && H > 1 && W > 1, "car_fused_samples: bad sizes");
     CAR_REQUIRE(lat_pad >= 2 && lat_h > 2 * lat_pad + 1 && lat_w > 2 * lat_pad + 1 && ((lat_h - 2 * lat_pad) & 1) && ((lat_w - 2 * lat_pad) & 1),
@@ -792,11 +802,11 @@ int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* r
     a.no_sample = no_sample != 0;
     a.S = (long)b * V * R * P;
     a.blk0 = blk0;
-    a.e = e; a.qry = qry; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val; a.part = part;
+    a.e = e; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val; a.part = part;
     long groups = (long)b * V * car_div_up(R, kTileRays) * car_div_up(P, kTileSteps);
     if (nblk > 0) groups = (groups - blk0 < nblk) ? groups - blk0 : nblk;     // development build: a slice of the sample groups
     void (*kern)(const FusedArgs) = fused_kernel<0>;
-#ifdef CAR_ABLATION
+#if defined(CAR_ABLATION) && !defined(CAR_ABLATION_NONE)       // CAR_ABLATION_NONE: the development build's entries without the timing variants
     switch (abl) {
         case 1: kern = fused_kernel<1>; break;   case 2: kern = fused_kernel<2>; break;   case 3: kern = fused_kernel<3>; break;
         case 4: kern = fused_kernel<4>; break;   case 5: kern = fused_kernel<5>; break;   case 11: kern = fused_kernel<11>; break;
@@ -825,12 +835,12 @@ int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* r
 }  // namespace
 
 extern "C" size_t car_fused_blob_floats(void) { return (size_t)kBlobTiles * kTile; }
-extern "C" size_t car_fused_bias_floats(void) { return (size_t)kBiasFloats; }
+extern "C" size_t car_fused_bias_floats(void) { return (size_t)(kBiasFloats + kBiasScratch); }      // the table + car_fused_pack's scratch
 
 extern "C" int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
                                  int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P,
-                                 int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
-    return launch_fused(0, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, qry, g, logit, pt,
+                                 int H, int W, int no_sample, float* e, float* g, float* logit, float* pt, float* pixel_val, void* stream) {
+    return launch_fused(0, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, g, logit, pt,
                         pixel_val, nullptr, stream);
 }
 
@@ -839,10 +849,10 @@ extern "C" int car_fused_samples(const float* poses, const float* rays, const fl
 extern "C" int car_fused_tile_steps(void) { return kTileSteps; }
 extern "C" int car_fused_samples_parts(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
                                        int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,
-                                       int P, int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val,
+                                       int P, int H, int W, int no_sample, float* e, float* g, float* logit, float* pt, float* pixel_val,
                                        float* part, void* stream) {
     CAR_REQUIRE(part, "car_fused_samples_parts: null output");
-    return launch_fused(0, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, qry, g, logit, pt,
+    return launch_fused(0, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, g, logit, pt,
                         pixel_val, part, stream);
 }
 
@@ -850,19 +860,19 @@ extern "C" int car_fused_samples_parts(const float* poses, const float* rays, co
 // development build only (tools/build_dev.py): timing-only variants of the kernel, results are wrong by construction
 extern "C" int car_fused_samples_ablate(int abl, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h,
                                         int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b,
-                                        int V, int R, int P, int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt,
+                                        int V, int R, int P, int H, int W, int no_sample, float* e, float* g, float* logit, float* pt,
                                         float* pixel_val, void* stream) {
-    return launch_fused(abl, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, qry, g, logit, pt,
+    return launch_fused(abl, 0, 0, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, g, logit, pt,
                         pixel_val, nullptr, stream);
 }
 // the same launch cut into slices of `nblk` sample groups (one kernel launch each): every slice starts its workgroups in phase
 extern "C" int car_fused_samples_sliced(int nblk, const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h,
                                         int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b,
-                                        int V, int R, int P, int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt,
+                                        int V, int R, int P, int H, int W, int no_sample, float* e, float* g, float* logit, float* pt,
                                         float* pixel_val, void* stream) {
     const long groups = (long)b * V * car_div_up(R, kTileRays) * car_div_up(P, kTileSteps);
     for (long b0 = 0; b0 < groups; b0 += nblk) {
-        const int rc = launch_fused(0, (int)b0, nblk, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, qry, g,
+        const int rc = launch_fused(0, (int)b0, nblk, poses, rays, steps, lattice, lat_h, lat_w, lat_pad, gmeta, wpt, blob, bias, b, V, R, P, H, W, no_sample, e, g,
                                     logit, pt, pixel_val, nullptr, stream);
         if (rc != CAR_OK) return rc;
     }

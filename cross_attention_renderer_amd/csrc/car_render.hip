@@ -16,6 +16,8 @@ extern "C" size_t car_fused_bias_floats(void);
 extern "C" int car_fused_tile_steps(void);
 extern "C" size_t car_round2_packed_floats(void);
 extern "C" size_t car_round2_bias_floats(void);
+extern "C" size_t car_round2q_packed_floats(void);
+extern "C" size_t car_round2q_bias_floats(void);
 extern "C" size_t car_chain_packed_floats(int K, int N);
 extern "C" int car_chain_pack(const float* W, int ldw, const float* W2, int K, int N, int chained, float* packed, float* scale, int slot,
                               void* stream);
@@ -89,6 +91,34 @@ __global__ void pack16_kernel(const float* __restrict__ W, int ldw, const float*
         _Float16* o = out + tile * 1024 + lane * 8 + e;
         o[0] = hi;
         o[512] = lo;
+    }
+}
+// <Wa r + ba, Wb x + bb> = r^T (M x + v) + u^T x + c for two 128-wide layers that are only ever dotted with each other (the first round's
+// key_map_2 / query_embed_2, the second round's query_repeat_embed_2 / query_embed_2; models.py:491, 529, 533, 553-556):
+//     M[i][j] = sum_k Wa[k][i] Wb[k][j],  v[i] = sum_k Wa[k][i] bb[k],  u[j] = sum_k Wb[k][j] ba[k],  c = sum_k ba[k] bb[k]
+// accumulated in fp64 in ascending k (every product of two fp32 values is exact there) and rounded once to fp32.  One workgroup per row i of M.
+__global__ void bilinear_fold_kernel(const float* __restrict__ Wa, const float* __restrict__ ba, const float* __restrict__ Wb,
+                                     const float* __restrict__ bb, int D, float* __restrict__ M, float* __restrict__ v, float* __restrict__ u,
+                                     float* __restrict__ c) {
+    const int i = blockIdx.x, j = threadIdx.x;
+    if (j >= D) return;
+    double m = 0.0;
+    for (int k = 0; k < D; ++k) m += (double)Wa[k * D + i] * (double)Wb[k * D + j];
+    M[i * D + j] = (float)m;
+    if (j == 0) {
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s += (double)Wa[k * D + i] * (double)bb[k];
+        v[i] = (float)s;
+    }
+    if (i == 0) {
+        double s = 0.0;
+        for (int k = 0; k < D; ++k) s += (double)Wb[k * D + j] * (double)ba[k];
+        u[j] = (float)s;
+        if (j == 0) {
+            double t = 0.0;
+            for (int k = 0; k < D; ++k) t += (double)ba[k] * (double)bb[k];
+            c[0] = (float)t;
+        }
     }
 }
 // A-operand tiles of v_mfma_f32_32x32x16_f16 for car_round2.hip: [chunk][tile 4][K group kgs][hi|lo][lane][8 halves], output
@@ -377,7 +407,7 @@ struct Plan {
     // offsets in floats.  latent_value ... lout_c: car_chain_pack tiles of the per-ray chains (car_raychain.hip; latent_value and lin_in
     // read their input rows from memory, the *_c layers the previous layer's accumulators); chain_scale: their powers of two;
     // mid_bias / tail_bias: their biases in consumption order
-    size_t steps, blob, fbias, wpt, r2w, r2b, proj[CAR_MAX_LEVELS], proj16[CAR_MAX_LEVELS], latent_value, lin_in, enc_c, qreh_c, lz_c[kBlocks], fc0_c[kBlocks],
+    size_t steps, blob, fbias, wpt, r2qw, r2qb, proj[CAR_MAX_LEVELS], proj16[CAR_MAX_LEVELS], latent_value, lin_in, enc_c, qreh_c, lz_c[kBlocks], fc0_c[kBlocks],
         fc1_c[kBlocks], lout_c, chain_scale, mid_bias, tail_bias, total;
 };
 // car_linear_x3 wants rows of whole float4s and a K worth its 32-wide chunks; narrower levels stay on car_linear
@@ -390,8 +420,8 @@ Plan plan_layout(const car_dims& d) {
     p.blob = take(car_fused_blob_floats());
     p.fbias = take(car_fused_bias_floats());
     p.wpt = take((size_t)kC * 4);
-    p.r2w = take(car_round2_packed_floats());
-    p.r2b = take(car_round2_bias_floats());
+    p.r2qw = take(car_round2q_packed_floats());
+    p.r2qb = take(car_round2q_bias_floats());
     for (int l = 0; l < CAR_MAX_LEVELS; ++l) p.proj[l] = l < d.n_levels ? take(car_linear_packed_floats(d.level_c[l], kC)) : 0;
     // the same slices for the split-fp16 kernel (car_linear_x3), which car_project_maps takes for the levels it serves
     for (int l = 0; l < CAR_MAX_LEVELS; ++l) p.proj16[l] = (l < d.n_levels && level_on_f16_pipe(d.level_c[l])) ? take(car_linear_x3_packed_floats(d.level_c[l], kC)) : 0;
@@ -431,7 +461,7 @@ int check_dims(const car_dims* d, const char* who) {
 
 // ---- workspace layout ----------------------------------------------------------------------------------------------
 struct Work {
-    size_t rays, phi_x, e, q, g, logit, logit2, pt, pixel_val, coords, at_wt, at_wt2, amax, depth, ebar, z1, uh, valid, part, total;                                  // offsets in floats
+    size_t rays, phi_x, e, g, logit, logit2, pt, pixel_val, coords, at_wt, at_wt2, amax, depth, ebar, z1, uh, valid, part, total;                                  // offsets in floats
 };
 // step groups per (view, ray) of the first round's partial sums (car_fused_samples_parts)
 inline size_t step_groups(const car_dims& d) { const int ts = car_fused_tile_steps(); return (size_t)((d.P + ts - 1) / ts); }
@@ -443,7 +473,6 @@ Work work_layout(const car_dims& d) {
     w.rays = take(n * d.R * CAR_RAY_FLOATS);
     w.phi_x = take(BR * kPhiLd);
     w.e = take(S * kC);
-    w.q = take(S * kD);
     w.g = take(S * CAR_G_DIM);
     w.logit = take(S);
     w.logit2 = take(S);
@@ -533,6 +562,7 @@ extern "C" size_t car_workspace_bytes(const car_dims* dims) {
     if (check_dims(dims, "car_workspace_bytes") != CAR_OK) return 0;
     return work_layout(*dims).total * sizeof(float);
 }
+
 namespace {
 size_t lattice_floats(const car_dims& d) { const Lattice L = lattice_of(d); return (size_t)d.b * d.V * 2 * L.h * L.w * kC; }
 size_t level_floats(const car_dims& d, int l) { return (size_t)d.b * d.V * d.level_h[l] * d.level_w[l] * kC; }
@@ -564,7 +594,7 @@ extern "C" int car_workspace_find(const car_dims* dims, const char* name, size_t
     const Work w = work_layout(*dims);
     const size_t n = (size_t)dims->b * dims->V, S = n * dims->R * dims->P, BR = (size_t)dims->b * dims->R;
     const struct { const char* name; size_t off, cnt; } tab[] = {
-        {"rays", w.rays, n * dims->R * CAR_RAY_FLOATS}, {"e", w.e, S * kC}, {"qry", w.q, S * kD}, {"g", w.g, S * CAR_G_DIM},
+        {"rays", w.rays, n * dims->R * CAR_RAY_FLOATS}, {"e", w.e, S * kC}, {"g", w.g, S * CAR_G_DIM},
         {"logit", w.logit, S}, {"logit2", w.logit2, S}, {"pt", w.pt, S * 3}, {"at_wt2", w.at_wt2, S}, {"ebar", w.ebar, BR * kC},
         {"z1", w.z1, BR * kE}, {"uh", w.uh, BR * kD}, {"part", w.part, n * dims->R * step_groups(*dims) * kC}};
     for (const auto& t : tab)
@@ -581,7 +611,7 @@ extern "C" int car_fused_pack(const car_weights* w, float* blob_f, float* bias, 
                 w->key_map_w && w->key_map_b && w->key_map_2_w && w->key_map_2_b && w->query_embed_w && w->query_embed_b &&
                 w->query_embed_2_w && w->query_embed_2_b, "car_fused_pack: a weight pointer of the fused layers is null");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(bias, 0, sizeof(float) * kBiasFloats, st) != hipSuccess) { car_set_error("car_fused_pack: memset failed"); return CAR_E_LAUNCH; }
+    if (hipMemsetAsync(bias, 0, sizeof(float) * (kBiasFloats + kBiasScratch), st) != hipSuccess) { car_set_error("car_fused_pack: memset failed"); return CAR_E_LAUNCH; }
     _Float16* blob = reinterpret_cast<_Float16*>(blob_f);
     float* fdown = bias + kBiasScale;
     float* pscale = bias + kBiasScale + 8;                           // pack-time scratch: 2^shift per layer
@@ -593,22 +623,23 @@ extern "C" int car_fused_pack(const car_weights* w, float* blob_f, float* bias, 
         hipLaunchKernelGGL(pack16_kernel, dim3(256), dim3(256), 0, st, W, ldw, b, N, K, n_tiles, ksteps, mode, kbase, pscale + layer,
                            blob + (size_t)tile_off * kTile16 * 2);
     };
+    // the closing pair key_map_2 / query_embed_2 folded into one layer (car_fused_layout.h): M in fp32 behind the bias table, v, u, c inside it
+    float* Mf = bias + kBiasFloats;
+    hipLaunchKernelGGL(bilinear_fold_kernel, dim3(kD), dim3(kD), 0, st, w->key_map_2_w, w->key_map_2_b, w->query_embed_2_w, w->query_embed_2_b, kD, Mf,
+                       bias + kBiasV, bias + kBiasU, bias + kBiasConst);
     scale(w->query_encode_latent_2_w, kC, kE, kC, nullptr, kLayerW2);
     scale(w->query_embed_w, 16, kD, 16, w->query_embed_b, kLayerQ1);
-    scale(w->query_embed_2_w, kD, kD, kD, nullptr, kLayerQ2);
+    scale(Mf, kD, kD, kD, nullptr, kLayerM);
     scale(w->key_map_w, kC, kD, kC, nullptr, kLayerK1);
-    scale(w->key_map_2_w, kD, kD, kD, nullptr, kLayerK2);
     pack16(w->query_encode_latent_2_w, kC, nullptr, kE, kC, kTE, kKS, 0, 0, kLayerW2, kOffW2);
     pack16(w->query_embed_w, 16, w->query_embed_b, kD, 16, kTD, 1, 0, 0, kLayerQ1, kOffQ1);
-    pack16(w->query_embed_2_w, kD, nullptr, kD, kD, kTD, 4, 1, 0, kLayerQ2, kOffQ2);
+    pack16(Mf, kD, nullptr, kD, kD, kTD, 4, 1, 0, kLayerM, kOffM);
     pack16(w->key_map_w, kC, nullptr, kD, kC, kTD, 9, 1, 0, kLayerK1, kOffK1);
     pack16(w->key_map_w, kC, nullptr, kD, kC, kTD, 9, 1, kE, kLayerK1, kOffK1 + 9 * kTD);
-    pack16(w->key_map_2_w, kD, nullptr, kD, kD, kTD, 4, 1, 0, kLayerK2, kOffK2);
     hipLaunchKernelGGL(wpt_kernel, dim3(1), dim3(kC), 0, st, w->query_encode_latent_w, w->query_encode_latent_b, wpt, fdown + 5);
     CAR_CHECK_LAUNCH("car_fused_pack");
     auto d2d = [&](float* dst, const float* src, int n) { return hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToDevice, st) == hipSuccess; };
-    if (!d2d(bias + kBiasE, w->query_encode_latent_2_b, kE) || !d2d(bias + kBiasQ2, w->query_embed_2_b, kD) ||
-        !d2d(bias + kBiasK1, w->key_map_b, kD) || !d2d(bias + kBiasK2, w->key_map_2_b, kD)) {
+    if (!d2d(bias + kBiasE, w->query_encode_latent_2_b, kE) || !d2d(bias + kBiasK1, w->key_map_b, kD)) {
         car_set_error("car_fused_pack: bias copy failed");
         return CAR_E_LAUNCH;
     }
@@ -690,13 +721,45 @@ extern "C" int car_round2_pack(const float* wr1, const float* br1, const float* 
     return CAR_OK;
 }
 
+// For car_round2_logits_from_g (csrc/car_round2.hip, G instance): query_repeat_embed_2 and query_embed_2 folded into the one layer of the
+// bilinear form <q2, qry> = y^T (M x + v) + u^T x + c (M = Wr2^T Wq2, v = Wr2^T bq2, u = Wq2^T br2, c = <br2, bq2>; bilinear_fold_kernel) and the
+// two 16 -> 128 layers that make y and x from g.  wpacked [car_round2q_packed_floats()] = M (chained K order) | Wr1[:, 128:] | Wq1, each laid out
+// as car_round2_pack lays out its own; bias [car_round2q_bias_floats()] = br1 | v | bq1 | u | 2^-shift of Wr1g, M, Wq1 | c | scratch (their
+// 2^shift, then M in fp32).
+extern "C" int car_round2q_pack(const float* wr1, const float* br1, const float* wr2, const float* br2, const float* wq1, const float* bq1,
+                                const float* wq2, const float* bq2, float* wpacked, float* bias, void* stream) {
+    CAR_REQUIRE(wr1 && br1 && wr2 && br2 && wq1 && bq1 && wq2 && bq2 && wpacked && bias, "car_round2q_pack: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)car_round2q_bias_floats();
+    if (hipMemsetAsync(bias, 0, sizeof(float) * nb, st) != hipSuccess) { car_set_error("car_round2q_pack: memset failed"); return CAR_E_LAUNCH; }
+    float* down = bias + 4 * kD;                                     // [0] Wr1g, [1] M, [2] Wq1, [3] c; [4..6]: the layers' 2^shift (pack-time scratch)
+    float* Mf = bias + 4 * kD + 8;                                   // scratch: M in fp32
+    _Float16* out = reinterpret_cast<_Float16*>(wpacked);
+    const size_t first = (size_t)4 * 4 * 2 * 2 * 64 * 8, small = (size_t)4 * 2 * 64 * 8;                  // halves: the 128 x 128 layer, a 128 x 16 layer
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(bilinear_fold_kernel, dim3(kD), dim3(kD), 0, st, wr2, br2, wq2, bq2, kD, Mf, bias + kD, bias + 3 * kD, down + 3);
+    hipLaunchKernelGGL(layer_scale_kernel, dim3(1), dim3(1024), 0, st, wr1 + kD, kD + 16, kD, 16, (const float*)nullptr, down + 4, down + 0);
+    hipLaunchKernelGGL(layer_scale_kernel, dim3(1), dim3(1024), 0, st, Mf, kD, kD, kD, (const float*)nullptr, down + 5, down + 1);
+    hipLaunchKernelGGL(layer_scale_kernel, dim3(1), dim3(1024), 0, st, wq1, 16, kD, 16, (const float*)nullptr, down + 6, down + 2);
+    hipLaunchKernelGGL(pack32_kernel, dim3(128), dim3(256), 0, st, Mf, kD, 4, 2, 1, down + 5, out);
+    hipLaunchKernelGGL(pack32_kernel, dim3(16), dim3(256), 0, st, wr1 + kD, kD + 16, 1, 1, 0, down + 4, out + first);
+    hipLaunchKernelGGL(pack32_kernel, dim3(16), dim3(256), 0, st, wq1, 16, 1, 1, 0, down + 6, out + first + small);
+    CAR_CHECK_LAUNCH("car_round2q_pack");
+    if (hipMemcpyAsync(bias, br1, sizeof(float) * kD, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(bias + 2 * kD, bq1, sizeof(float) * kD, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        car_set_error("car_round2q_pack: bias copy failed");
+        return CAR_E_LAUNCH;
+    }
+    return CAR_OK;
+}
+
 extern "C" int car_plan_build(const car_dims* dims, const car_weights* w, void* plan, void* stream) {
     CAR_TRY(check_dims(dims, "car_plan_build"));
     CAR_REQUIRE(w && plan, "car_plan_build: null pointer");
     const float* const* all = reinterpret_cast<const float* const*>(w);
     for (size_t k = 0; k < sizeof(car_weights) / sizeof(const float*); ++k)
         CAR_REQUIRE(all[k], "car_plan_build: weight pointer %zu of car_weights is null", k);
-    CAR_REQUIRE(car_fused_blob_floats() == (size_t)kBlobTiles * kTile && car_fused_bias_floats() == (size_t)kBiasFloats,
+    CAR_REQUIRE(car_fused_blob_floats() == (size_t)kBlobTiles * kTile && car_fused_bias_floats() == (size_t)(kBiasFloats + kBiasScratch),
                 "car_plan_build: the fused kernel was built with another weight layout");
     const Plan p = plan_layout(*dims);
     float* base = static_cast<float*>(plan);
@@ -714,8 +777,8 @@ extern "C" int car_plan_build(const car_dims* dims, const car_weights* w, void* 
     }
     // split-fp16 operand tiles of the fused per-sample kernel and of the round-2 kernel
     CAR_TRY(car_fused_pack(w, base + p.blob, base + p.fbias, base + p.wpt, stream));
-    CAR_TRY(car_round2_pack(w->query_repeat_embed_w, w->query_repeat_embed_b, w->query_repeat_embed_2_w, w->query_repeat_embed_2_b,
-                            base + p.r2w, base + p.r2b, stream));
+    CAR_TRY(car_round2q_pack(w->query_repeat_embed_w, w->query_repeat_embed_b, w->query_repeat_embed_2_w, w->query_repeat_embed_2_b,
+                             w->query_embed_w, w->query_embed_b, w->query_embed_2_w, w->query_embed_2_b, base + p.r2qw, base + p.r2qb, stream));
     // fp32 MFMA layers (car_linear.hip)
     int coff = 0;
     for (int l = 0; l < dims->n_levels; ++l) {
@@ -837,11 +900,11 @@ static int render_phases(const car_dims* dims, const void* plan, const car_input
         const Lattice L = lattice_of(d);
         if (rows_first)
             CAR_TRY(car_fused_samples(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->gmeta, pl + p.wpt, pl + p.blob,
-                                      pl + p.fbias, b, V, R, P, d.H, d.W, d.no_sample != 0, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
+                                      pl + p.fbias, b, V, R, P, d.H, d.W, d.no_sample != 0, ws + w.e, ws + w.g, ws + w.logit, ws + w.pt, pixel_val, stream));
         else
             CAR_TRY(car_fused_samples_parts(in->poses, ws + w.rays, steps, in->lattice, L.h, L.w, L.pad, in->gmeta, pl + p.wpt, pl + p.blob,
-                                            pl + p.fbias, b, V, R, P, d.H, d.W, d.no_sample != 0, ws + w.e, ws + w.q, ws + w.g, ws + w.logit, ws + w.pt,
-                                            pixel_val, ws + w.part, stream));
+                                            pl + p.fbias, b, V, R, P, d.H, d.W, d.no_sample != 0, ws + w.e, ws + w.g, ws + w.logit, ws + w.pt, pixel_val,
+                                            ws + w.part, stream));
     }
     }
     if (!(phases & CAR_PHASE_RAYS)) return CAR_OK;
@@ -872,7 +935,8 @@ static int render_phases(const car_dims* dims, const void* plan, const car_input
         }
         {   // a15, per sample: second-round query and logits
             Stage stage("round2_logits", st);
-            CAR_TRY(car_round2_logits(ws + w.g, ws + w.uh, ws + w.q, pl + p.r2w, pl + p.r2b, b, V, R, P, ws + w.logit2, stream));
+            // no 128-wide query rows exist on this route: <q2, qry> is a bilinear form of two hidden vectors both made from g (car_round2.hip)
+            CAR_TRY(car_round2_logits_from_g(ws + w.g, ws + w.uh, pl + p.r2qw, pl + p.r2qb, b, V, R, P, ws + w.logit2, stream));
         }
         {
             Stage stage("attend_2", st);

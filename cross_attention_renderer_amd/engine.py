@@ -437,6 +437,8 @@ class RenderEngine:
         _lib.check(lib.car_lattice_shape(ctypes.byref(d_all), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(lpad)), "car_lattice_shape")
         lattice_scene = V * 2 * lh.value * lw.value * 576                                        # floats per scene
 
+        phases = 1 | 2 | (0 if self.first_round_parts else 4)
+
         def ws_bytes(nb, nr):
             return lib.car_workspace_bytes(ctypes.byref(self._dims(nb, nr, z)))
 
@@ -523,12 +525,12 @@ class RenderEngine:
                     ci.gmeta = gmeta_ptr
                     ci.steps = steps.data_ptr()
                     co = _lib.CarOutputs(*[tgt[k].data_ptr() for k in order])
-                    if self.first_round_parts:
+                    if phases == 3:
                         _lib.check(lib.car_render_forward(ctypes.byref(d), _ptr(plan), ctypes.byref(ci), ctypes.byref(co),
                                                           _ptr(work), work.numel() * 4, st), "car_render_forward")
                     else:
                         _lib.check(lib.car_render_forward_phase(ctypes.byref(d), _ptr(plan), ctypes.byref(ci), ctypes.byref(co),
-                                                                _ptr(work), work.numel() * 4, 1 | 2 | 4, st), "car_render_forward_phase")
+                                                                _ptr(work), work.numel() * 4, phases, st), "car_render_forward_phase")
                     if not whole:
                         for k in order:
                             dst = out[k][:, 0] if k == "rgb" else out[k]

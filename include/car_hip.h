@@ -142,8 +142,8 @@ int car_lattice_encode_linear(const float* lattice, int lat_h, int lat_w, int la
 
 /* ---- a6-a13 + logits of a14 in ONE kernel for the default configuration (V = 2, C = 576, hidden 128): geometry, the
  * per-texel-projected encode (car_gather_encode's arithmetic, with ALL pyramid levels summed once per stereo pair on their common
- * lattice: four taps per sample and source instead of four per level), 576->288 per source, key MLP, query MLP and the round-1
- * logits, with e / key / qry chained through the MFMA accumulator registers (csrc/car_fused.hip; models.py:261-344, 487-532).
+ * lattice: four taps per sample and source instead of four per level), 576->288 per source, key_map, query_embed and the round-1
+ * logits, every layer chained through the MFMA accumulator registers (csrc/car_fused.hip; models.py:261-344, 487-532).
  * Every layer runs on the f16 matrix pipe with both operands split into fp16 high/low halves (three products per term,
  * fp32-class accuracy).  `blob` / `bias` are the layer weights in the kernel's operand order: car_fused_blob_floats() /
  * car_fused_bias_floats() floats, written by car_plan_build (layout: csrc/car_fused_mma.h; the fp16 halves of each layer carry
@@ -155,38 +155,40 @@ int car_lattice_encode_linear(const float* lattice, int lat_h, int lat_w, int la
  * from which the kernel derives the power of two that keeps the activations of the first layer inside fp16's range.
  * `no_sample` = 1: `rays` come from car_ray_setup(no_sample = 1) and `steps` holds the P depths (models.py:221-222): a sample is the
  * projection of the query ray's point at that depth instead of a point of the clipped epipolar segment; everything after it is the same.
- * Outputs: e [S,576], qry [S,128], g [S,16] (the geometric query local_coords, models.py:528), logit [S], pt [S,3],
- * pixel_val [S,2] with S = b*V*R*P.  The lattice of one (view, padding mode) must stay below 2 GiB (nodes are addressed by 32-bit
+ * Outputs: e [S,576], g [S,16] (the geometric query local_coords, models.py:528), logit [S], pt [S,3],
+ * pixel_val [S,2] with S = b*V*R*P.  Neither key nor qry (models.py:491, 529) is formed: logit = <key, qry> / 16 is evaluated as the bilinear
+ * form r^T (M x + v) + u^T x + c of r = relu(key_map(e)) and x = relu(query_embed(g)) with M = Wk2^T Wq2 folded once per checkpoint by
+ * car_fused_pack (csrc/car_fused_layout.h) — one 128 x 128 layer per sample instead of key_map_2 and query_embed_2.  The lattice of one (view, padding mode) must stay below 2 GiB (nodes are addressed by 32-bit
  * byte offsets with the upper range reserved for samples that read zeros): a finest level up to ~470 pixels wide; wider pyramids take the
  * stage entries (the Python engine falls back by itself). */
 size_t car_fused_blob_floats(void);
 size_t car_fused_bias_floats(void);
 int car_fused_samples(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
                       int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R, int P,
-                      int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val, void* stream);
+                      int H, int W, int no_sample, float* e, float* g, float* logit, float* pt, float* pixel_val, void* stream);
 /* The same launch, which also leaves the FIRST attention round's value sum of every (view, ray, group of car_fused_tile_steps()
  * consecutive steps) in `part` [b*V][R][ceil(P / tile_steps)][576]: sum_j exp(logit_j - m) e_j over the group's samples, m their largest
  * logit — each workgroup reads the rows of e it has just written back from L2, an eighth of the bytes the attention launch would
  * otherwise stream from HBM.  car_attend_parts (below) folds a ray's groups together; models.py:533-541. */
-/* The kernel's source pass alone, over explicit rows (the three-view exchange, models.py:345-475): row = sample * ncomp + comp gathers the
- * merged lattice of map (row_src & 0x3fffffff), padding mode (row_src >> 30) & 1 at row_grid [2], adds the point term of row_pe [4] (as
- * car_lattice_encode_rows) and runs the second point-MLP layer: e [rows][288].  Samples are [n_sets][R][P]; every 24-ray x 8-step tile of one
- * (set, comp) must share its (map, padding mode).  lattice: car_merge_lattice; gmeta [1]: its largest magnitude; blob / bias / wpt:
- * car_fused_pack_rows(W1 [576][579], b1, W2 [288][576], b2, ...) with car_fused_blob_floats() / car_fused_bias_floats() / 576 * 4 floats. */
+int car_fused_tile_steps(void);
+int car_fused_samples_parts(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
+                            int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,
+                            int P, int H, int W, int no_sample, float* e, float* g, float* logit, float* pt, float* pixel_val,
+                            float* part, void* stream);
 /* The exchange's row lists on the device: for samples [n_scenes*V][pts] with car_sample_setup's pixel_val [.,2], pt_in [.,V,3] (the point in every
  * context frame) and ptenc [.,V,4] (its tanh encoding), row (sample, k) = component k of sample: k = 0 own view (border padding, own grid point),
  * k >= 1 the other views o in ascending order (zeros padding) at the projection of CONTEXT o's sample of the same index moved into the sample's frame. */
 int car_exchange_rows(const float* poses, const float* pixel_val, const float* pt_in, const float* ptenc, int n_scenes, int V, long pts, int H,
                       int W, int* row_src, float* row_grid, float* row_pe, void* stream);
+/* The kernel's source pass alone, over explicit rows (the three-view exchange, models.py:345-475): row = sample * ncomp + comp gathers the
+ * merged lattice of map (row_src & 0x3fffffff), padding mode (row_src >> 30) & 1 at row_grid [2], adds the point term of row_pe [4] (as
+ * car_lattice_encode_rows) and runs the second point-MLP layer: e [rows][288].  Samples are [n_sets][R][P]; every 24-ray x 8-step tile of one
+ * (set, comp) must share its (map, padding mode).  lattice: car_merge_lattice; gmeta [1]: its largest magnitude; blob / bias / wpt:
+ * car_fused_pack_rows(W1 [576][579], b1, W2 [288][576], b2, ...) with car_fused_blob_floats() / car_fused_bias_floats() / 576 * 4 floats. */
 int car_fused_pack_rows(const float* w1, const float* b1, const float* w2, const float* b2, float* blob, float* bias, float* wpt, void* stream);
 int car_fused_rows(const float* lattice, int lat_h, int lat_w, int lat_pad, const float* gmeta, const float* wpt, const float* blob,
                    const float* bias, const int* row_src, const float* row_grid, const float* row_pe, int n_sets, int R, int P, int ncomp,
                    float* e, void* stream);
-int car_fused_tile_steps(void);
-int car_fused_samples_parts(const float* poses, const float* rays, const float* steps, const float* lattice, int lat_h, int lat_w,
-                            int lat_pad, const float* gmeta, const float* wpt, const float* blob, const float* bias, int b, int V, int R,
-                            int P, int H, int W, int no_sample, float* e, float* qry, float* g, float* logit, float* pt, float* pixel_val,
-                            float* part, void* stream);
 
 /* ---- 1x1 convolutions / linear layers on channel-last rows, fp32 MFMA (models.py:333-341, 487-491, 529, 548, 553;
  *      resnet_block_fc.py:53-62, 132-168).  Y[M,N] = act(X[M,K] W^T + bias).
@@ -236,7 +238,8 @@ int car_attend(const float* qa, const float* qb, int dq, const float* val, int D
                const float* pt, const float* poses, float* depth, int32_t* w_argmax, void* stream);
 /* The same round from precomputed logits [b*V,R,P] and per-step-group partial value sums `part` [b*V][R][ceil(P / tile_steps)][D]
  * (car_fused_samples_parts): z_out = sum_g exp(m_g - M) / L part_g, with m_g the group's largest logit, M the ray's, L the softmax
- * denominator — the same sum as car_attend's over the sample rows; w_out, depth and w_argmax exactly as car_attend computes them. */
+ * denominator — the same sum as car_attend's over the sample rows; w_out, depth and w_argmax exactly as car_attend computes them.
+ * `tile_steps` must be car_fused_tile_steps() (the group size `part` was made with; checked). */
 int car_attend_parts(const float* logit, const float* part, int tile_steps, int D, int b, int V, int R, int P, float* w_out,
                      float* z_out, int ld_z, int reps, const float* pt, const float* poses, float* depth, int32_t* w_argmax,
                      void* stream);
@@ -251,6 +254,18 @@ size_t car_round2_packed_floats(void);
 size_t car_round2_bias_floats(void);
 int car_round2_logits(const float* g, const float* uh, const float* qry, const float* wpacked, const float* bias,
                       int b, int V, int R, int P, float* logit, void* stream);
+/* The same logits WITHOUT any 128-wide rows (the one-call forward's form since round 6).  With y = relu(Wr1[:,128:] g + br1 + uh) and
+ * x = relu(Wq1 g + bq1) (query_embed, models.py:126, 529) the product <Wr2 y + br2, Wq2 x + bq2> is the bilinear form
+ *     y^T (M x + v) + u^T x + c,   M = Wr2^T Wq2,  v = Wr2^T bq2,  u = Wq2^T br2,  c = <br2, bq2>
+ * folded once per checkpoint by car_round2q_pack (fp64 accumulation, rounded once to fp32): ONE 128 x 128 layer per sample — no more matrix
+ * work than car_round2_logits spends on q2 alone — and the first round's query rows are neither written (car_fused_samples folds its own
+ * pair of closing layers the same way and forms no qry) nor read: 2 x 4.3 GB per 65 536-ray frame.  Same arithmetic otherwise
+ * (v_mfma_f32_32x32x16_f16, fp16 hi / lo halves, per-sample powers of two); agrees with car_round2_logits on stored rows to fp32 rounding.
+ * wpacked [car_round2q_packed_floats()], bias [car_round2q_bias_floats()]: car_round2q_pack. */
+size_t car_round2q_packed_floats(void);
+size_t car_round2q_bias_floats(void);
+int car_round2_logits_from_g(const float* g, const float* uh, const float* wpacked, const float* bias, int b, int V, int R, int P,
+                             float* logit, void* stream);
 
 /* r[row, c] = relu(r[row, c] + u[ray(row), c]) with ray(row) = scene b, ray r of the sample row (models.py:549-553:
  * the z_embed half of query_repeat_embed is constant along the samples of a ray). r [b*V,R,P,C], u [b,R,C]. */
@@ -383,6 +398,11 @@ typedef struct car_outputs {       /* the tensors of the reference's output dict
  *                    wpacked [car_round2_packed_floats()], bias [car_round2_bias_floats()] for car_round2_logits. */
 int car_fused_pack(const car_weights* weights, float* blob, float* bias, float* wpt, void* stream);
 int car_round2_pack(const float* wr1, const float* br1, const float* wr2, const float* br2, float* wpacked, float* bias, void* stream);
+/*   car_round2q_pack: wr1, wr2 as above, wq1 = query_embed.weight (128, 16), wq2 = query_embed_2.weight (128, 128) -> the folded layer
+ *                    M = wr2^T wq2 and the two 16 -> 128 layers, wpacked [car_round2q_packed_floats()], bias [car_round2q_bias_floats()]
+ *                    (the table and the packer's scratch behind it) for car_round2_logits_from_g. */
+int car_round2q_pack(const float* wr1, const float* br1, const float* wr2, const float* br2, const float* wq1, const float* bq1,
+                     const float* wq2, const float* bq2, float* wpacked, float* bias, void* stream);
 
 size_t car_plan_bytes(const car_dims* dims);
 int car_plan_build(const car_dims* dims, const car_weights* weights, void* plan, void* stream);
@@ -398,7 +418,7 @@ size_t car_workspace_bytes(const car_dims* dims);
 int car_render_forward(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
                        void* workspace, size_t workspace_bytes, void* stream);
 /* The same launches in two phases, for hosts that overlap them across batches of rays on two streams (engine.py):
- * CAR_PHASE_SAMPLES = rays + the fused per-sample kernel (matrix-pipe / power bound; writes e, qry, g, logit, pt into the workspace),
+ * CAR_PHASE_SAMPLES = rays + the fused per-sample kernel (matrix-pipe / power bound; writes e, g, logit, pt into the workspace),
  * CAR_PHASE_RAYS = both attention rounds and the per-ray chains (HBM bound; reads them, writes the outputs).  The second phase of a
  * batch must be ordered after its first phase (an event) and use the same dims / inputs / outputs / workspace; batches with their own
  * workspaces are independent.  phases = both is car_render_forward.
@@ -411,7 +431,7 @@ int car_render_forward(const car_dims* dims, const void* plan, const car_inputs*
 int car_render_forward_phase(const car_dims* dims, const void* plan, const car_inputs* in, const car_outputs* out,
                              void* workspace, size_t workspace_bytes, int phases, void* stream);
 /* Where a named intermediate lives inside the workspace after car_render_forward (tests, debugging, profiling): one of
- * "rays" "e" "qry" "g" "logit" "logit2" "pt" "at_wt2" "ebar" "z1" "uh" "part".  Returns 0 and the float offset / count. */
+ * "rays" "e" "g" "logit" "logit2" "pt" "at_wt2" "ebar" "z1" "uh" "part".  Returns 0 and the float offset / count. */
 int car_workspace_find(const car_dims* dims, const char* name, size_t* offset_floats, size_t* n_floats);
 
 /* ---- stage timing (the reference's only hooks are record_function labels, resnet_block_fc.py:54, 139, and one time.time() pair,

@@ -189,17 +189,17 @@ def case_fused(R, P, b, tail):
     torch.cuda.synchronize()
     t = {"poses": out["stages"]["poses"].to(dev).contiguous(), "rays": out["stages"]["rays"].contiguous(), "steps": torch.linspace(0, 1, P).to(dev),
          "lattice": pair[:nlat].clone(), "gmeta": pair[goff:goff + 4].clone(), "wpt": wpt, "blob": blob, "bias": bias,
-         "e": torch.zeros(S, 576, device=dev), "qry": torch.zeros(S, 128, device=dev), "g": torch.zeros(S, 16, device=dev),
+         "e": torch.zeros(S, 576, device=dev), "g": torch.zeros(S, 16, device=dev),
          "logit": torch.zeros(S, device=dev), "pt": torch.zeros(S, 3, device=dev), "pixel_val": torch.zeros(S, 2, device=dev),
          "part": torch.zeros(n * R * (-(-P // ts)), 576, device=dev)}
-    outs = ["e", "qry", "g", "logit", "pt", "pixel_val", "part"]
+    outs = ["e", "g", "logit", "pt", "pixel_val", "part"]
     run_both(lambda p: L.check(lib.car_fused_samples_parts(p("poses"), p("rays"), p("steps"), p("lattice"), lh.value, lw.value, lpad.value, p("gmeta"),
-                                                           p("wpt"), p("blob"), p("bias"), b, V, R, P, H, H, 0, p("e"), p("qry"), p("g"), p("logit"),
+                                                           p("wpt"), p("blob"), p("bias"), b, V, R, P, H, H, 0, p("e"), p("g"), p("logit"),
                                                            p("pt"), p("pixel_val"), p("part"), stream()), "car_fused_samples_parts"), t, outs, tail)
 
 
 def case_tail_kernels(R, P, b, tail):
-    """car_attend_parts, car_attend and car_round2_logits on the tensors a real forward left in its workspace."""
+    """car_attend_parts, car_attend, car_round2_logits and car_round2_logits_from_g on the tensors a real forward left in its workspace."""
     lib = L.load()
     md, eng, z, out, dinp, H = _forward_state(R, P, b)
     d = eng._dims(b, R, z)
@@ -220,10 +220,22 @@ def case_tail_kernels(R, P, b, tail):
                                               p("depth"), p("amax"), stream()), "car_attend"), t, list(outs), tail)
     r2w, r2b = eng._round2_weights(dev)
     torch.cuda.synchronize()
-    t = {"g": _ws(eng, lib, d, "g"), "uh": _ws(eng, lib, d, "uh"), "qry": _ws(eng, lib, d, "qry"), "r2w": r2w.clone(), "r2b": r2b.clone(),
+    qry = torch.randn(S, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(3))      # stored query rows: the staged routes' form
+    t = {"g": _ws(eng, lib, d, "g"), "uh": _ws(eng, lib, d, "uh"), "qry": qry, "r2w": r2w.clone(), "r2b": r2b.clone(),
          "logit2": torch.zeros(S, device=dev)}
     run_both(lambda p: L.check(lib.car_round2_logits(p("g"), p("uh"), p("qry"), p("r2w"), p("r2b"), b, V, R, P, p("logit2"), stream()),
                                "car_round2_logits"), t, ["logit2"], tail)
+    r2qw = torch.empty(lib.car_round2q_packed_floats(), device=dev)
+    r2qb = torch.empty(lib.car_round2q_bias_floats(), device=dev)
+    ps = [x.detach().float().reshape(x.shape[0], -1).contiguous() for x in
+          (md.query_repeat_embed.weight, md.query_repeat_embed.bias, md.query_repeat_embed_2.weight, md.query_repeat_embed_2.bias,
+           md.query_embed.weight, md.query_embed.bias, md.query_embed_2.weight, md.query_embed_2.bias)]
+    L.check(lib.car_round2q_pack(*[ctypes.c_void_p(x.data_ptr()) for x in ps], ctypes.c_void_p(r2qw.data_ptr()), ctypes.c_void_p(r2qb.data_ptr()),
+                                 stream()), "car_round2q_pack")
+    torch.cuda.synchronize()
+    t = {"g": _ws(eng, lib, d, "g"), "uh": _ws(eng, lib, d, "uh"), "r2qw": r2qw, "r2qb": r2qb, "logit2": torch.zeros(S, device=dev)}
+    run_both(lambda p: L.check(lib.car_round2_logits_from_g(p("g"), p("uh"), p("r2qw"), p("r2qb"), b, V, R, P, p("logit2"), stream()),
+                               "car_round2_logits_from_g"), t, ["logit2"], tail)
 
 
 def case_exchange(rows, N, tail=True):

@@ -55,24 +55,42 @@ def pack_tiles16(W: Tensor, bias: Optional[Tensor], n_tiles: int, kmap: Tensor, 
     return both.view(torch.float32).reshape(ks, n_tiles, 512)
 
 
-LAYERS = ("W2", "Q1", "Q2", "K1", "K2")
+LAYERS = ("W2", "Q1", "M", "K1")
+
+
+def bilinear_fold(wa: Tensor, ba: Tensor, wb: Tensor, bb: Tensor):
+    """<Wa r + ba, Wb x + bb> = r^T (M x + v) + u^T x + c: M = Wa^T Wb, v = Wa^T bb, u = Wb^T ba, c = <ba, bb>, accumulated in fp64 in
+    ascending k exactly as bilinear_fold_kernel (csrc/car_render.hip) does, rounded once to fp32."""
+    wa, wb, ba, bb = wa.double(), wb.double(), ba.double(), bb.double()
+    D = wa.shape[0]
+    M = torch.zeros(D, D, dtype=torch.float64)
+    v = torch.zeros(D, dtype=torch.float64)
+    u = torch.zeros(D, dtype=torch.float64)
+    c = torch.zeros((), dtype=torch.float64)
+    for k in range(D):
+        M += wa[k][:, None] * wb[k][None, :]
+        v += wa[k] * bb[k]
+        u += wb[k] * ba[k]
+        c += ba[k] * bb[k]
+    return M.float(), v.float(), u.float(), c.float()
 
 
 def pack_fused(m):
-    """(blob, bias table, wpt) of csrc/car_fused.hip for the module's parameters (layout: csrc/car_fused_layout.h)."""
+    """(blob, bias table + scratch, wpt) of csrc/car_fused.hip for the module's parameters (layout: csrc/car_fused_layout.h): key_map_2 and
+    query_embed_2 enter only through their bilinear fold M, v, u, c."""
     f = lambda t: t.detach().float().cpu().reshape(t.shape[0], -1)
     v = lambda t: t.detach().float().cpu()
     C = m.query_encode_latent.weight.shape[0]
     E2 = C // 2
-    w2, q1, q2, k1, k2 = f(m.query_encode_latent_2.weight), f(m.query_embed.weight), f(m.query_embed_2.weight), f(m.key_map.weight), f(m.key_map_2.weight)
+    w2, q1, k1 = f(m.query_encode_latent_2.weight), f(m.query_embed.weight), f(m.key_map.weight)
+    M, fv, fu, fc = bilinear_fold(f(m.key_map_2.weight), v(m.key_map_2.bias), f(m.query_embed_2.weight), v(m.query_embed_2.bias))
     p = {"W2": pow2_scale(w2.abs().max().item()), "Q1": pow2_scale(max(q1.abs().max().item(), v(m.query_embed.bias).abs().max().item())),
-         "Q2": pow2_scale(q2.abs().max().item()), "K1": pow2_scale(k1.abs().max().item()), "K2": pow2_scale(k2.abs().max().item())}
+         "M": pow2_scale(M.abs().max().item()), "K1": pow2_scale(k1.abs().max().item())}
     parts = [
         pack_tiles16(w2, None, E2 // 16, std16_k(C // 32), p["W2"]),
         pack_tiles16(q1, v(m.query_embed.bias), 8, std16_k(1), p["Q1"]),
-        pack_tiles16(q2, None, 8, chained16_k(4), p["Q2"]),
+        pack_tiles16(M, None, 8, chained16_k(4), p["M"]),
         torch.cat([pack_tiles16(k1, None, 8, chained16_k(E2 // 32, base=E2 * sv), p["K1"]) for sv in range(2)]),
-        pack_tiles16(k2, None, 8, chained16_k(4), p["K2"]),
     ]
     blob = torch.cat([x.reshape(-1) for x in parts])
     w1 = f(m.query_encode_latent.weight)
@@ -83,7 +101,8 @@ def pack_fused(m):
         scales[8 + i] = p[n]
     a = wpt.abs()
     scales[5] = (((a[:, 0] + a[:, 1]) + a[:, 2]) + a[:, 3]).max()
-    bias = torch.cat([v(m.query_encode_latent_2.bias), v(m.query_embed_2.bias), v(m.key_map.bias), v(m.key_map_2.bias), scales])
+    scales[6] = fc
+    bias = torch.cat([v(m.query_encode_latent_2.bias), fv, v(m.key_map.bias), fu, scales, M.reshape(-1)])      # M: the packer's scratch
     return blob, bias, wpt
 
 
@@ -113,4 +132,19 @@ def pack_round2(m):
     packed = torch.cat([pack_tiles32(wr2, 4, 2, True, p2), pack_tiles32(wr1, 1, 1, False, p1)])
     bias = torch.cat([m.query_repeat_embed.bias.detach().float().cpu(), m.query_repeat_embed_2.bias.detach().float().cpu(),
                       torch.tensor([1.0 / p1, 1.0 / p2, p1, p2])])
+    return packed, bias
+
+
+def pack_round2q(m):
+    """(packed weights, bias table + scratch) of car_round2_logits_from_g: M = Wr2^T Wq2 in the chained K order, then Wr1[:, 128:] and Wq1;
+    bias = br1 | v | bq1 | u | 2^-shift of (Wr1g, M, Wq1) | c | their 2^shift | 0 | M in fp32 (scratch)."""
+    f = lambda t: t.detach().float().cpu().reshape(t.shape[0], -1)
+    v = lambda t: t.detach().float().cpu()
+    wr1 = f(m.query_repeat_embed.weight)[:, 128:].contiguous()
+    wq1 = f(m.query_embed.weight).contiguous()
+    M, fv, fu, fc = bilinear_fold(f(m.query_repeat_embed_2.weight), v(m.query_repeat_embed_2.bias), f(m.query_embed_2.weight), v(m.query_embed_2.bias))
+    p1, pm, pq = pow2_scale(wr1.abs().max().item()), pow2_scale(M.abs().max().item()), pow2_scale(wq1.abs().max().item())
+    packed = torch.cat([pack_tiles32(M, 4, 2, True, pm), pack_tiles32(wr1, 1, 1, False, p1), pack_tiles32(wq1, 1, 1, False, pq)])
+    bias = torch.cat([v(m.query_repeat_embed.bias), fv, v(m.query_embed.bias), fu, torch.tensor([1.0 / p1, 1.0 / pm, 1.0 / pq]), fc.reshape(1),
+                      torch.tensor([p1, pm, pq, 0.0]), M.reshape(-1)])
     return packed, bias

@@ -46,13 +46,24 @@ def test_round5_entries_validate_their_arguments(lib):
     assert lib.car_kq_tail_floats() == 72 * 512 and lib.car_kq_bias_floats() == 2 * 128 + 16
     assert lib.car_attend_parts(None, None, 8, 576, 1, 2, 8, 8, None, None, 576, 1, None, None, None, None, None) == -1
     assert b"null pointer" in lib.car_last_error()
-    assert lib.car_fused_samples_parts(*([None] * 4), 521, 521, 5, *([None] * 4), 1, 2, 8, 8, 256, 256, 0, *([None] * 7), None) == -1
+    assert lib.car_fused_samples_parts(*([None] * 4), 521, 521, 5, *([None] * 4), 1, 2, 8, 8, 256, 256, 0, *([None] * 6), None) == -1
     assert lib.car_lattice_encode_linear(None, 37, 37, 5, None, None, None, None, 1, 16, None, None, 576, 288, None, 288, 0, None) == -1
     assert lib.car_fused_rows(None, 37, 37, 5, *([None] * 7), 1, 8, 8, 3, None, None) == -1
     assert lib.car_key_query_logits(None, 576, None, None, 576, None, None, None, 16, None, None, None) == -1
     assert lib.car_kq_pack(*([None] * 9)) == -1 and lib.car_fused_pack_rows(*([None] * 8)) == -1
     assert lib.car_exchange_rows(None, None, None, None, 1, 3, 8, 64, 64, None, None, None, None) == -1
     assert lib.car_linear_wgrad(None, 4, None, 4, 8, 4, 4, 16, None, 4, None, None) == -1
+
+
+def test_round6_entries_validate_their_arguments(lib):
+    """The entries added in round 6: sizes without a GPU, codes (never aborts) on null pointers."""
+    # the folded 128 x 128 layer and two 128 x 16 layers as fp16 hi / lo tiles (64 + 8 + 8 KB); four vectors + scales, then 128 x 128 of scratch
+    assert lib.car_round2q_packed_floats() == lib.car_round2_packed_floats() + 2048 and lib.car_round2q_bias_floats() == 4 * 128 + 8 + 128 * 128
+    assert lib.car_fused_bias_floats() == 288 + 3 * 128 + 16 + 128 * 128                                # the table + the packer's scratch
+    assert lib.car_round2_logits_from_g(None, None, None, None, 1, 2, 8, 8, None, None) == -1
+    assert b"null pointer" in lib.car_last_error()
+    assert lib.car_round2q_pack(*([None] * 11)) == -1
+    assert lib.car_attend_parts(None, None, 4, 576, 1, 2, 8, 8, None, None, 576, 1, None, None, None, None, None) == -1
 
 
 def test_product_package_never_imports_the_oracle():
@@ -103,7 +114,7 @@ def test_one_call_abi_host_side(lib):
     for l, (c, h) in enumerate(((256, 64), (256, 128), (64, 256))):
         d.level_c[l], d.level_h[l], d.level_w[l] = c, h, h
     S = 2 * 8192 * 64
-    assert lib.car_workspace_bytes(ctypes.byref(d)) >= 4 * S * (576 + 128 + 16)           # e, qry, g dominate
+    assert 4 * S * (576 + 128) > lib.car_workspace_bytes(ctypes.byref(d)) >= 4 * S * (576 + 16)      # e, g dominate; no 128-wide query rows
     assert lib.car_plan_bytes(ctypes.byref(d)) >= 4 * (lib.car_fused_blob_floats() + lib.car_round2_packed_floats())
     # the three levels (64, 128, 256 wide: factors 4, 2, 1) share the lattice u in [-5, 515] (pad = r_max + 1 = 5)
     lh, lw, pad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

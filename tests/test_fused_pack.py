@@ -55,11 +55,15 @@ def test_fused_blob_layout():
     y = _walk16(halves(324, 332, 1, 8), gin) * down["Q1"]
     want = m.query_embed.weight.detach().reshape(128, 16).double() @ gq + m.query_embed.bias.detach().double()
     assert (y - want).abs().max() < 1e-5
-    # Q2 / K2: chained over a 128-wide accumulator set (8 source tiles, 4 K steps)
-    for off, layer, name in ((332, m.query_embed_2, "Q2"), (508, m.key_map_2, "K2")):
-        x = torch.randn(128, generator=g).double()
-        y = _walk16(halves(off, off + 32, 4, 8), chained(x)) * down[name]
-        assert (y - layer.weight.detach().reshape(128, 128).double() @ x).abs().max() < 1e-5
+    # M = Wk2^T Wq2: chained over a 128-wide accumulator set (8 source tiles, 4 K steps); with v, u, c it reproduces <key, qry> of the two
+    # closing layers for any pair of hidden vectors (models.py:491, 529, 533)
+    x, r = torch.randn(128, generator=g).double(), torch.randn(128, generator=g).double()
+    wk2, bk2 = m.key_map_2.weight.detach().reshape(128, 128).double(), m.key_map_2.bias.detach().double()
+    wq2, bq2 = m.query_embed_2.weight.detach().reshape(128, 128).double(), m.query_embed_2.bias.detach().double()
+    y = _walk16(halves(332, 364, 4, 8), chained(x)) * down["M"]
+    assert (y - wk2.T @ wq2 @ x).abs().max() < 1e-5
+    folded = r @ (y + bias[288:416].double()) + bias[544:672].double() @ x + bias[678].double()
+    assert abs(folded - (wk2 @ r + bk2) @ (wq2 @ x + bq2)) < 1e-4
     # K1: chained over [e_0 ; e_1], 9 K steps per source
     x = torch.randn(576, generator=g).double()
     y = sum(_walk16(halves(364 + 72 * sv, 364 + 72 * (sv + 1), 9, 8), chained(x, 288 * sv)) for sv in range(2)) * down["K1"]
@@ -123,6 +127,41 @@ def test_round2_packing_layout():
     assert (y * bias[256].double() - want).abs().max() < 1e-5
 
 
+def test_round2q_fold_reproduces_the_two_layers():
+    """car_round2_logits_from_g's operands: M = Wr2^T Wq2 walked the way the 32x32x16 MFMA contracts the chained tiles, with v, u, c, gives
+    <query_repeat_embed_2(y), query_embed_2(x)> for any pair of hidden vectors; the two 16 -> 128 layers sit behind it."""
+    m = _module(5)
+    packed, bias = PR.pack_round2q(m)
+    from cross_attention_renderer_amd import _lib
+    lib = _lib.load()
+    assert packed.numel() == lib.car_round2q_packed_floats() and bias.numel() == lib.car_round2q_bias_floats()
+    g = torch.Generator().manual_seed(2)
+    wm = packed[:16384].view(torch.float16).reshape(4, 4, 2, 2, 64, 8).double()      # (c, t, kg, hl, lane, e)
+    wm = wm[:, :, :, 0] + wm[:, :, :, 1]
+    x, y = torch.randn(128, generator=g).double().abs(), torch.randn(128, generator=g).double().abs()
+    t = torch.zeros(128, dtype=torch.float64)
+    for c in range(4):
+        for kg in range(2):
+            for h in range(2):
+                for e in range(8):
+                    k = 32 * c + (e & 3) + 8 * (2 * kg + (e >> 2)) + 4 * h
+                    t += wm[c, :, kg, 32 * h:32 * h + 32, e].reshape(-1) * x[k]
+    t = t * bias[513].double() + bias[128:256].double()                                  # M x + v
+    folded = y @ t + bias[384:512].double() @ x + bias[515].double()
+    wr2, br2 = m.query_repeat_embed_2.weight.detach().reshape(128, 128).double(), m.query_repeat_embed_2.bias.detach().double()
+    wq2, bq2 = m.query_embed_2.weight.detach().reshape(128, 128).double(), m.query_embed_2.bias.detach().double()
+    assert abs(folded - (wr2 @ y + br2) @ (wq2 @ x + bq2)) < 1e-4
+    gq = torch.randn(16, generator=g).double()
+    for off, slot, W in ((16384, 512, m.query_repeat_embed.weight.detach().reshape(128, 144)[:, 128:]), (16384 + 2048, 514, m.query_embed.weight.detach().reshape(128, 16))):
+        w1 = packed[off:off + 2048].view(torch.float16).reshape(4, 2, 64, 8).double()  # (t, hl, lane, e)
+        w1 = w1[:, 0] + w1[:, 1]
+        yy = torch.zeros(128, dtype=torch.float64)
+        for h in range(2):
+            for e in range(8):
+                yy += w1[:, 32 * h:32 * h + 32, e].reshape(-1) * gq[8 * h + e]
+        assert (yy * bias[slot].double() - W.double() @ gq).abs().max() < 1e-5
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("scale", [1.0, 2e-4, 5e3])
 def test_device_packers_emit_the_reference_bytes(scale):
@@ -162,3 +201,13 @@ def test_device_packers_emit_the_reference_bytes(scale):
     assert torch.equal(dwpt.cpu().view(576, 4), wpt)
     assert torch.equal(dr2w.cpu().view(torch.int32), r2w.view(torch.int32))
     assert torch.equal(dr2b.cpu(), r2b)
+    # the folded layer and the two 16 -> 128 layers car_round2_logits_from_g reads
+    r2qw, r2qb = PR.pack_round2q(m)
+    assert r2qw.numel() == lib.car_round2q_packed_floats() and r2qb.numel() == lib.car_round2q_bias_floats()
+    dqw, dqb = torch.empty_like(r2qw, device=dev), torch.empty_like(r2qb, device=dev)
+    rc = lib.car_round2q_pack(w.query_repeat_embed_w, w.query_repeat_embed_b, w.query_repeat_embed_2_w, w.query_repeat_embed_2_b,
+                              w.query_embed_w, w.query_embed_b, w.query_embed_2_w, w.query_embed_2_b, dqw.data_ptr(), dqb.data_ptr(), st)
+    assert rc == 0, lib.car_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(dqw.cpu().view(torch.int32), r2qw.view(torch.int32))
+    assert torch.equal(dqb.cpu(), r2qb)

@@ -989,6 +989,52 @@ def test_key_query_chain_kernel_matches_the_separate_layers(M, Ce):
     assert ((d(logit) - want).abs() / bound).max().item() < 8e-6
 
 
+@pytest.mark.parametrize("b,R,P,wscale", [(1, 77, 32, 1.0), (2, 50, 5, 1.0), (1, 300, 64, 30.0), (1, 33, 16, 1e-3)])
+def test_second_round_bilinear_form_matches_the_two_layers(b, R, P, wscale):
+    """car_round2_logits_from_g: <q2, qry> / 16 evaluated as y^T (M x + v) + u^T x + c with M = Wr2^T Wq2 folded by car_round2q_pack, against
+    fp64 matmuls of the four separate layers (models.py:529, 549-556) and against car_round2_logits fed the fp64-made query rows; ragged sizes,
+    weights of very different magnitude."""
+    from cross_attention_renderer_amd import _lib as L
+    lib = _lib()
+    dev = torch.device("cuda:0")
+    V = 2
+    S = b * V * R * P
+    g_ = torch.Generator().manual_seed(S)
+    rnd = lambda *sh: torch.randn(*sh, generator=g_)
+    gq = (rnd(S, 16) * torch.logspace(-2, 1, S).unsqueeze(1)).to(dev)
+    uh = rnd(b * R, 128).to(dev)
+    wr1, br1 = (rnd(128, 144) / 4).to(dev), rnd(128).to(dev)
+    wr2, br2 = (rnd(128, 128) / 128 ** 0.5 * wscale).to(dev), rnd(128).to(dev)
+    wq1, bq1 = (rnd(128, 16) / 4).to(dev), rnd(128).to(dev)
+    wq2, bq2 = (rnd(128, 128) / 128 ** 0.5 / wscale).to(dev), rnd(128).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    wp, bp = torch.empty(lib.car_round2q_packed_floats(), device=dev), torch.empty(lib.car_round2q_bias_floats(), device=dev)
+    L.check(lib.car_round2q_pack(_ptr(wr1), _ptr(br1), _ptr(wr2), _ptr(br2), _ptr(wq1), _ptr(bq1), _ptr(wq2), _ptr(bq2), _ptr(wp), _ptr(bp), st), "car_round2q_pack")
+    logit = torch.full((S,), float("nan"), device=dev)
+    L.check(lib.car_round2_logits_from_g(_ptr(gq), _ptr(uh), _ptr(wp), _ptr(bp), b, V, R, P, _ptr(logit), st), "car_round2_logits_from_g")
+    d = lambda t: t.double()
+    ray = (torch.arange(S, device=dev) // P)                               # (scene-view, ray) -> (scene, ray)
+    ray = (ray // R // V) * R + ray % R
+    y = torch.relu(d(gq) @ d(wr1[:, 128:]).T + d(br1) + d(uh)[ray])
+    x = torch.relu(d(gq) @ d(wq1).T + d(bq1))
+    q2, qry = y @ d(wr2).T + d(br2), x @ d(wq2).T + d(bq2)
+    want = (q2 * qry).sum(1) / 16
+    # fp32-class bound of either evaluation order: the magnitudes that enter the sums
+    q2b, qb = y.abs() @ d(wr2).abs().T + d(br2).abs(), x.abs() @ d(wq2).abs().T + d(bq2).abs()
+    bound = (q2b * qb).sum(1) / 16
+    torch.cuda.synchronize()
+    assert torch.isfinite(logit).all()
+    assert ((d(logit) - want).abs() / bound).max().item() < 4e-6
+    # the stored-query kernel on the same inputs (the staged routes' form)
+    w0, b0 = torch.empty(lib.car_round2_packed_floats(), device=dev), torch.empty(lib.car_round2_bias_floats(), device=dev)
+    L.check(lib.car_round2_pack(_ptr(wr1), _ptr(br1), _ptr(wr2), _ptr(br2), _ptr(w0), _ptr(b0), st), "car_round2_pack")
+    qrows = qry.float().contiguous()
+    logit0 = torch.empty(S, device=dev)
+    L.check(lib.car_round2_logits(_ptr(gq), _ptr(uh), _ptr(qrows), _ptr(w0), _ptr(b0), b, V, R, P, _ptr(logit0), st), "car_round2_logits")
+    torch.cuda.synchronize()
+    assert ((d(logit) - d(logit0)).abs() / bound).max().item() < 4e-6
+
+
 @pytest.mark.parametrize("name", ["t1_nview1", "t1_nview3", "t1_no_latent_concat"])
 def test_staged_route_with_the_key_query_chain_kernel_equals_the_separate_layers(name):
     """The stage route's default (car_key_query_logits) against its five-launch form: attention weights and rgb to fp32 rounding; both

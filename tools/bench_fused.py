@@ -3,6 +3,7 @@ product kernel (variant 0) and the timing-only ablation variants of the developm
 variants > 0 are wrong by construction):
   1 no tap loads | 2 no gather work | 3 = 2 + no weight DMA / barriers | 5 the source passes without their matrix work | 4 phase stamps | 20 where a wave waits inside a chunk
   11 no chunk barrier (racy) | 12 = 3 + no A-operand reads | 13 no A-operand reads | 100 the PRODUCT library's kernel, timed the same way | 101 the product launch with the first round's partial sums (what the forward issues)
+  400 round 6's candidate with the source passes on 32x32x16 tiles, two waves per SIMD (tools/probes/car_fused_w32.hip; build with CAR_DEV_UNIT=car_fused_w32.hip), compared with 100
 (earlier rounds' probes — masked lanes, tap orders, deep tap rings, the full-lattice timing probe — are recorded in profiles/)
 Usage (GPU box): python tools/bench_fused.py [variants...]"""
 import ctypes
@@ -36,6 +37,10 @@ def main():
         fn_base = ctypes.CDLL(base_path).car_fused_samples
         fn_base.restype = ctypes.c_int
         fn_base.argtypes = _lib.SIGNATURES["car_fused_samples"][1]
+    fn_w32 = getattr(dev_lib, "car_fused_samples_w32", None)
+    if fn_w32 is not None:
+        fn_w32.restype = ctypes.c_int
+        fn_w32.argtypes = _lib.SIGNATURES["car_fused_samples"][1]
     lib = _lib.load()
     dev = torch.device("cuda:0")
     model = bench.build_model(dev)
@@ -77,6 +82,16 @@ def main():
     wpt = torch.empty(576 * 4, device=dev)
     st = P_(torch.cuda.current_stream().cuda_stream)
     _lib.check(lib.car_fused_pack(ctypes.byref(w), blob.data_ptr(), bias.data_ptr(), wpt.data_ptr(), st), "car_fused_pack")
+    # variant 400's blob: the W2 region (18 K steps x 18 tiles of [hi | lo][lane][8 halves]) re-laid for the 32 x 32 x 16 A operand:
+    # [K step][32-channel tile T][K half][hi | lo][lane][8 halves], lane l = row l % 32, k = 16 half + 8 (l / 32) + e — a permutation of the bytes
+    torch.cuda.synchronize()
+    blob32 = blob.clone()
+    old = blob[:18 * 18 * 512].view(torch.int16).view(18, 18, 2, 64, 8)
+    T_, kh_, lane_ = torch.meshgrid(torch.arange(9, device=dev), torch.arange(2, device=dev), torch.arange(64, device=dev), indexing="ij")
+    t_src = 2 * T_ + ((lane_ % 32) >> 4)
+    lane_src = 16 * (2 * kh_ + lane_ // 32) + lane_ % 16
+    new = old[:, t_src, :, lane_src, :]                                 # index tensors split by a slice: (T, kh, lane, ks, hl, e)
+    blob32[:18 * 18 * 512].view(torch.int16).view(18, 9, 2, 2, 64, 8).copy_(new.permute(3, 0, 1, 4, 2, 5))
     lh, lw, lpad = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     _lib.check(lib.car_lattice_shape(ctypes.byref(d), ctypes.byref(lh), ctypes.byref(lw), ctypes.byref(lpad)), "car_lattice_shape")
     gmeta = eng._pair.data_ptr() + 4 * lib.car_gmeta_offset(ctypes.byref(d))
@@ -121,9 +136,11 @@ def main():
             a.record(ext) if ext is not None else a.record()
             args = (eng._pose_dev.data_ptr(), ws("rays"), steps.data_ptr(), lat_ptr, lat_h, lat_w, lat_pad,
                     gmeta, wpt.data_ptr(), blob.data_ptr(),
-                    bias.data_ptr(), 1, 2, Rk, bench.P, bench.H, bench.H, 0, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
+                    bias.data_ptr(), 1, 2, Rk, bench.P, bench.H, bench.H, 0, ws("e"), ws("g"), ws("logit"), ws("pt"),
                     pixel_val.data_ptr(), st)
-            rc = fn_sliced(v - 1000, *args) if v >= 1000 else prod(*args) if v == 100 else prod_parts(*args[:-1], ws("part"), args[-1]) if v == 101 else fn_base(*args) if v == 300 else fn(v, *args)
+            if v == 400:
+                args = args[:9] + (blob32.data_ptr(),) + args[10:]
+            rc = fn_w32(*args) if v == 400 else fn_sliced(v - 1000, *args) if v >= 1000 else prod(*args) if v == 100 else prod_parts(*args[:-1], ws("part"), args[-1]) if v == 101 else fn_base(*args) if v == 300 else fn(v, *args)
             b_.record(ext) if ext is not None else b_.record()
             assert rc == 0, dev_lib.car_last_error()
             lat.append((a, b_))
@@ -133,7 +150,7 @@ def main():
             st8 = pixel_val.view(torch.int64)[: (2 * R * bench.P // 192) * 16].view(-1, 16).cpu().double()
             seq = [0, 1, 2, 3, 4, 7, 8, 5, 6]                     # stamp indices in program order
             names = ["tables+geometry", "first gather + weights 0", "source pass 0", "source pass 1", "K1 over e_1 (+ its stores)", "K1 over e_0 (LDS-DMA rows)",
-                     "K2", "query layers + stores"]
+                     "(nothing: K2 folded away)", "query layer + folded 128 x 128 layer + logit"]
             tot = (st8[:, 6] - st8[:, 0]).mean().item()
             print("phase clock ticks per workgroup (mean over %d groups; s_memtime):" % st8.shape[0])
             for j, n_ in enumerate(names):
@@ -190,13 +207,13 @@ def main():
             print(f"source passes, per wave and chunk (mean over {w8.shape[0]} waves, {n:.0f} chunks each; s_memtime ticks): "
                   f"9 x (A-operand reads + 6 MFMAs issued) {m(7):.0f}, DMA pieces {m(5):.0f}, affine {m(6):.0f}, blends incl. the wait for their taps {m(0):.0f}, "
                   f"h rows stored + tap loads issued {m(4):.0f}, chunk-end wait for the weight DMA {m(1):.0f}, barrier {m(2):.0f}")
-        if v in (0, 100, 101, 300) or v >= 1000 or 60 <= v <= 69:    # keep the results: the development kernels must equal the product's bit for bit
+        if v in (0, 100, 101, 300, 400) or v >= 1000 or 60 <= v <= 69:    # keep the results: the development kernels must equal the product's bit for bit
             outs[v] = [torch.empty(cnt_, device=dev).copy_(eng._work[o_:o_ + cnt_]) for o_, cnt_ in
                        [(lambda n_: (lib.car_workspace_find(ctypes.byref(d), n_.encode(), ctypes.byref(off), ctypes.byref(cnt)), (off.value, cnt.value))[1])(n_)
-                        for n_ in ("e", "qry", "logit", "pt", "g")]]
+                        for n_ in ("e", "logit", "pt", "g")]]
             ref = 300 if 300 in outs else 100
             if v != ref and ref in outs:
-                for n_, x, y in zip(("e", "qry", "logit", "pt", "g"), outs[v], outs[ref]):
+                for n_, x, y in zip(("e", "logit", "pt", "g"), outs[v], outs[ref]):
                     print(f"   ({v}) vs ({ref}) {n_:6s} max |diff| {(x - y).abs().max().item():.3e}  max |ref| {y.abs().max().item():.3e}  equal {torch.equal(x, y)}")
         print(f"ABL={v}: fused kernel median {ms[len(ms) // 2]:.3f} ms  min {ms[0]:.3f} ms  -> {flop / ms[len(ms) // 2] / 1e9:.1f} TFLOP/s (nominal flops)", flush=True)
 

@@ -18,7 +18,7 @@ def build_dev() -> str:
     os.makedirs(DEV_DIR, exist_ok=True)
     extra = os.environ.get("CAR_DEV_FLAGS", "").split()
     stamp = os.path.join(DEV_DIR, "flags.txt")
-    fresh = os.path.exists(stamp) and open(stamp).read() == " ".join(extra)
+    fresh = os.path.exists(stamp) and open(stamp).read() == " ".join(extra) + (" unit=" + os.environ["CAR_DEV_UNIT"] if os.environ.get("CAR_DEV_UNIT") else "")
     headers = [os.path.join(ge.CSRC, f) for f in os.listdir(ge.CSRC) if f.endswith(".h")]
     dev_units = ("car_fused.hip", "car_gather.hip")            # the units that carry -DCAR_ABLATION variants
     objs = [os.path.join(ge.CSRC, "_obj", u.replace(".hip", ".o")) for u in ge.UNITS if u not in dev_units]
@@ -29,7 +29,16 @@ def build_dev() -> str:
             subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCAR_ABLATION", *extra, "-c", src, "-o", obj,
                                    "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS[unit]])
         objs.append(obj)
-    open(stamp, "w").write(" ".join(extra))
+    # development-only units (kernels under evaluation, tools/probes/): CAR_DEV_UNIT=car_fused_w32.hip
+    unit = os.environ.get("CAR_DEV_UNIT")
+    if unit:
+        src = os.path.join(ROOT, "tools", "probes", unit)
+        obj = os.path.join(DEV_DIR, unit.replace(".hip", "_dev.o"))
+        if ge._stale(obj, [src] + headers) or not fresh:
+            subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra, "-c", src, "-o", obj,
+                                   "-I", os.path.join(ROOT, "include"), "-I", ge.CSRC, *ge.UNITS["car_fused.hip"]])
+        objs.append(obj)
+    open(stamp, "w").write(" ".join(extra) + (" unit=" + unit if unit else ""))
     if ge._stale(DEV_LIB, objs):
         subprocess.check_call([ge._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", DEV_LIB, *objs])
     return DEV_LIB

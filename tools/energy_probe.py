@@ -78,7 +78,7 @@ def main():
 
     def fused_args(blob_t):
         return (poses.data_ptr(), ws("rays"), steps.data_ptr(), eng._pair.data_ptr(), lh.value, lw.value, lpad.value, gmeta, wpt.data_ptr(),
-                blob_t.data_ptr(), bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, 0, ws("e"), ws("qry"), ws("g"), ws("logit"), ws("pt"),
+                blob_t.data_ptr(), bias.data_ptr(), 1, 2, R, bench.P, bench.H, bench.H, 0, ws("e"), ws("g"), ws("logit"), ws("pt"),
                 pixel_val.data_ptr())
     w_out = torch.empty(S, device=dev)
     zb = torch.empty(R, 576, device=dev)
