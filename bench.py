@@ -14,7 +14,8 @@ HBM before the timed region; ``get_z`` (the image encoder) is excluded on both s
 
 Configurations (sizes of BASELINE.json's configs that fit one GPU):
   c2  256 x 256, 64 samples, 1 scene: one forward call of 65 536 rays per step                        (the driver's line)
-  c3  256 x 256, 64 samples, batch of 12 scenes, this rank's share of the 8-GPU job: 12 x 8192 rays in one call per step
+  c3  256 x 256, 64 samples, batch of 12 scenes: on one GPU a rank's share of the 8-GPU job (12 x 8192 rays in one call per step); with
+      --gpus N the whole frames of all twelve scenes, their rays banded over the N ranks (12 x 65536 / N rays per rank and step)
   c4  256 x 256, 128 samples (gather-bound stress), 1 scene, 65 536 rays per step
   c5  384 x 384, 64 samples, 1 scene, 147 456 rays per step
 
@@ -205,7 +206,7 @@ def timed_loop(model, frames, z, tile, gather, steps, chunk_rays, dist):
     for i in range(steps):
         render_frame(model, frames[i % len(frames)], z, tile, chunk_rays)
         if gather is not None:
-            gather(tile[0])
+            gather(tile.view(-1, tile.shape[-1]))
     if gather is not None:
         gather.wait()
     torch.cuda.synchronize()
@@ -260,6 +261,9 @@ def main():
                     help="host = camera matrices stay CPU tensors: the reference's own torch.inverse on the CPU per frame + a 768-byte upload, no "
                          "device synchronisation (default); gpu = the whole input dict on the GPU as the reference's scripts hand it over: same "
                          "host arithmetic after one small download per frame; device = car_pose_setup on the GPU (opt-in, last-ulp differences)")
+    ap.add_argument("--rays-per-scene", type=int, default=None,
+                    help="c3 with N > 1 ranks: rays of every scene's frame that are banded over the ranks (default: the whole 256 x 256 frame; "
+                         "smaller values only for dry runs of the code path with all ranks on one device)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to smoke-test the multi-rank code path)")
     ap.add_argument("--device", type=int, default=None, help="device index for every rank (smoke tests of the multi-rank path on one GPU; default LOCAL_RANK)")
     args = ap.parse_args()
@@ -296,19 +300,24 @@ def main():
 
     Hc, Pc, nb, R_frame, what = CONFIGS[args.config]
     if world > 1 and nb != 1:
-        sys.exit("bench.py: multi-GPU runs band the single-scene configurations (c2, c4, c5); c3 already is a rank's share")
+        # config 3 on N ranks (BASELINE: "batch_size 12, ray-sharded across 8 GPUs"): the rays of ALL twelve scenes' frames are banded —
+        # rank g renders rays [g R / N, (g + 1) R / N) of every scene (shard rays, not scenes: 12 is no multiple of 8) and the
+        # (12, R / N, 5) tiles are exchanged by one all-gather per step.  At N = 8 a rank's call is the 12 x 8192 rays the one-GPU line times.
+        R_frame = args.rays_per_scene or Hc * Hc
+        what = f"batch of 12 scenes at {Hc}x{Hc}, {Pc} samples/view, {R_frame} rays of every scene banded over {world} ranks (config 3)"
     model = build_model(dev, Pc, Hc)
     model.pose_route = "device" if args.cameras == "device" else "host"
     model._engine = RenderEngine(model)
     _, z = make_frame(0.5, dev, Hc, nb)
     band = ray_band(R_frame, rank, world)
-    if nb != 1:
-        band = ((3 * Hc // 8) * Hc, (3 * Hc // 8) * Hc + R_frame)            # c3: one rank's band of image rows of every scene
+    if nb != 1 and world == 1:
+        band = ((3 * Hc // 8) * Hc, (3 * Hc // 8) * Hc + R_frame)            # c3 on one GPU: one rank's band of image rows of every scene
     R = band[1] - band[0]
     n_frames = args.steps + args.warmup
     frames = trajectory(n_frames, dev, band if (world > 1 or nb != 1) else None, args.cameras == "host", Hc, nb)
     tile = torch.empty(nb, R, 5, device=dev)
-    gather = TileGather(world, -(-R_frame // world), 5, dev) if world > 1 else None
+    # one all-gather per step of this rank's (scenes, rays, 5) tile, flattened to rows: (world, nb * R / N, 5) on every rank
+    gather = TileGather(world, nb * -(-R_frame // world), 5, dev) if world > 1 else None
     if gather is not None and R != -(-R_frame // world):
         sys.exit("bench.py: the frame's rays must divide evenly over the ranks")
     extras = world == 1 and not args.no_extras
@@ -328,7 +337,7 @@ def main():
         for i in range(args.warmup):
             render_frame(model, frames[args.steps + i], z, tile, args.chunk_rays)
             if gather is not None:
-                gather(tile[0])
+                gather(tile.view(-1, 5))
         if gather is not None:
             gather.wait()
         model._engine.profile(True)                              # stage events from here on (rank-local)
@@ -412,11 +421,11 @@ def main():
 
         # the other multi-GPU arrangement: every rank renders whole frames of its own (replicas), tiles all-gathered
         per_rank = None
-        if world > 1 and not args.no_extras:
+        if world > 1 and not args.no_extras and nb == 1:
             k2 = max(2, args.steps // 2)
             full = trajectory(k2, dev, None, args.cameras == "host", Hc, nb)
             tile2 = torch.empty(nb, R_frame, 5, device=dev)
-            g2 = TileGather(world, R_frame, 5, dev)
+            g2 = TileGather(world, nb * R_frame, 5, dev)
             render_frame(model, full[0], z, tile2, args.chunk_rays)
             t2 = timed_loop(model, full, z, tile2, g2, k2, args.chunk_rays, dist)
             per_rank = (k2, t2)

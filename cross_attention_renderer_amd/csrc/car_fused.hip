@@ -146,17 +146,18 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     // the tile's sample of (wave, row lane & 15): tile_ray / tile_step above; the 8 rows a tap instruction gathers are one step of
     // neighbouring rays (shared lattice rows)
     const int pgs = (a.P + kTileSteps - 1) / kTileSteps, bundles = (a.R + kTileRays - 1) / kTileRays;
-#if !defined(CAR_WG_ORDER) || CAR_WG_ORDER == 0
-    const int pg = blk % pgs, bun = (blk / pgs) % bundles;
-    const int nset = blk / (pgs * bundles);                            // ROWS: (sample set, component)
-#else
-    // development build (profiles/round6_fused_closing.md): other orders of the workgroups inside an XCD's band, judged by FETCH_SIZE
+    // Order of the sample groups inside an XCD's band: STEP-MAJOR — (step group, sample set, ray tile), ray tiles fastest — so the ~32 workgroups
+    // an XCD runs at a time are neighbouring ray tiles at ONE group of steps (a 65 536-ray frame at 64 steps: XCD k renders step group k of
+    // every ray).  Round 6 measured three orders on the same box (profiles/round6_fused_closing.md): against the ray-major order of rounds 2-5
+    // (a tile's 8 step groups on consecutive workgroups) this one fetches 4.5 % fewer bytes on the memory side and runs the launch 2.4 %
+    // faster; putting a tile's 2 x 8 workgroups side by side fetches 5 % MORE.  A pure permutation of the work: results are unchanged.
     const int nsets = ROWS ? a.b * a.ncomp : a.b * a.V;
-#if CAR_WG_ORDER == 1                                                  // (ray tile, view, step group): a tile's 2 x 8 workgroups are neighbours
-    const int pg = blk % pgs, nset = (blk / pgs) % nsets, bun = blk / (pgs * nsets);
-#else                                                                  // 2: (step group, view, ray tile): an XCD runs neighbouring ray tiles at ONE step group
+#if !defined(CAR_WG_ORDER) || CAR_WG_ORDER == 2
     const int pg = blk / (nsets * bundles), nset = (blk / bundles) % nsets, bun = blk % bundles;
-#endif
+#elif CAR_WG_ORDER == 0                                                // development build: rounds 2-5, (sample set, ray tile, step group)
+    const int pg = blk % pgs, bun = (blk / pgs) % bundles, nset = blk / (pgs * bundles);
+#else                                                                  // development build: (ray tile, sample set, step group)
+    const int pg = blk % pgs, nset = (blk / pgs) % nsets, bun = blk / (pgs * nsets);
 #endif
     const int nn = ROWS ? nset / a.ncomp : nset, comp = ROWS ? nset % a.ncomp : 0;
     const int ray_i = bun * kTileRays + tile_ray(wave, s), pp = pg * kTileSteps + tile_step(wave, s);

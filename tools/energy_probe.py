@@ -100,6 +100,22 @@ def main():
         ("torch fill of 1 GB (HBM writes)", lambda: (big.fill_(1.0), 0)[1], 0),
         ("torch sum over 1 GB (HBM reads)", lambda: (big.sum(), 0)[1], 0),
     ]
+    if os.environ.get("CAR_ENERGY_ROWS") == "closing":
+        # round 6's closing table (profiles/round6_fused_closing.md): the product kernel, the development build's kernel (CAR_DEV_FLAGS, e.g.
+        # -DCAR_WG_ORDER=0: the ray-major workgroup order of rounds 2-5) and, if built in (CAR_DEV_UNIT=car_fused_w32.hip), the 32x32x16 candidate
+        rows = [rows[0], rows[2], ("development build's kernel (CAR_DEV_FLAGS=%s)" % os.environ.get("CAR_DEV_FLAGS", ""), lambda: fn(0, *fused_args(blob), st), S)]
+        fn_w32 = getattr(dev_lib, "car_fused_samples_w32", None)
+        if fn_w32 is not None:
+            fn_w32.restype = ctypes.c_int
+            fn_w32.argtypes = _lib.SIGNATURES["car_fused_samples"][1]
+            torch.cuda.synchronize()
+            blob32 = blob.clone()
+            old = blob[:18 * 18 * 512].view(torch.int16).view(18, 18, 2, 64, 8)
+            T_, kh_, lane_ = torch.meshgrid(torch.arange(9, device=dev), torch.arange(2, device=dev), torch.arange(64, device=dev), indexing="ij")
+            new = old[:, 2 * T_ + ((lane_ % 32) >> 4), :, 16 * (2 * kh_ + lane_ // 32) + lane_ % 16, :]        # (T, kh, lane, ks, hl, e)
+            blob32[:18 * 18 * 512].view(torch.int16).view(18, 9, 2, 2, 64, 8).copy_(new.permute(3, 0, 1, 4, 2, 5))
+            rows.append(("32x32x16 candidate, two waves per SIMD (tools/probes/car_fused_w32.hip)", lambda: fn_w32(*fused_args(blob32), st), S))
+            rows.append(("product kernel alone, again", rows[1][1], S))
     out = []
     for name, call, samples in rows:
         torch.cuda.synchronize()

@@ -175,7 +175,8 @@ __global__ void __launch_bounds__(kThreads) fused_kernel_w32(const FusedArgs a) 
         blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
     const int pgs = (a.P + kTileSteps - 1) / kTileSteps, bundles = (a.R + kTileRays - 1) / kTileRays;
-    const int pg = blk % pgs, bun = (blk / pgs) % bundles, nn = blk / (pgs * bundles);
+    const int nsets = a.b * a.V;                                       // the product's step-major order (car_fused.hip)
+    const int pg = blk / (nsets * bundles), nn = (blk / bundles) % nsets, bun = blk % bundles;
     // sample of row r of this wave's tile, relative to the workgroup's first ray at step 0 (i_base): 32-bit byte offsets from scalar bases
     const long i_base = ((long)nn * a.R + (long)bun * kTileRays) * a.P;
     auto row_rel = [&](int r) -> int {                                 // sample index - i_base of row r (clamped to a live sample)
