@@ -55,6 +55,7 @@ SIGNATURES = {
                                  c_int, c_int, _P, _P]),
     "car_gather_encode_rows": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_long, _P, c_int, _P]),
     "car_merge_lattice": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    "car_merge_lattice_max": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P]),
     "car_lattice_encode_rows": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_long, _P, c_int, _P]),
     "car_lattice_encode_linear": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_long, _P, _P, c_int, c_int, _P, c_int, c_int, _P]),
     "car_project_points": (c_int, [_P, _P, c_int, c_long, c_int, c_int, c_int, c_int, _P, _P]),

@@ -504,6 +504,9 @@ extern "C" int car_linear_wgrad(const float* dY, int ldy, const float* X, int ld
     CAR_REQUIRE(dY && X && dW, "car_linear_wgrad: null pointer");
     CAR_REQUIRE(M > 0 && N > 0 && K > 0 && ldy >= N && ldx >= K && lddw >= K, "car_linear_wgrad: bad sizes M=%ld N=%d K=%d", M, N, K);
     CAR_REQUIRE(ldy % 4 == 0 && ldx % 4 == 0, "car_linear_wgrad: row strides must be multiples of 4 floats (got %d, %d)", ldy, ldx);
+    // every tile kernel below stages its operands with 16-byte loads: a column-offset view whose first element is not 16-byte aligned
+    // would fault on the device, so it is refused here
+    CAR_REQUIRE((((uintptr_t)dY | (uintptr_t)X) & 15) == 0, "car_linear_wgrad: dY and X must be 16-byte aligned (a column-offset view? copy it first)");
     // wide layers over many rows: the bf16 x 3 kernel (CAR_WGRAD_FP32 in flags keeps them on the fp32 pipe: A/B and tests); wide layers
     // otherwise: the fp32 pipe's 192 x 320 workgroup tile; everything else its 128 x 128 one
     if ((N > 128 || K + (db ? 1 : 0) > 128) && M >= 4096 && !(flags & CAR_WGRAD_FP32))

@@ -861,6 +861,21 @@ extern "C" int car_merge_lattice(const float* const* levels, const int* level_h,
     for (int l = 0; l < n_levels; ++l) CAR_REQUIRE(levels[l], "car_merge_lattice: level %d is null", l);
     return launch_merge(levels, level_h, level_w, L.r, n_levels, L.h, L.w, L.pad, n_maps, lattice, nullptr, (hipStream_t)stream, "car_merge_lattice");
 }
+// The same, and the lattice's largest magnitude in the same pass (gmax [1]: zeroed here, then one atomic per workgroup of the merge) — what
+// car_fused_rows takes as `gmeta`; no separate reduction over the gigabyte of lattice.
+extern "C" int car_merge_lattice_max(const float* const* levels, const int* level_h, const int* level_w, int n_levels, int n_maps, float* lattice,
+                                     float* gmax, void* stream) {
+    CAR_REQUIRE(levels && level_h && level_w && n_levels > 0 && n_levels <= CAR_MAX_LEVELS && n_maps > 0 && lattice && gmax, "car_merge_lattice_max: bad arguments");
+    car_dims d{};
+    d.b = n_maps; d.V = 1; d.n_levels = n_levels;
+    for (int l = 0; l < n_levels; ++l) { d.level_h[l] = level_h[l]; d.level_w[l] = level_w[l]; }
+    const Lattice L = lattice_of(d);
+    CAR_REQUIRE(L.ok, "car_merge_lattice_max: every level must be an integer factor coarser than the widest one, the same factor in both directions");
+    for (int l = 0; l < n_levels; ++l) CAR_REQUIRE(levels[l], "car_merge_lattice_max: level %d is null", l);
+    if (hipMemsetAsync(gmax, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) { car_set_error("car_merge_lattice_max: memset failed"); return CAR_E_LAUNCH; }
+    return launch_merge(levels, level_h, level_w, L.r, n_levels, L.h, L.w, L.pad, n_maps, lattice, reinterpret_cast<unsigned*>(gmax), (hipStream_t)stream,
+                        "car_merge_lattice_max");
+}
 
 // the launches of one forward call in two phases: CAR_PHASE_SAMPLES = rays + the fused per-sample kernel (compute / power bound),
 // CAR_PHASE_RAYS = the attention rounds and the per-ray chains (HBM bound), which only read what the first phase left in the workspace

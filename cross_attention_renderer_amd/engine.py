@@ -100,13 +100,13 @@ class RenderEngine:
         # one-call route: the first attention round folds the fused kernel's per-step-group partial sums (default); False = it streams
         # the rows of e as in rounds 1-4 (CAR_PHASE_ROWS_FIRST_ROUND: A/B measurements and tests)
         self.first_round_parts = True
+        self.wgrad_fp32 = False        # training: True keeps the wide layers' weight gradients on the fp32 matrix pipe (CAR_WGRAD_FP32) instead of bf16 x 3
         self.fuse_kq = True            # staged route: key / query chains and the first round's logits in one kernel (car_key_query_logits); False = five launches (A/B)
         self._kq = None
         self._kq_key = None
         # three-view exchange, first + second layer: "rows" = the fused per-sample kernel's source pass over the rows (car_fused_rows, default);
         # True = the gather-fed linear kernel (car_lattice_encode_linear); False = two launches (A/B partners)
         self.fuse_exchange = "rows"
-        self._xlat_gmeta = None
         self._xpack = None
         self._xpack_key = None
         # sizing of the one-call route (tests shrink them to force several calls)
@@ -576,6 +576,19 @@ class RenderEngine:
         return rows
 
     # ------------------------------------------------------------------ kernels
+    def _lds_refused(self, rc: int, what: str) -> bool:
+        """True when ``rc`` says the device refused the kernel's LDS reservation (CAR_E_LAUNCH with the "cannot reserve" text: a part with less
+        than gfx950's 160 KB per compute unit) — the ONE condition under which a route steps down to the next HIP kernel of the same library.
+        Anything else (an argument error, a sticky fault of an earlier launch) raises: it must not silently change the arithmetic."""
+        if rc == 0:
+            return False
+        msg = (self.lib.car_last_error() or b"").decode()
+        if rc == -2 and "cannot reserve" in msg:
+            import warnings
+            warnings.warn(f"{what}: {msg}: taking the next kernel of the library")
+            return True
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
     def linear(self, x: Tensor, ldx: int, layer: PackedLinear, y: Tensor, ldy: int, M: int, flags: int = 0):
         # linear_flags (the NO_GLDS A/B knob of car_linear) selects the fp32-pipe kernel for every layer: the split-fp16 kernel has no such
         # variant, and an A/B run must not change arithmetic on some layers only
@@ -583,12 +596,10 @@ class RenderEngine:
                 and y.data_ptr() % 16 == 0 and M >= self.linear_x3_min_rows):
             tiles, bias = layer.x3
             rc = self.lib.car_linear_x3(_ptr(x), ldx, _ptr(tiles), _ptr(bias), layer.K, layer.N, _ptr(y), ldy, M, flags, _stream())
-            if rc == 0:
+            if not self._lds_refused(rc, "car_linear_x3"):
                 return
-            # the split-fp16 kernel could not be launched on this device (its 72 KB weight double buffer needs a gfx950-class LDS): the
-            # same layer on the fp32 matrix pipe from here on — another HIP kernel of the same library, never a host path
-            import warnings
-            warnings.warn(f"car_linear_x3 unavailable ({self.lib.car_last_error().decode()}): wide layers stay on car_linear")
+            # the split-fp16 kernel's 72 KB weight double buffer was refused: the same layer on the fp32 matrix pipe from here on — another
+            # HIP kernel of the same library, never a host path
             self.linear_x3 = False
         _lib.check(self.lib.car_linear(_ptr(x), ldx, _ptr(layer.packed), layer.K, layer.N, _ptr(y), ldy, M,
                                        flags | self.linear_flags, _stream()), "car_linear")
@@ -729,10 +740,11 @@ class RenderEngine:
             tiles, bias_k1 = kmap.x3
             tail, tail_bias = self._kq_weights(dev)
             logit1 = torch.empty(S, **f32)
-            _lib.check(lib.car_key_query_logits(_ptr(e), Ce, _ptr(tiles), _ptr(bias_k1), Ce, _ptr(g), _ptr(tail), _ptr(tail_bias), S, _ptr(q),
-                                                _ptr(logit1), st), "car_key_query_logits")
-            return self._finish(inp, z, b, V, R, P, Ce, Dl, e, None, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug, kmajor,
-                                logit1=logit1)
+            rc = lib.car_key_query_logits(_ptr(e), Ce, _ptr(tiles), _ptr(bias_k1), Ce, _ptr(g), _ptr(tail), _ptr(tail_bias), S, _ptr(q), _ptr(logit1), st)
+            if not self._lds_refused(rc, "car_key_query_logits"):
+                return self._finish(inp, z, b, V, R, P, Ce, Dl, e, None, q, g, pt, pixel_val, poses, rays, coords9, phi_x, ld_phi, debug, kmajor,
+                                    logit1=logit1)
+            self.fuse_kq = False                                   # LDS reservation refused: the five separate launches below
         k1 = torch.empty(S, 128, **f32)
         self.linear(e, Ce, kmap, k1, 128, S, RELU_OUT)
         key = torch.empty(S, 128, **f32)
@@ -757,10 +769,11 @@ class RenderEngine:
         floats = n_maps * 2 * lh.value * lw.value * C
         if n_maps * 2 * lh.value * lw.value >= 2 ** 31 - 1 or floats * 4 > self._free_budget(dev) // 2:
             return None
-        self._xlat = None
+        self._xlat = None                                           # the previous lattice goes before the next one is allocated
         lattice = torch.empty(floats, device=dev, dtype=torch.float32)
-        _lib.check(self.lib.car_merge_lattice(ptrs, hs, ws, L, n_maps, _ptr(lattice), None, None, None, _stream()), "car_merge_lattice")
-        self._xlat, self._xlat_key = (lattice, lh.value, lw.value, lpad.value), key
+        gmax = torch.empty(1, device=dev, dtype=torch.float32)     # largest |lattice value|: taken in the merge's own pass
+        _lib.check(self.lib.car_merge_lattice_max(ptrs, hs, ws, L, n_maps, _ptr(lattice), _ptr(gmax), _stream()), "car_merge_lattice_max")
+        self._xlat, self._xlat_key = (lattice, lh.value, lw.value, lpad.value, gmax), key
         return self._xlat
 
     def _encode_three_views(self, maps, poses, pixel_val, ptenc, pt_in, b, R, P, H, W, C, pk, keep=None):
@@ -794,28 +807,29 @@ class RenderEngine:
             if lat is not None and self.fuse_exchange == "rows" and not self.linear_flags and C == 576:
                 # the fused per-sample kernel's source pass over the exchange's rows (car_fused_rows): its gather machinery and W2 in one
                 # launch, e written [S, 3, 288]; the lattice's largest magnitude (the first layer's fp16 scale) is taken once per lattice
-                lattice, lh, lw, lpad = lat
-                if self._xlat_gmeta is None or self._xlat_gmeta[0] is not lattice:
-                    self._xlat_gmeta = (lattice, lattice.abs().max().reshape(1).contiguous())
+                lattice, lh, lw, lpad, gmax = lat
                 blob, fbias, fwpt = self._exchange_pack(dev)
                 enc = torch.empty(S * 3, C // 2, **f32)
-                _lib.check(self.lib.car_fused_rows(_ptr(lattice), lh, lw, lpad, _ptr(self._xlat_gmeta[1]), _ptr(fwpt), _ptr(blob), _ptr(fbias), _ptr(src),
-                                                   _ptr(rgrid), _ptr(rpe), n, R, P, 3, _ptr(enc), _stream()), "car_fused_rows")
-                return enc.view(S, 3 * (C // 2))
+                rc = self.lib.car_fused_rows(_ptr(lattice), lh, lw, lpad, _ptr(gmax), _ptr(fwpt), _ptr(blob), _ptr(fbias), _ptr(src), _ptr(rgrid), _ptr(rpe),
+                                             n, R, P, 3, _ptr(enc), _stream())
+                if not self._lds_refused(rc, "car_fused_rows"):
+                    return enc.view(S, 3 * (C // 2))
+                self.fuse_exchange = True                          # LDS reservation refused: the gather-fed linear kernel, then two launches
             if lat is not None and self.fuse_exchange and self.linear_x3 and not self.linear_flags and layer2.x3 is not None:
                 # first AND second exchange layer in one kernel: the lattice rows are gathered 32 channels at a time into the matrix pipe's
                 # operands, the 576-wide rows (2.3 KB x 3 S) are never written (csrc/car_linear16.hip, GATHER instance; bit-identical
                 # to the two launches below)
-                lattice, lh, lw, lpad = lat
+                lattice, lh, lw, lpad, _ = lat
                 tiles, bias2 = layer2.x3
                 enc = torch.empty(S * 3, C // 2, **f32)
-                _lib.check(self.lib.car_lattice_encode_linear(_ptr(lattice), lh, lw, lpad, _ptr(src), _ptr(rgrid), _ptr(rpe), _ptr(wpt), n, S * 3,
-                                                              _ptr(tiles), _ptr(bias2), C, C // 2, _ptr(enc), C // 2, 0, _stream()),
-                           "car_lattice_encode_linear")
-                return enc.view(S, 3 * (C // 2))
+                rc = self.lib.car_lattice_encode_linear(_ptr(lattice), lh, lw, lpad, _ptr(src), _ptr(rgrid), _ptr(rpe), _ptr(wpt), n, S * 3,
+                                                        _ptr(tiles), _ptr(bias2), C, C // 2, _ptr(enc), C // 2, 0, _stream())
+                if not self._lds_refused(rc, "car_lattice_encode_linear"):
+                    return enc.view(S, 3 * (C // 2))
+                self.fuse_exchange = False
             h1 = torch.empty(S * 3, C, **f32)
             if lat is not None:                                     # four taps of the merged lattice per row instead of twelve
-                lattice, lh, lw, lpad = lat
+                lattice, lh, lw, lpad, _ = lat
                 _lib.check(self.lib.car_lattice_encode_rows(_ptr(lattice), lh, lw, lpad, C, _ptr(src), _ptr(rgrid), _ptr(rpe), _ptr(wpt), n, S * 3,
                                                             _ptr(h1), C, _stream()), "car_lattice_encode_rows")
             else:

@@ -33,6 +33,7 @@ from . import _lib
 from .engine import ACCUM, PLACE_OTHER2, PLACE_OWN, PLACE_PLAIN, RELU_IN, RELU_OUT, PackedLinear, RenderEngine, _ptr, _round_up, _stream
 
 Tensor = torch.Tensor
+WGRAD_FP32 = 16            # CAR_WGRAD_FP32 (include/car_hip.h)
 
 
 def _check(code, what):
@@ -55,8 +56,10 @@ class _Ops:
         return self._t[key]
 
     def wgrad(self, dy: Tensor, ldy: int, x: Tensor, ldx: int, M: int, N: int, K: int, dw: Tensor, lddw: int, db: Optional[Tensor], relu_x=False):
-        _check(self.lib.car_linear_wgrad(_ptr(dy), ldy, _ptr(x), ldx, M, N, K, RELU_IN if relu_x else 0, _ptr(dw), lddw, _ptr(db), _stream()),
-               "car_linear_wgrad")
+        # engine.wgrad_fp32 = True keeps the wide layers' weight gradients on the fp32 matrix pipe (CAR_WGRAD_FP32): the reference's fp32
+        # arithmetic term for term, at half the rate of the default bf16 hi / lo x 3 kernel (~2^-17 per term)
+        flags = (RELU_IN if relu_x else 0) | (WGRAD_FP32 if getattr(self.eng, "wgrad_fp32", False) else 0)
+        _check(self.lib.car_linear_wgrad(_ptr(dy), ldy, _ptr(x), ldx, M, N, K, flags, _ptr(dw), lddw, _ptr(db), _stream()), "car_linear_wgrad")
 
     def relu_mask(self, grad: Tensor, ldg: int, act: Tensor, lda: int, M: int, N: int):
         _check(self.lib.car_relu_mask(_ptr(grad), ldg, _ptr(act), lda, M, N, _stream()), "car_relu_mask")

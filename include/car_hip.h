@@ -129,6 +129,10 @@ int car_gather_encode_rows(const float* const* gmaps, const int* level_h, const 
  * shape — and car_lattice_encode_rows reads four taps of it per row (row_src / row_grid / row_pe as above). */
 int car_merge_lattice(const float* const* levels, const int* level_h, const int* level_w, int n_levels, int n_maps, float* lattice,
                       int* lat_h, int* lat_w, int* lat_pad, void* stream);
+/* The same merge, which also leaves the lattice's largest magnitude in gmax [1] (taken in the merge's own pass: one atomic per workgroup) —
+ * the `gmeta` car_fused_rows wants. */
+int car_merge_lattice_max(const float* const* levels, const int* level_h, const int* level_w, int n_levels, int n_maps, float* lattice,
+                          float* gmax, void* stream);
 int car_lattice_encode_rows(const float* lattice, int lat_h, int lat_w, int lat_pad, int Cg, const int* row_src, const float* row_grid,
                             const float* row_pe, const float* wpt, int n_maps, long rows, float* out, int ld_out, void* stream);
 /* car_lattice_encode_rows followed by car_linear_x3 (below) in ONE kernel, for the three-view exchange's second layer (models.py:333-341 on
