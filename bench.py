@@ -233,17 +233,27 @@ def pair_setup(model, frame, z, reps: int = 3):
     return sorted(ms)[len(ms) // 2]
 
 
-def eval_mode(model, frames, z, tile, steps: int):
-    """The eval loop's shape (eval_realestate10k.py:142-161): every frame belongs to a NEW stereo pair, so the lattice is re-projected
-    before every frame (the pyramid itself — get_z — is excluded as everywhere)."""
-    eng = model._engine
+def eval_mode(model, frames, z, tile, steps: int, prefetch: bool = True):
+    """The eval loop's shape (eval_realestate10k.py:142-161): every frame belongs to a NEW stereo pair, so the pyramid is re-laid channel-last
+    and the lattice re-projected for every frame (the pyramid itself — get_z — is excluded as everywhere).  Two copies of the pyramid
+    alternate, so every frame's pair differs from the one in place.  ``prefetch``: the loop announces the next pair before it renders the
+    current one (model.prefetch_pair, what experiment_scripts/eval_realestate10k.py does): the set-up runs on a side stream beside the
+    render; False: the set-up runs inside the next forward, in front of its kernels (rounds 4-5)."""
+    pyr = (z, [t.clone() for t in z])
+    render_frame(model, frames[0], pyr[0], tile, 1 << 30)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    pyr = pyr + ([t.clone() for t in z],)                           # three copies: (in place, announced, next) are distinct tensors, as in the loop
     for i in range(steps):
-        eng._pair_key = None
-        render_frame(model, frames[i % len(frames)], z, tile, 1 << 30)
+        if prefetch:
+            model.prefetch_pair(pyr[(i + 1) % 3])                   # the loop's order: the next pair is announced, then the current one rendered
+        render_frame(model, frames[i % len(frames)], pyr[i % 3], tile, 1 << 30)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    model._engine.drop_prefetched()
+    render_frame(model, frames[0], z, tile, 1 << 30)               # the caller's pyramid back in place
+    torch.cuda.synchronize()
+    return ms
 
 
 def main():
@@ -345,7 +355,7 @@ def main():
         stages = model._engine.stage_times()
         model._engine.profile(False)
 
-        ev_ms = share = pose = power = ab = None
+        ev_ms = ev_ms_inline = share = pose = power = ab = None
         if extras:
             # A/B of this round's change to the tail: the same K steps with the first attention round streaming the rows of e
             # (CAR_PHASE_ROWS_FIRST_ROUND: the fused kernel without its partial sums + car_attend over e, the form of rounds 1-4)
@@ -382,7 +392,8 @@ def main():
                                      "+ attention + per-ray chains); the fused kernel alone by component: profiles/round5_fused_energy.md")
             except Exception as exc:                                  # measurement plumbing must never cost the line
                 power = {"available": False, "error": repr(exc)}
-            ev_ms = eval_mode(model, frames, z, tile, max(3, min(args.steps, 8)))
+            ev_ms = eval_mode(model, frames, z, tile, max(4, min(args.steps, 8)), True)
+            ev_ms_inline = eval_mode(model, frames, z, tile, max(4, min(args.steps, 8)), False)
             if nb == 1 and args.chunk_rays >= R:
                 # a rank's share of this frame at G GPUs: one call of R / G rays per step, every step a new pose — what bounds the scaling
                 # of the banded frame before the (overlapped) all-gather
@@ -400,6 +411,32 @@ def main():
                 share.update({"rays_per_step": R_frame // 8, "steps": kG, "ms_per_step": share["ms_per_step_8"],
                               "note": "one forward call of 1/G of the frame per step on ONE GPU (a new pose every step), G = 2, 4, 8: frame time / this = the "
                                       "scaling G ranks reach if the tile all-gather hides under the next frame; a projection, not a measurement on G GPUs"})
+            if nb != 1 and args.chunk_rays >= R:
+                # config 3's job is twelve WHOLE frames per step, their rays banded over the ranks: one GPU renders all of it (the engine splits
+                # the call where the workspace does not fit), a rank of G renders 12 x 65536 / G rays per step — the G = 8 share is the line above
+                full_R = Hc * Hc
+                kF = 2
+                frF = trajectory(kF + 1, dev, None, args.cameras == "host", Hc, nb)
+                tF = torch.empty(nb, full_R, 5, device=dev)
+                render_frame(model, frF[kF], z, tF, 1 << 30)
+                eF = timed_loop(model, frF, z, tF, None, kF, 1 << 30, None) / kF
+                del tF
+                share = {"whole_job_ms_per_step": eF * 1e3, "whole_job_rays_per_step": nb * full_R}
+                for G in (2, 4, 8):
+                    kG, rs = max(4, args.steps // 2), full_R // G
+                    g0 = (3 * G // 8) * rs
+                    frG = trajectory(kG, dev, (g0, g0 + rs), args.cameras == "host", Hc, nb)
+                    tG = torch.empty(nb, rs, 5, device=dev)
+                    render_frame(model, frG[0], z, tG, 1 << 30)
+                    eG = min(timed_loop(model, frG, z, tG, None, kG, 1 << 30, None) for _ in range(2)) / kG
+                    share[f"projected_scaling_{G}"] = eF / eG
+                    share[f"ms_per_step_{G}"] = eG * 1e3
+                    del tG, frG
+                share.update({"rays_per_step": nb * full_R // 8, "ms_per_step": share["ms_per_step_8"],
+                              "note": "config 3 = twelve whole 256 x 256 frames per step; a rank of G renders the band [g R / G, (g + 1) R / G) of every "
+                                      "scene in one call: whole job on ONE GPU / this = the scaling G ranks reach if the tile all-gather hides under the "
+                                      "next step; a projection, not a measurement on G GPUs"})
+                render_frame(model, frames[0], z, tile, args.chunk_rays)         # the line's own workspace back in place
             if args.cameras == "host" and nb == 1 and args.chunk_rays >= R:
                 # the same frames with the WHOLE dict on the GPU (the reference scripts' call): host pose route, one download + sync per pose
                 kp = max(4, min(args.steps, 10))
@@ -527,9 +564,11 @@ def main():
             # what the restructuring moved out of the timed region, and what it holds in memory
             "pair_setup_ms": setup_ms, "lattice_bytes": lattice_bytes, "workspace_bytes": workspace_bytes,
             "eval_mode": None if ev_ms is None else {
-                "ms_per_step": ev_ms, "value": rays_step / (ev_ms * 1e-3), "unit": "rays/s",
-                "note": "every frame brings a new stereo pair (eval_realestate10k.py:142-161): car_project_maps runs before every frame; "
-                        "get_z excluded as in the headline figure"},
+                "ms_per_step": ev_ms, "value": rays_step / (ev_ms * 1e-3), "unit": "rays/s", "ms_per_step_without_prefetch": ev_ms_inline,
+                "note": "every frame brings a new stereo pair (eval_realestate10k.py:142-161): channel-last copies of the pyramid + car_project_maps "
+                        "for every frame, announced one frame ahead (model.prefetch_pair, as experiment_scripts/eval_realestate10k.py does) so that "
+                        "they run on a side stream beside the previous render; ms_per_step_without_prefetch: the same loop with the set-up inside "
+                        "the forward (rounds 4-5); get_z excluded as in the headline figure"},
             "rank_share": share,
             "first_round_ab": ab,
             "power": power,

@@ -88,6 +88,9 @@ struct FusedArgs {
     // gathers map (row_src & 0x3fffffff), padding mode (row_src >> 30) & 1 at row_grid [2] and adds the point term of row_pe [4]; a workgroup's 192
     // rows are 24 rays x 8 steps of ONE (sample set, component): its rows share their map and padding mode
     const int* row_src; const float* row_grid; const float* row_pe; int ncomp;
+#ifdef CAR_BOUNDS
+    long lattice_floats;       // extent of `lattice` (0: unknown to the entry), for the debug build's range checks
+#endif
 };
 
 // chunk order:  W2 x18 (source 0) | W2 x18 (source 1) | K1 over e_1 x5 (2,2,2,2,1 K steps) | K1 over e_0 x5 | Q1 | M x2
@@ -115,6 +118,9 @@ __device__ __forceinline__ NextChunk next_chunk_w2(const float* __restrict__ blo
     n.src = blob + (long)(w2 ? kOffW2 + step * kTE : chunk_tile_offset(kG_K1b)) * kTile;
     n.dst = lds + kLdsW + (gn & 1) * kChunkTiles * kTile;
     n.nkb = w2 ? 2 * kTE : 2 * chunk_tiles(kG_K1b);
+#ifdef CAR_BOUNDS
+    n.lim = blob + (long)kBlobTiles * kTile;
+#endif
     return n;
 }
 
@@ -296,6 +302,9 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     const long map_floats = (long)a.lh * a.lw * kC;
     const long lat0 = ROWS ? ((long)rows_map * 2 + rows_mode) * map_floats : ((long)(sc_own * a.V + 0) * 2 + (v_own == 0 ? 0 : 1)) * map_floats;
     const long lat1 = ROWS ? lat0 : ((long)(sc_own * a.V + 1) * 2 + (v_own == 1 ? 0 : 1)) * map_floats;
+#ifdef CAR_BOUNDS
+    CAR_BOUNDS_TRAP(a.lattice_floats == 0 || (lat0 >= 0 && lat0 + map_floats <= a.lattice_floats && lat1 >= 0 && lat1 + map_floats <= a.lattice_floats));
+#endif
     const __amdgpu_buffer_rsrc_t rsrc[2] = {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lattice + lat0), 0, (int)a.map_bytes, 0x00027000),
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lattice + lat1), 0, (int)a.map_bytes, 0x00027000)};
@@ -304,6 +313,9 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
         const int chunk_off = 128 * c;                                 // the chunk's 32 channels: scalar offset, not range-checked
         const unsigned tbv = reinterpret_cast<const unsigned*>(lds + kLdsTapB)[(wave * kRows + r0 + 8 * it) * 2 + sv];
         const unsigned o00 = tbv + qd16, o10 = o00 + row_step;          // east taps: the instruction's immediate offset (one node = 2304 B)
+        // debug build: a live tap (offsets at or above 2^31 mark samples that read zeros: the hardware's range check serves them) must end
+        // inside the (view, padding mode) lattice WITH the chunk's scalar offset, which the hardware does not check
+        CAR_BOUNDS_TRAP(tbv >= 0x80000000u || (long)o10 + (kC * 4) + chunk_off + 16 <= (long)a.map_bytes);
         auto ld = [&](unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc[sv], (int)off, chunk_off, 0)); };
         tap[0] = ld(o00);
         tap[1] = ld(o00 + (unsigned)(kC * 4));
@@ -606,6 +618,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
             for (int it = 0; it < 2; ++it) {
                 const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(ebuf[m & 1] + it * 256));
                 const float* gsrc = esrc[it] + 32 * m;
+                CAR_BOUNDS_TRAP(gsrc >= a.e && gsrc + 4 <= a.e + a.S * kC);
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
@@ -739,6 +752,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
                 const int k = 4 * it + grp, pp_k = pg * kTileSteps + k;
                 pw[rw][it] = expf(lgt_of(rr, k) - mx);                 // a step past P carries -inf: weight 0 (its row is a duplicate of step P - 1)
                 const f32x4* rowp = reinterpret_cast<const f32x4*>(a.e + (((long)nn * a.R + ray_c) * a.P + (pp_k < a.P ? pp_k : a.P - 1)) * kC + 4 * sub);
+                CAR_BOUNDS_TRAP(reinterpret_cast<const float*>(rowp) >= a.e && reinterpret_cast<const float*>(rowp + 16 * (kC / 64 - 1) + 1) <= a.e + a.S * kC);
 #pragma unroll
                 for (int j = 0; j < kC / 64; ++j) xr[rw][it][j] = __builtin_nontemporal_load(rowp + 16 * j);   // read once, written by other waves: past L1
             }
@@ -804,6 +818,9 @@ int launch_fused(int abl, int blk0, int nblk, const float* poses, const float* r
     a.S = (long)b * V * R * P;
     a.blk0 = blk0;
     a.e = e; a.g = g; a.logit = logit; a.pt = pt; a.pixel_val = pixel_val; a.part = part;
+#ifdef CAR_BOUNDS
+    a.lattice_floats = (long)b * V * 2 * lat_h * lat_w * kC;
+#endif
     long groups = (long)b * V * car_div_up(R, kTileRays) * car_div_up(P, kTileSteps);
     if (nblk > 0) groups = (groups - blk0 < nblk) ? groups - blk0 : nblk;     // development build: a slice of the sample groups
     void (*kern)(const FusedArgs) = fused_kernel<0>;

@@ -28,13 +28,21 @@ __device__ __forceinline__ constexpr int chunk_tile_offset(int g);      // defin
 __device__ __forceinline__ constexpr int chunk_tiles(int g);
 
 // Descriptor of the chunk to prefetch, resolved once per chunk with scalar branches so the per-piece issue is straight-line
-struct NextChunk { const float* src; float* dst; int nkb; };
+struct NextChunk {
+    const float* src; float* dst; int nkb;
+#ifdef CAR_BOUNDS
+    const float* lim = nullptr;        // one past the packed array the chunk lies in (nullptr: unknown to this kernel)
+#endif
+};
 __device__ __forceinline__ NextChunk next_chunk(const float* __restrict__ blob, float* lds, int g) {
     const int ge = g < kNumChunks ? g : kNumChunks - 1;            // past the end: re-copy the last chunk onto itself
     NextChunk n;
     n.src = blob + (long)chunk_tile_offset(ge) * kTile;
     n.dst = lds + kLdsW + (ge & 1) * kChunkTiles * kTile;
     n.nkb = 2 * chunk_tiles(ge);
+#ifdef CAR_BOUNDS
+    n.lim = blob + (long)kBlobTiles * kTile;
+#endif
     return n;
 }
 // piece p of the next chunk: wave w copies KB number kWaves p + w (wrapped into the chunk: re-copying identical bytes is harmless).
@@ -45,9 +53,24 @@ __device__ __forceinline__ void stream_issue_piece(const NextChunk& n, int p, in
     int kb = kWaves * p + wave;
     kb = kb < n.nkb ? kb : kb - n.nkb;
     kb = kb < n.nkb ? kb : kb - n.nkb;
+    // a piece index that two subtractions do not bring back into the chunk would copy 1 KB from BEHIND it (car_linear16.hip before 0d74f26:
+    // three pieces issued for a four-KB chunk); and no piece may leave the packed array
+    CAR_BOUNDS_TRAP(kb >= 0 && kb < n.nkb);
+#ifdef CAR_BOUNDS
+    {   // 32-bit arithmetic on the distance (a 64-bit pointer compare would move the address computation below into vector registers)
+        const int room = n.lim ? (int)(n.lim - n.src) : 0x7fffffff;
+        CAR_BOUNDS_TRAP((kb + 1) * 256 <= room);
+    }
+#endif
     // `wave` is scalar, so both addresses are: scalar base + the lane's 16 bytes (no 64-bit vector address arithmetic per piece)
     const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(n.dst + kb * 256));
     const float* gsrc = n.src + kb * 256;
+#ifdef CAR_BOUNDS
+    {   // the checks' branches make the compiler lose sight of the address being wave-uniform: say so again for the "s" operand below
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)gsrc), hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)gsrc >> 32));
+        gsrc = reinterpret_cast<const float*>(((uintptr_t)hi << 32) | lo);
+    }
+#endif
     const unsigned voff = 16u * (unsigned)lane;
     unsigned keep;
 #define CAR_DMA_PIECE(POLICY) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" POLICY "\n\ts_mov_b32 m0, %0" \

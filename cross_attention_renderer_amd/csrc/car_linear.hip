@@ -97,6 +97,7 @@ linear_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ Wp
                 const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
                     (unsigned)(uintptr_t)(lds_void*)(dst + 4 * (t * 256 + wave * 64)));
                 const float* gsrc = src + 4 * f4;
+                CAR_BOUNDS_TRAP(gsrc >= Wp && gsrc + 4 <= Wp + (long)chunks * tiles_alloc * kTileFloats);     // debug build: inside the packed layer
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");

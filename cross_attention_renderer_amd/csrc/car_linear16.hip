@@ -69,6 +69,9 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
         n.src = a.Wp + ((long)ce * a.tiles_total + tile0) * kTile;
         n.dst = lds + (ce & 1) * NT * kTile;
         n.nkb = 2 * NT;
+#ifdef CAR_BOUNDS
+        n.lim = a.Wp + (long)a.chunks * a.tiles_total * kTile;
+#endif
         return n;
     };
     {

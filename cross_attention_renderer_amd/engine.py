@@ -117,6 +117,9 @@ class RenderEngine:
         self.last_calls = 0            # number of car_render_forward calls the last forward was split into
         self._round2_key = None
         self._round2 = None
+        self._pf = None                # prefetch(): announced stereo pairs (key -> channel-last pyramid + lattice), projected on a side stream
+        self._pf_stream = None
+        self.prefetch_side_stream = True   # False (A/B): prefetch() projects on the launch stream itself
         self._pose_key = None
         self._pose_dev = None
         self._pose_src = None
@@ -187,10 +190,81 @@ class RenderEngine:
         the stale maps would be rendered."""
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in z)
         if key != self._maps_key or self._maps_src is None or any(a is not b_ for a, b_ in zip(self._maps_src, z)):
+            pf = self._pf.get(key) if self._pf else None
+            if pf is not None and all(a is b_ for a, b_ in zip(pf["src"], z)):
+                # this pyramid was announced by prefetch(): its channel-last copies and its lattice are (being) made on the side stream.
+                # The launch stream waits for them here — at the latest possible point — and takes them over
+                del self._pf[key]
+                torch.cuda.current_stream().wait_event(pf["done"])
+                self._maps, self._maps_key, self._maps_src = pf["maps"], key, list(z)
+                self._pair = None
+                self._pair, self._pair_key = pf["pair"], (key, pf["plan_key"], 0, pf["b"])
+                return self._maps
             self._maps = [t.detach().float().permute(0, 2, 3, 1).contiguous() for t in z]
             self._maps_key = key
             self._maps_src = list(z)
         return self._maps
+
+    def prefetch(self, z: List[Tensor]) -> bool:
+        """Announces the NEXT stereo pair's pyramid while the current frame is still to be rendered (the eval loop knows its next batch:
+        eval_realestate10k.py:142-161): the channel-last copies and car_project_maps of ``z`` run on a side stream, ordered behind
+        everything queued so far (so behind the ``get_z`` that made ``z``) and beside the render that follows on the launch stream; the
+        forward that later receives these very tensors waits for the side stream's event and finds its lattice ready.  Needs a plan (one
+        forward with the current weights) and room for a second lattice; returns False — and does nothing — otherwise, or when ``z`` is the
+        pyramid already in place.  Same kernels, same arguments, same results as the projection inside forward."""
+        m = self.m
+        if (self._plan is None or not self.fuse_samples or not self.project_maps or m.n_view != 2 or len(z) != 3 or z[0].device.type != "cuda"
+                or sum(t.shape[1] for t in z) != 576 or not self._common_lattice(z)):
+            return False
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in z)
+        if key == self._maps_key and self._pair is not None:
+            return False
+        if self._pf is None:
+            self._pf = {}
+        if key in self._pf and all(a is b_ for a, b_ in zip(self._pf[key]["src"], z)):
+            return True
+        dev = z[0].device
+        V = m.n_view
+        b = z[0].shape[0] // V
+        d = self._dims(b, 48, z)
+        if d.P != self._plan_key[1] or tuple(d.level_c[:3]) != self._plan_key[2]:
+            return False
+        need = 4 * self.lib.car_gmaps_floats(ctypes.byref(d))
+        if need == 0 or not self._lattice_fits(b, 48, z) or need > self._free_budget(dev) // 3:
+            return False                                             # another lattice must leave the workspace its room
+        with torch.cuda.device(dev):
+            if self._pf_stream is None:
+                self._pf_stream = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream()
+            side = self._pf_stream if self.prefetch_side_stream else main
+            # the loop announces pair i + 1 BEFORE it renders pair i (announced one step earlier and not taken over yet): two announced pairs
+            # may wait; an older one nobody came for is dropped — once the side stream is done with it (its buffers go back to the launch
+            # stream's pool)
+            while len(self._pf) >= 2:
+                old = self._pf.pop(next(iter(self._pf)))
+                main.wait_event(old["done"])
+            # buffers come from the launch stream's pool; the side stream starts behind everything queued there so far (the allocator's
+            # reuse of a freed block is ordered on the launch stream) and the tensors are handed back to it through the event
+            maps = [torch.empty(t.shape[0], t.shape[2], t.shape[3], t.shape[1], device=dev, dtype=torch.float32) for t in z]
+            pair = torch.empty(need // 4, device=dev, dtype=torch.float32)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for dst, t in zip(maps, z):
+                    dst.copy_(t.detach().permute(0, 2, 3, 1))
+                ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in maps])
+                _lib.check(self.lib.car_project_maps(ctypes.byref(d), _ptr(self._plan), ptrs, _ptr(pair), ctypes.c_void_p(side.cuda_stream)),
+                           "car_project_maps")
+                done = torch.cuda.Event()
+                done.record(side)
+            self._pf[key] = {"key": key, "src": list(z), "maps": maps, "pair": pair, "done": done, "plan_key": self._plan_key, "b": b}
+        return True
+
+    def drop_prefetched(self) -> None:
+        """Forgets every announced pair (after the side stream is done with them)."""
+        if self._pf:
+            for old in self._pf.values():
+                torch.cuda.current_stream().wait_event(old["done"])
+        self._pf = None
 
     def _projected_maps(self, maps: List[Tensor], device):
         """G_l = query_encode_latent.weight[:, ch_l] F_l per pyramid level (channel-last, C wide), plus the [C,4]

@@ -179,6 +179,17 @@ class CrossAttentionRenderer(nn.Module):
         return self._engine.render(input, z, debug=debug)
 
 
+    def prefetch_pair(self, z) -> bool:
+        """Eval-loop hook (not in the reference, whose loop pays nothing per pair): announce the NEXT stereo pair's pyramid ``z`` — the list
+        ``get_z`` returned for the next batch — before rendering the current one.  Its per-pair set-up (channel-last copies, the first
+        point-MLP layer per texel, the common lattice: ``car_project_maps``, 1.3 ms at 256 x 256) then runs on a side stream beside the
+        current frame's kernels instead of in front of the next frame.  Optional: ``forward`` computes the same thing itself when it was not
+        announced.  Returns whether anything was started (engine.RenderEngine.prefetch)."""
+        if self._engine is None:
+            return False
+        return self._engine.prefetch(list(z))
+
+
 def renderer_param_shapes(model="midas_vit", n_view=2, no_latent_concat=False) -> Dict[str, tuple]:
     """name -> shape of every renderer parameter except the image encoder's."""
     m = CrossAttentionRenderer(model=model, n_view=n_view, no_latent_concat=no_latent_concat, with_encoder=False)

@@ -56,6 +56,16 @@ def gather_rays(tile: torch.Tensor, n_rays: int, group=None) -> torch.Tensor:
     return out
 
 
+def assemble_tiles(gathered: torch.Tensor, b: int, n_rays: int) -> torch.Tensor:
+    """TileGather's buffer (world, b * R_g, C) — every rank's (b, R_g, C) tile of a batch of b scenes, flattened to rows — as the whole
+    (b, n_rays, C) frames: rank g holds rays [g R_g, (g + 1) R_g) of EVERY scene (config 3: twelve scenes, rays banded over the ranks;
+    the bands must be equal: n_rays % world == 0)."""
+    world = gathered.shape[0]
+    if n_rays % world or gathered.shape[1] != b * (n_rays // world):
+        raise ValueError(f"assemble_tiles: {tuple(gathered.shape)} is not {world} equal bands of {b} x {n_rays} rays")
+    return gathered.view(world, b, n_rays // world, -1).permute(1, 0, 2, 3).reshape(b, n_rays, -1)
+
+
 class TileGather:
     """Overlapped all-gather of equally sized per-rank tiles (R, C) -> (world, R, C).
 

@@ -37,14 +37,27 @@ def evaluate(rank, opt, default_data=DEFAULT_DATA):
         items = ((ds[i][0], None) for i in range(len(ds)))
     else:
         items = (harness.synthetic_pair(H, opt.views, seed=5 + i) for i in range(opt.batch_size))
-    for k, (inp, z) in enumerate(items):
-        if real:
-            inp = {part: {kk: (vv[None] if torch.is_tensor(vv) else vv) for kk, vv in d.items()} for part, d in inp.items()}   # batch of 1
-            inp = harness.to_device(inp, dev, opt.cameras)
-            with torch.no_grad():
-                z = model.get_z(inp)
-        else:
-            inp, z = harness.to_device(inp, dev, opt.cameras), [t.to(dev) for t in z]
+    def prepared():
+        """Items moved to the device with their pyramids: get_z for the real reader, the seeded stand-in otherwise."""
+        for inp, z in items:
+            if real:
+                inp = {part: {kk: (vv[None] if torch.is_tensor(vv) else vv) for kk, vv in d.items()} for part, d in inp.items()}   # batch of 1
+                inp = harness.to_device(inp, dev, opt.cameras)
+                with torch.no_grad():
+                    z = model.get_z(inp)
+            else:
+                inp, z = harness.to_device(inp, dev, opt.cameras), [t.to(dev) for t in z]
+            yield inp, z
+    it = prepared()
+    nxt = next(it, None)
+    k = -1
+    while nxt is not None:
+        (inp, z), k = nxt, k + 1
+        # the loop knows its next batch (eval_realestate10k.py:131-142): its pyramid is made now and announced, so that its per-pair set-up
+        # (car_project_maps) runs on a side stream beside this item's render instead of in front of the next one
+        nxt = next(it, None)
+        if nxt is not None:
+            model.prefetch_pair(nxt[1])
         start = time.time()
         tile = harness.render_frame(model, inp, z, chunk_rays=-(-H * H // n_chunks), rank=rank, world=opt.gpus)
         torch.cuda.synchronize()

@@ -1,7 +1,9 @@
 """Generate the ``get_z`` fixtures by running the *reference's own* ``CrossAttentionRenderer.get_z`` (models.py:148-188) with its
 own multi-view DPT-hybrid encoder (midas/dpt_depth.py, midas/vit.py, midas/blocks.py, vit_models.py) in this container.
 
-    python tests/golden/make_encoder_golden.py
+    python tests/golden/make_encoder_golden.py                  (timm restated by timm_stub.py: what this container can do)
+    python tests/golden/make_encoder_golden.py --timm           (on a machine WITH timm == 0.5.4: the reference on the real package;
+                                                                 compares with the committed fixtures, --write replaces them)
 
 The reference builds the encoder's ResNetV2 trunk and transformer blocks from timm 0.5.4, which is not installed here:
 ``timm_stub.py`` restates those layers (see its header) so that the reference's modules import and run.  Everything else — image
@@ -23,8 +25,18 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
-import timm_stub                                       # noqa: E402
-timm_stub.install()                                    # before anything of the reference is imported
+USE_TIMM = "--timm" in sys.argv
+if USE_TIMM:
+    # the pin SURVEY 8(f2) still lacks: the timm-defined layers (ResNetV2 stem / stages, ViT blocks, hybrid embedding) from timm itself
+    try:
+        import timm                                    # noqa: E402
+    except ImportError:
+        sys.exit("make_encoder_golden.py --timm: timm is not installed here (pip install timm==0.5.4 — the version the reference pins, requirements.txt)")
+    if timm.__version__ != "0.5.4":
+        sys.exit(f"make_encoder_golden.py --timm: timm {timm.__version__} found, the reference pins 0.5.4 (its ResNetV2 / hybrid-ViT definitions changed later)")
+else:
+    import timm_stub                                   # noqa: E402
+    timm_stub.install()                                # before anything of the reference is imported
 import encoder_cases as EC                             # noqa: E402
 import ref_import                                      # noqa: E402
 
@@ -62,6 +74,15 @@ def main():
               f"fp32 run: max err / rms {['%.1e' % w for w in noise]}  shapes {[tuple(t.shape) for t in z]}")
         assert max(worst) < 1e-8, "get_z does not reproduce the reference"
         names = sorted(shapes)
+        if USE_TIMM:
+            # the committed fixture was made on timm_stub.py: how far is the real package from it?
+            old = np.load(EC.fixture_path(variant))
+            diff = [float(np.abs(old[f"z{i}"] - s_).max() / max(np.abs(s_).max(), 1e-30)) for i, s_ in enumerate(EC.sample(z))]
+            same_table = list(old["names"]) == names and list(old["shapes"]) == [str(shapes[n]) for n in names]
+            print(f"{variant:14s} timm {timm.__version__} vs the committed (stub-made) fixture: max |diff| / max per level {['%.1e' % d for d in diff]}, "
+                  f"name / shape table {'identical' if same_table else 'DIFFERENT'}")
+            if "--write" not in sys.argv:
+                continue
         np.savez_compressed(EC.fixture_path(variant), names=np.asarray(names), shapes=np.asarray([str(shapes[n]) for n in names]),
                             stats=EC.stats(z), **{f"z{i}": s_ for i, s_ in enumerate(EC.sample(z))})
 

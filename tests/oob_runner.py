@@ -7,7 +7,13 @@ bit-identical between the two calls; a write outside an argument changes a margi
 accesses do not fault — the old car_linear16.hip ran to completion there — and re-used address ranges served stale data; dropped.)
 Test infrastructure only.
 
-usage: python tests/oob_runner.py <family | case>      (CAR_OOB_LIB=<path>: another build of car_linear_x3, for checking the harness)"""
+Second instrument, for reads whose value nobody uses (no margin can show them): the library built with -DCAR_BOUNDS (tools/build_bounds.py),
+in which every LDS-DMA / buffer-load / row-load helper compares its source range with the extent its launcher passed and TRAPS outside it —
+the process then dies in the middle of a case (a "RUN name" line without its "OK").  CAR_OOB_FULL_LIB=<path> runs every case on such a build.
+
+usage: python tests/oob_runner.py <family | case>
+       CAR_OOB_LIB=<path>       another build of car_linear_x3 only (checking the harness against a known bug)
+       CAR_OOB_FULL_LIB=<path>  another build of the whole library (the -DCAR_BOUNDS build)"""
 import ctypes
 import os
 import sys
@@ -20,6 +26,13 @@ for p_ in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golde
         sys.path.insert(0, p_)
 
 from cross_attention_renderer_amd import _lib as L  # noqa: E402
+
+if os.environ.get("CAR_OOB_FULL_LIB"):               # every entry from another build of the library (the package's loader is handed it)
+    _full = ctypes.CDLL(os.environ["CAR_OOB_FULL_LIB"])
+    for _name, (_res, _args) in L.SIGNATURES.items():
+        _fn = getattr(_full, _name)
+        _fn.restype, _fn.argtypes = _res, _args
+    L._lib = _full
 
 dev = torch.device("cuda:0")
 MARGIN = 256 * 1024                    # elements (4 bytes each) on either side of the payload

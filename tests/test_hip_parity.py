@@ -512,6 +512,41 @@ def test_first_round_from_partial_sums_equals_the_row_form(name):
     _check_outputs(b_, lambda k: ora[k], "row form vs oracle")
 
 
+def test_prefetched_pair_equals_the_inline_projection():
+    """model.prefetch_pair (the eval loop's hook): the next pair's channel-last pyramid and lattice made on a side stream beside the current
+    render — the forward that then receives those tensors returns exactly what it returns when it projects the pair itself; a pair that is
+    announced and never rendered is dropped; the pair in place is not re-projected."""
+    from cross_attention_renderer_amd import synthetic as S
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    dev = torch.device("cuda:0")
+    H, P, R, b = 64, 16, 120, 2
+    torch.manual_seed(0)
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).eval()
+    S.perturb_parameters(m, seed=3)
+    m.H = m.W = H
+    m = m.to(dev)
+    inp = to_device(S.stereo_scene(H, b=b, uv=C.select_rays(H, R), seed=4, alpha=0.4), dev, cameras_on_host=True)
+    za, zb, zc = ([t.to(dev) for t in S.feature_maps(b, 2, H, seed=sd)] for sd in (1, 2, 3))
+    keys = ("rgb", "depth_ray", "at_wt", "valid_mask", "pixel_val")
+    with torch.no_grad():
+        assert m.prefetch_pair(za) is False                            # no engine / plan yet: the first forward projects its pair itself
+        want_b = {k: v.clone() for k, v in m(inp, z=zb).items() if k in keys}
+        want_a = {k: v.clone() for k, v in m(inp, z=za).items() if k in keys}
+        assert m.prefetch_pair(za) is False                            # the pair in place
+        zd = [t.clone() for t in zc]
+        assert m.prefetch_pair(zc) and m.prefetch_pair(zd) and m.prefetch_pair(zb)     # two may wait: zc, announced first and never rendered, is dropped
+        assert len(m._engine._pf) == 2
+        got_a = m(inp, z=za)                                           # renders beside the side stream's projections
+        pair_before = m._engine._pair
+        got_b = m(inp, z=zb)
+        assert len(m._engine._pf) == 1 and m._engine._pair is not pair_before, "the forward did not take the announced pair over"
+        m._engine.drop_prefetched()
+        torch.cuda.synchronize()
+    for k in keys:
+        assert torch.equal(got_a[k], want_a[k]), k
+        assert torch.equal(got_b[k], want_b[k]), k
+
+
 def test_one_call_c_abi_without_second_round():
     """repeat_attention=False (models.py:547) through car_render_forward and the oracle at real widths."""
     from cross_attention_renderer_amd import synthetic as S

@@ -47,6 +47,12 @@ def _worker(rank, world, port, n_rays, ret):
             out = tg.wait()
             for r in range(world):
                 assert (out[r] == r * 10 + it).all()
+        # config 3's exchange (bench.py --gpus N --config c3): a batch of b = 2 scenes, the rays of BOTH banded over the ranks, every
+        # rank's (b, R / N, 5) tile flattened to rows through ONE overlapped gather, reassembled into whole frames
+        if n_rays % world == 0:
+            tg2 = Sh.TileGather(world, 2 * (n_rays // world), 5, "cpu")
+            tg2(tile.reshape(-1, 5))
+            assert torch.equal(Sh.assemble_tiles(tg2.wait(), 2, n_rays), want), "the batched tile gather does not reassemble the frames"
         ret[rank] = 1
     finally:
         dist.destroy_process_group()
