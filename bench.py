@@ -355,7 +355,7 @@ def main():
         stages = model._engine.stage_times()
         model._engine.profile(False)
 
-        ev_ms = ev_ms_inline = share = pose = power = ab = None
+        ev_ms = ev_ms_pf = share = pose = power = ab = None
         if extras:
             # A/B of this round's change to the tail: the same K steps with the first attention round streaming the rows of e
             # (CAR_PHASE_ROWS_FIRST_ROUND: the fused kernel without its partial sums + car_attend over e, the form of rounds 1-4)
@@ -392,8 +392,8 @@ def main():
                                      "+ attention + per-ray chains); the fused kernel alone by component: profiles/round5_fused_energy.md")
             except Exception as exc:                                  # measurement plumbing must never cost the line
                 power = {"available": False, "error": repr(exc)}
-            ev_ms = eval_mode(model, frames, z, tile, max(4, min(args.steps, 8)), True)
-            ev_ms_inline = eval_mode(model, frames, z, tile, max(4, min(args.steps, 8)), False)
+            ev_ms = eval_mode(model, frames, z, tile, max(4, min(args.steps, 8)), False)
+            ev_ms_pf = eval_mode(model, frames, z, tile, max(4, min(args.steps, 8)), True)
             if nb == 1 and args.chunk_rays >= R:
                 # a rank's share of this frame at G GPUs: one call of R / G rays per step, every step a new pose — what bounds the scaling
                 # of the banded frame before the (overlapped) all-gather
@@ -408,6 +408,14 @@ def main():
                     # one after a change of the ray count can carry an allocator refill
                     share[f"projected_scaling_{G}"] = (elapsed / args.steps) / (eG / kG)
                     share[f"ms_per_step_{G}"] = eG / kG * 1e3
+                    if G == 8:                                                # where an eighth of the frame spends its time (HIP events per stage)
+                        eng.profile(True)
+                        timed_loop(model, frG, z, tG, None, kG, 1 << 30, None)
+                        st8 = {}
+                        for name, ms in eng.stage_times():
+                            st8.setdefault(name, []).append(ms)
+                        eng.profile(False)
+                        share["stage_ms_8"] = {k: sum(v) / len(v) for k, v in st8.items()}
                 share.update({"rays_per_step": R_frame // 8, "steps": kG, "ms_per_step": share["ms_per_step_8"],
                               "note": "one forward call of 1/G of the frame per step on ONE GPU (a new pose every step), G = 2, 4, 8: frame time / this = the "
                                       "scaling G ranks reach if the tile all-gather hides under the next frame; a projection, not a measurement on G GPUs"})
@@ -564,11 +572,12 @@ def main():
             # what the restructuring moved out of the timed region, and what it holds in memory
             "pair_setup_ms": setup_ms, "lattice_bytes": lattice_bytes, "workspace_bytes": workspace_bytes,
             "eval_mode": None if ev_ms is None else {
-                "ms_per_step": ev_ms, "value": rays_step / (ev_ms * 1e-3), "unit": "rays/s", "ms_per_step_without_prefetch": ev_ms_inline,
+                "ms_per_step": ev_ms, "value": rays_step / (ev_ms * 1e-3), "unit": "rays/s", "ms_per_step_with_prefetch": ev_ms_pf,
                 "note": "every frame brings a new stereo pair (eval_realestate10k.py:142-161): channel-last copies of the pyramid + car_project_maps "
-                        "for every frame, announced one frame ahead (model.prefetch_pair, as experiment_scripts/eval_realestate10k.py does) so that "
-                        "they run on a side stream beside the previous render; ms_per_step_without_prefetch: the same loop with the set-up inside "
-                        "the forward (rounds 4-5); get_z excluded as in the headline figure"},
+                        "for every frame, inside the forward that first sees the pair; ms_per_step_with_prefetch: the same free-running loop "
+                        "announcing the next pair one frame ahead (model.prefetch_pair: the set-up on a side stream) — it competes with the "
+                        "running frame's kernels for the same compute units and gains only where the loop synchronises per item, as the eval "
+                        "script does (DESIGN.md section 4.3); get_z excluded as in the headline figure"},
             "rank_share": share,
             "first_round_ab": ab,
             "power": power,

@@ -278,26 +278,30 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
     }
 }
 
-// scale[0] = 2^shift with max |W| 2^shift in [2^13, 2^14), scale[1] = 2^-shift.  One workgroup.
-__global__ void scale16_kernel(const float* __restrict__ W, int ldw, int K, int N, float* __restrict__ scale) {
-    __shared__ float red[16];
+// max |W| over the layer, as the bit pattern of a non-negative float (orders like an integer), into scale[2] (zeroed by the caller): a grid
+// of workgroups, one atomic each.  (One workgroup reading the whole matrix took 25 us per layer: 0.9 ms of a training step, which re-packs
+// its ~36 forward and transposed layers after every optimizer step.)
+__global__ void absmax16_kernel(const float* __restrict__ W, int ldw, int K, int N, float* __restrict__ scale) {
+    __shared__ float red[4];
     float m = 0.0f;
-    for (long idx = threadIdx.x; idx < (long)N * K; idx += blockDim.x) m = fmaxf(m, fabsf(W[(idx / K) * ldw + idx % K]));
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)N * K; idx += (long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(W[(idx / K) * ldw + idx % K]));
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < (int)(blockDim.x / 64); ++w) m = fmaxf(m, red[w]);
-        float p, inv;
-        pow2_scale(fmaxf(m, 1e-30f), p, inv);
-        scale[0] = p;
-        scale[1] = inv;
+        atomicMax(reinterpret_cast<unsigned*>(scale + 2), __float_as_uint(m));
     }
 }
 // [K step][tile][hi | lo][lane][8 halves]: lane l carries output 16 tile + l % 16 and k = 32 step + 8 (l >> 4) + e
-__global__ void pack16x3_kernel(const float* __restrict__ W, int ldw, int K, int N, int tiles, long total, const float* __restrict__ scale,
+// scale[2] holds max |W| (absmax16_kernel): every thread derives the layer's power of two from it — scale[0] = 2^shift with
+// max |W| 2^shift in [2^13, 2^14), scale[1] = 2^-shift, written by the first thread for the consuming kernel
+__global__ void pack16x3_kernel(const float* __restrict__ W, int ldw, int K, int N, int tiles, long total, float* __restrict__ scale,
                                 _Float16* __restrict__ out) {
-    const float p = scale[0];
+    float p, inv;
+    pow2_scale(fmaxf(scale[2], 1e-30f), p, inv);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scale[0] = p; scale[1] = inv; }
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
         const long tile = idx >> 9;
@@ -343,7 +347,9 @@ extern "C" int car_linear_x3_pack(const float* W, int ldw, int K, int N, float* 
     const int tiles = N / 16, ksteps = (K + 31) / 32;
     float* scale = packed + (size_t)ksteps * tiles * kTile;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(scale16_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, W, ldw, K, N, scale);
+    if (hipMemsetAsync(scale + 2, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) { car_set_error("car_linear_x3_pack: memset failed"); return CAR_E_LAUNCH; }
+    const long elems = (long)N * K;
+    hipLaunchKernelGGL(absmax16_kernel, dim3((unsigned)(elems < 65536 ? 8 : 64)), dim3(256), 0, (hipStream_t)stream, W, ldw, K, N, scale);
     hipLaunchKernelGGL(pack16x3_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, W, ldw, K, N, tiles, (long)ksteps * tiles * 512, scale,
                        reinterpret_cast<_Float16*>(packed));
     CAR_CHECK_LAUNCH("car_linear_x3_pack");

@@ -200,10 +200,22 @@ class RenderEngine:
                 self._pair = None
                 self._pair, self._pair_key = pf["pair"], (key, pf["plan_key"], 0, pf["b"])
                 return self._maps
-            self._maps = [t.detach().float().permute(0, 2, 3, 1).contiguous() for t in z]
+            self._maps = [self._as_channel_last(t) for t in z]
             self._maps_key = key
             self._maps_src = list(z)
         return self._maps
+
+    @staticmethod
+    def _as_channel_last(t: Tensor) -> Tensor:
+        """[n, C, H, W] -> [n, H, W, C] rows for the kernels: a VIEW when the level already lies channel-last in memory (torch.channels_last:
+        what an encoder run in that memory format returns, and what the training scripts allocate) — no copy; a channel-last copy
+        otherwise (the reference's NCHW pyramid)."""
+        tt = t.detach()
+        if tt.dtype == torch.float32:
+            v = tt.permute(0, 2, 3, 1)
+            if v.is_contiguous():
+                return v
+        return tt.float().permute(0, 2, 3, 1).contiguous()
 
     def prefetch(self, z: List[Tensor]) -> bool:
         """Announces the NEXT stereo pair's pyramid while the current frame is still to be rendered (the eval loop knows its next batch:

@@ -169,6 +169,13 @@ class CrossAttentionRenderer(nn.Module):
     def forward(self, input, z=None, val=False, debug=False) -> Dict[str, Tensor]:
         """Render the query rays (models.py:190-626) on the HIP engine.  ``input`` is not mutated."""
         from .engine import RenderEngine          # deferred: importing the package must work without the .so
+        if self.training and torch.is_grad_enabled() and not debug and (
+                any(p.requires_grad for p in self.parameters()) or (z is not None and any(t.requires_grad for t in z))):
+            # the reference's training loop calls model(model_input) on a module in train() mode under autograd (training.py:92): the same
+            # call here is the forward with gradients (training.render_train: HIP forward and backward); eval() / no_grad() callers — the
+            # render and eval scripts — take the inference engine below
+            from .training import render_train
+            return render_train(self, input, z)
         if z is None:
             z = self.get_z(input)
         elif not hasattr(self, "H"):

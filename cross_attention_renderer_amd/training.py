@@ -254,6 +254,9 @@ class _RenderTrain(torch.autograd.Function):
         ctx.param_versions = {nme: t._version for nme, t in ctx.params.items()}
         ctx.need_dz = any(ctx.needs_input_grad[3:3 + n_levels])
         ctx.z_dtypes = [t.dtype for t in z]
+        # a level that lies channel-last in memory gets its gradient back as a view of the channel-last scatter buffer (same strides as the
+        # level: no NHWC -> NCHW copy, as the forward took it without the NCHW -> NHWC one)
+        ctx.z_channel_last = [t.dtype == torch.float32 and t.permute(0, 2, 3, 1).is_contiguous() for t in z]
         outs = (rgb.view(b, 1, R, 3), depth[..., None], valid[..., None], at_wt, amax.long()[..., None], coords9, pixel_val)
         ctx.mark_non_differentiable(*outs[2:])
         return outs
@@ -408,7 +411,8 @@ class _RenderTrain(torch.autograd.Function):
                         ops.gather_backward(dm_o, grid, R * P, 1, PLACE_PLAIN, 1, d_rows, C, 0)
                         for full, part in zip(dmaps, dm_o):
                             full.view(b, V, *full.shape[1:])[:, o_] += part
-                    dz = [t.permute(0, 3, 1, 2).contiguous().to(dt) if nd else None for t, dt, nd in zip(dmaps, ctx.z_dtypes, need)]
+                    dz = [(t.permute(0, 3, 1, 2) if cl else t.permute(0, 3, 1, 2).contiguous().to(dt)) if nd else None
+                          for t, dt, nd, cl in zip(dmaps, ctx.z_dtypes, need, ctx.z_channel_last)]
             elif mode == "single":
                 wgrad("update_val_merge", d_e, Ce, sv["x1"], ld1, S)
                 if ctx.need_dz:
@@ -422,7 +426,8 @@ class _RenderTrain(torch.autograd.Function):
                 dmaps = [torch.zeros_like(t) for t in ctx.maps]
                 for grid, pad_mode, place in d_gather[2]:
                     ops.gather_backward(dmaps, grid, R * P, pad_mode, place, V, d_gather[0], d_gather[1], 0)
-                dz = [t.permute(0, 3, 1, 2).contiguous().to(dt) if nd else None for t, dt, nd in zip(dmaps, ctx.z_dtypes, need)]
+                dz = [(t.permute(0, 3, 1, 2) if cl else t.permute(0, 3, 1, 2).contiguous().to(dt)) if nd else None
+                      for t, dt, nd, cl in zip(dmaps, ctx.z_dtypes, need, ctx.z_channel_last)]
         out = [None, None, None] + dz + [grads[k].view_as(par[k]).to(par[k].dtype) for k in _param_names(m)]
         return tuple(out)
 

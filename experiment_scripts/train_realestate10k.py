@@ -54,7 +54,8 @@ def train(rank, opt):
     base = synthetic.stereo_scene(H, b=b, seed=5 + rank, n_view=opt.views)
     z = None
     if model.encoder.__class__.__name__ == "EncoderNotBuilt":
-        z = [t.to(dev).requires_grad_(True) for t in synthetic.feature_maps(b, opt.views, H, seed=1 + rank)]
+        # torch.channels_last memory: the renderer takes such a level as a view and returns its gradient in the same layout (no copies)
+        z = [t.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True) for t in synthetic.feature_maps(b, opt.views, H, seed=1 + rank)]
     optimizer = training.make_adam(params, opt.lr)                  # the reference's Adam and parameter group: what the checkpoint stores
     # the stand-in pyramid (no encoder built) is a per-rank leaf with an optimizer of its own, so that the saved 'optimizer' state matches
     # the reference's param groups
@@ -88,7 +89,7 @@ def train(rank, opt):
         u = inp["query"]["uv"][:, 0] / (H - 1) * 3.14159
         feats = torch.stack([torch.sin(u[..., 0]), torch.cos(u[..., 1]), torch.sin(u[..., 0] + u[..., 1]), torch.ones_like(u[..., 0])], dim=-1)
         gt_rgb = torch.tanh(torch.einsum("brk,bck->brc", feats, coef))[:, None]                             # (b, 1, R, 3)
-        out = render_train(model, inp, z=z)
+        out = model(inp, z=z)                                    # train() mode under autograd = training.render_train (the reference's call, training.py:92)
         loss = (gt_rgb - out["rgb"]).abs().mean()                                                           # loss_functions.image_loss
         if opt.depth:                                            # loss_functions.py:112-127: per-patch depth variance, masked per patch
             d = out["depth_ray"][..., 0].reshape(-1, 1, 32, 32)

@@ -178,3 +178,48 @@ def test_a_gradient_step_lowers_the_image_loss_by_the_predicted_amount():
     loss1 = loss_of().item()
     drop = loss0.item() - loss1
     assert np.isfinite(loss1) and predicted / 1.5 <= drop <= predicted * 1.5, (loss0.item(), loss1, predicted)
+
+
+def test_model_call_in_train_mode_carries_gradients_and_channel_last_levels_are_taken_as_they_lie():
+    """The reference's training loop calls model(model_input) (training.py:92): on a module in train() mode under autograd that call IS
+    render_train here; under no_grad() or in eval() mode it is the inference engine.  A pyramid level in torch.channels_last memory is used
+    as a view (no NCHW -> NHWC copy) and gets its gradient back in the same layout; the outputs equal the NCHW call's bit for bit, the gradients to the rounding of their atomics' order."""
+    from cross_attention_renderer_amd import synthetic as S
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    from cross_attention_renderer_amd.training import render_train
+    dev = torch.device("cuda:0")
+    H, P, R = 64, 16, 96
+    torch.manual_seed(0)
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).train()
+    S.perturb_parameters(m, seed=2)
+    m.H = m.W = H
+    m = m.to(dev)
+    inp = to_device(S.stereo_scene(H, b=2, uv=S.pixel_grid(H, H)[::43][:R].contiguous(), seed=6), dev, cameras_on_host=True)
+    base = [t.to(dev) for t in S.feature_maps(2, 2, H, seed=1)]
+    g = torch.Generator().manual_seed(1)
+    cot = torch.randn(2, 1, R, 3, generator=g).to(dev)
+
+    def grads(call, zs):
+        for p in m.parameters():
+            p.grad = None
+        out = call(zs)
+        assert out["rgb"].requires_grad and out["depth_ray"].requires_grad
+        ((out["rgb"] * cot).sum() + out["depth_ray"].sum()).backward()
+        return out, {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}, [t.grad for t in zs]
+    z_nchw = [t.clone().requires_grad_(True) for t in base]
+    z_cl = [t.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True) for t in base]
+    out_a, pg_a, zg_a = grads(lambda zs: render_train(m, inp, z=zs), z_nchw)
+    out_b, pg_b, zg_b = grads(lambda zs: m(inp, z=zs), z_cl)             # the module call itself, channel-last levels
+    eng = m._engine
+    assert all(mp.data_ptr() == t.data_ptr() for mp, t in zip(eng._maps, z_cl)), "a channel-last level was copied"
+    assert torch.equal(out_a["rgb"], out_b["rgb"]) and sorted(pg_a) == sorted(pg_b)
+    # the gradients meet in fp32 atomics (row slabs of the weight gradients, the pyramid's scatter): the same sums in another order from
+    # run to run, so "equal" means to fp32 rounding of the largest entry
+    close = lambda a, b_: (a - b_).abs().max().item() <= 2e-6 * max(a.abs().max().item(), 1e-30)
+    for k in pg_a:
+        assert close(pg_a[k], pg_b[k]), k
+    for a, b_, t in zip(zg_a, zg_b, z_cl):
+        assert b_.stride() == t.stride() and close(a, b_)
+    with torch.no_grad():
+        assert not m(inp, z=z_cl)["rgb"].requires_grad               # no_grad: the inference engine
+    assert not m.eval()(inp, z=z_cl)["rgb"].requires_grad            # eval(): the inference engine (its forward never builds a graph)

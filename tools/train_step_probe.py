@@ -22,7 +22,8 @@ def main():
     model = bench.build_model(dev).train()
     params = [p for p in model.parameters() if p.requires_grad]
     base = harness.to_device(synthetic.stereo_scene(H, b=b, seed=5), dev)          # cameras stay on the host
-    z = [t.to(dev).requires_grad_(True) for t in synthetic.feature_maps(b, 2, H, seed=1)]
+    cl = os.environ.get("CAR_PYRAMID", "channels_last") == "channels_last"         # the stand-in pyramid in torch.channels_last memory: no layout copies
+    z = [(t.to(dev).contiguous(memory_format=torch.channels_last) if cl else t.to(dev)).requires_grad_(True) for t in synthetic.feature_maps(b, 2, H, seed=1)]
     opt = training.make_adam(params, 5e-5)
     zopt = training.make_adam(z, 5e-5)
     grid = synthetic.pixel_grid(H, H).to(dev)
