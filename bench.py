@@ -59,9 +59,10 @@ CONFIGS = {
     "c2": (256, 64, 1, 256 * 256, "256x256 query frame, 64 samples/view, 2 context views (config 2)"),
     "c3": (256, 64, 12, 8192, "batch of 12 scenes at 256x256, 64 samples/view, one rank's band of 8192 rays per scene (config 3's per-rank share at 8 GPUs)"),
     "c4": (256, 128, 1, 256 * 256, "256x256 query frame, 128 samples/view (config 4, gather-bound stress)"),
-    "c5": (384, 64, 1, 384 * 384, "384x384 query frame, 64 samples/view (config 5's frame on one GPU)"),
+    "c5": (384, 64, 1, 384 * 384, "384x384 query frame of an UNPOSED pair (seeded R, unit t / 1.2 as the essential-matrix route places them), 64 samples/view (config 5's frame on one GPU)"),
 }
 H, P = 256, 64                     # the headline configuration's sizes (module-level for tools/ that import this file)
+SCENE = "stereo"                   # "unposed" for config 5: the pair of synthetic.unposed_scene (seeded R, unit t)
 FP32_MFMA_PEAK = 157.3e12          # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md)
 F16_MFMA_PEAK = 2.5e15             # v_mfma_f32_32x32x16_f16, dense (never the 2:1-sparse marketing figure)
 HBM_PEAK = 8.0e12
@@ -86,7 +87,10 @@ def make_frame(alpha: float, device, H_=None, b=1):
     """Input dict + feature pyramid for one query frame (the same stereo pair(s), query pose at ``alpha``)."""
     from cross_attention_renderer_amd import synthetic as S
     Hh = H if H_ is None else H_
-    inp = S.stereo_scene(Hh, b=b, alpha=alpha, seed=5)
+    if SCENE == "unposed":                                             # query = a pose of the unposed demo's rotate_interpolate path
+        inp = S.unposed_scene(Hh, frame=int(round(alpha * 75)), seed=5)
+    else:
+        inp = S.stereo_scene(Hh, b=b, alpha=alpha, seed=5)
     z = S.feature_maps(b, V, Hh, seed=1)
     if device is not None:
         inp = {k: {kk: vv.to(device) for kk, vv in v.items()} for k, v in inp.items()}
@@ -309,6 +313,9 @@ def main():
     from cross_attention_renderer_amd.sharding import TileGather, ray_band
 
     Hc, Pc, nb, R_frame, what = CONFIGS[args.config]
+    if args.config == "c5":
+        global SCENE
+        SCENE = "unposed"
     if world > 1 and nb != 1:
         # config 3 on N ranks (BASELINE: "batch_size 12, ray-sharded across 8 GPUs"): the rays of ALL twelve scenes' frames are banded —
         # rank g renders rays [g R / N, (g + 1) R / N) of every scene (shard rays, not scenes: 12 is no multiple of 8) and the
@@ -529,7 +536,8 @@ def main():
                     # which of these fields this run measured and which it copied from the committed counter passes
                     "live_fields": ["achieved", "frac", "frac_executed", "frac_of_fp32_pipe_peak", "launches", "ms_per_launch", "flop_per_launch", "flop_executed_per_launch"],
                     "static_fields": ["limiter", "ta_busy", "mfma_busy", "valu_share", "l1_bytes", "traffic", "per_unit_unthrottled_frac"],
-                    "static": "profiles/traffic.json: rocprofv3 --pmc passes of an earlier run of this kernel at config c2 (separate passes, not collected here; null for the other configs)",
+                    "static": "profiles/traffic.json: rocprofv3 --pmc passes of this kernel at config c2 (separate passes by construction, not collected here; null for the other configs)",
+                    "static_as_of": pmc.get("as_of"),      # date / build of the counter passes the static fields were copied from
                     "launches": len(lat), "ms_per_launch": mean * 1e3, "flop_per_launch": flop,
                     # what the kernel executes since round 6: key_map_2 and query_embed_2 folded into ONE 128 x 128 layer (the logit is a
                     # bilinear form of the two hidden vectors): 16 384 of the 440 320 algorithmic MACs per sample are not issued
@@ -547,7 +555,8 @@ def main():
             per_frame = fr["bytes_per_frame"]
             hbm = {"bytes_per_frame": per_frame, "achieved": per_frame / (elapsed / args.steps) / 1e12, "peak": 8.0, "unit": "TB/s",
                    "frac": per_frame / (elapsed / args.steps) / HBM_PEAK, "source": fr["source"],
-                   "static": "bytes_per_frame comes from profiles/traffic.json (PMC passes, not collected in this run); the time is this run's"}
+                   "static": "bytes_per_frame comes from profiles/traffic.json (PMC passes, not collected in this run); the time is this run's",
+                   "static_as_of": fr.get("as_of")}
         ref_flop = V * Pc * 2617728 + 791808
         calls = -(-R // args.chunk_rays)
         ms_step = elapsed / args.steps * 1e3

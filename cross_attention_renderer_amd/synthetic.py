@@ -168,3 +168,40 @@ def seeded_state_dict(shapes: Dict[str, Sequence[int]], seed: int = 0) -> Dict[s
             t = t / math.sqrt(max(fan_in, 1))
         out[name] = t
     return out
+
+
+def unposed_scene(H: int, frame: int = 38, n_poses: int = 80, uv: Optional[Tensor] = None, seed: int = 0, sf: float = 1.2):
+    """Config 5's synthetic input (load_video_superglue.py:465-483): two views of UNKNOWN pose, related by the (R, t) an
+    essential-matrix decomposition returns — a seeded rotation (about 14 degrees about a near-vertical axis) and a UNIT translation, the
+    scale being unobservable — placed as the unposed demo places them: the first camera is the world frame, the second sits at
+    inv([R | t]) with its position divided by ``sf``; the query is pose ``frame`` of ``trajectory.rotate_interpolate`` between them
+    (``n_poses`` - 4 of them); intrinsics = ``pinhole(H)`` for all three.  Returns an input dict shaped like ``stereo_scene``'s (b = 1)."""
+    import numpy as np
+    from . import trajectory as T
+    g = torch.Generator().manual_seed(seed)
+    r = torch.rand(6, generator=g, dtype=torch.float64)
+    axis = np.array([0.15 * (r[0].item() - 0.5), 1.0, 0.15 * (r[1].item() - 0.5)])
+    axis /= np.linalg.norm(axis)
+    ang = np.deg2rad(12.0 + 4.0 * r[2].item())
+    Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * (Kx @ Kx)                 # Rodrigues
+    t = np.array([-1.0, 0.08 * (r[3].item() - 0.5), 0.25 * (r[4].item() - 0.5)])
+    t /= np.linalg.norm(t)                                                          # recoverPose: unit translation
+    pose2 = np.eye(4)
+    pose2[:3, :3], pose2[:3, 3] = R, t
+    pose2 = np.linalg.inv(pose2)
+    pose2[:3, 3] /= sf
+    ctx = np.stack([np.eye(4), pose2])
+    path = T.rotate_interpolate(ctx, n_poses)
+    q = path[min(max(frame, 0), path.shape[0] - 1)]
+    if uv is None:
+        uv = pixel_grid(H, H)
+    Kf = pinhole(H).float()
+    Rn = uv.shape[0]
+    return {
+        "context": {"rgb": torch.zeros(1, 2, H, H, 3), "cam2world": torch.from_numpy(ctx).float()[None],
+                    "intrinsics": Kf[None, None].expand(1, 2, 4, 4).contiguous()},
+        "query": {"cam2world": torch.from_numpy(q).float()[None, None], "intrinsics": Kf[None, None].expand(1, 1, 4, 4).contiguous(),
+                  "uv": uv[None, None].expand(1, 1, Rn, 2).contiguous()},
+    }
+

@@ -49,7 +49,8 @@ CASES: Dict[str, dict] = {
     "t2_c2": dict(tier=2, H=256, P=64, b=1, rays=64, **REAL),
     "t2_c3": dict(tier=2, H=256, P=64, b=2, rays=48, alpha=0.3, **REAL),
     "t2_c4": dict(tier=2, H=256, P=128, b=1, rays=48, **REAL),
-    "t2_c5": dict(tier=2, H=384, P=64, b=1, rays=48, alpha=0.7, **REAL),
+    # config 5: the unposed pair (seeded R, unit t as an essential-matrix decomposition returns them; synthetic.unposed_scene), 384 x 384
+    "t2_c5": dict(tier=2, H=384, P=64, b=1, rays=48, scene="unposed", frame=52, **REAL),
 }
 
 DEFAULTS = dict(n_view=2, no_sample=False, no_latent_concat=False, repeat_attention=True,
@@ -88,6 +89,9 @@ def param_shapes(c: dict) -> Dict[str, tuple]:
 def build_inputs(c: dict):
     """(input dict, z list, uv) for a case, regenerated from seeds."""
     uv = select_rays(c["H"], c["rays"])
+    if c.get("scene") == "unposed":
+        return S.unposed_scene(c["H"], frame=c["frame"], uv=uv, seed=c["scene_seed"]), \
+            S.feature_maps(c["b"], c["n_view"], c["H"], seed=c["z_seed"], channels=c["channels"], strides=c["strides"])
     inp = S.stereo_scene(c["H"], b=c["b"], alpha=c["alpha"], baseline=c["baseline"], yaw_deg=c["yaw_deg"],
                          uv=uv, seed=c["scene_seed"], n_view=c["n_view"], query_at_context=c["query_at_context"])
     z = S.feature_maps(c["b"], c["n_view"], c["H"], seed=c["z_seed"], channels=c["channels"], strides=c["strides"])
