@@ -172,78 +172,111 @@ int launch_wgrad_tile(const float* dY, int ldy, const float* X, int ldx, long M,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same product on the bf16 matrix pipe (round 5): dW = dY^T X as three v_mfma_f32_16x16x32_bf16 products of bf16 hi / lo halves of BOTH
-// operands (hi hi + hi lo + lo hi, fp32 accumulate).  Both operands are activations here — no pack-time scale to lean on — and bf16 keeps
-// fp32's exponent, so no power of two has to be agreed on per launch, block or row (what the split-fp16 attempt of round 4 spent its time on):
-// x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), both rounded to nearest, |r| <= 2^-18 |x|; the dropped lo lo term is 2^-18
-// relative.  Errors are rounding-like (unbiased), far inside the gradient tests' bound (2e-5 of the largest entry against fp64).
+// The same product on the bf16 matrix pipe (round 5; staging rebuilt in round 6): dW = dY^T X as three v_mfma_f32_16x16x32_bf16 products of
+// bf16 hi / lo halves of BOTH operands (hi hi + hi lo + lo hi, fp32 accumulate).  Both operands are activations here — no pack-time scale to
+// lean on — and bf16 keeps fp32's exponent, so no power of two has to be agreed on per launch, block or row: x = hi + lo + r with
+// hi = bf16(x), lo = bf16(x - hi), both rounded to nearest, |r| <= 2^-18 |x|; the dropped lo lo term is 2^-18 relative.  Errors are
+// rounding-like (unbiased), far inside the gradient tests' bound (2e-5 of the largest entry against fp64).
 // A = dY^T (16 outputs n x 32 rows m), B = X (32 rows x 16 inputs k): lane (l & 15, l >> 4) feeds column l & 15 of its operand with the 8
 // rows 8 (l >> 4) .. + 7 — a COLUMN of the row-major block, so the transpose happens when the block is staged: a thread takes 8 rows x 4
-// columns from memory (8 float4, coalesced along the row), splits them, and writes each column's 8 rows as ONE 16-byte word per half into
-// an LDS image [column][32 rows]; a wave's operand read is then 1 KB contiguous (conflict-free).  512 threads = 8 waves as 2 x 4 over a
-// 192 x 320 tile of dW (a wave: 96 x 80 = 6 x 5 blocks, 120 accumulator registers), (192 + 320) / 4 column quads x 4 row octets = exactly
-// one staging task per thread and 32-row block; the next block's loads fly under this block's MFMAs, LDS is double buffered (131 KB), one
-// barrier per block.  Row slabs meet in dW with fp32 atomics, as in the fp32-pipe kernel.
+// columns from memory (8 float4, coalesced along the row) as two half tasks of 4 rows, splits them (v_cvt_pk_bf16_f32, two rows per
+// instruction) and writes 8 bytes per column, half task and operand half into the LDS image.  512 threads = 8 waves as 2 x 4 over a
+// 192 x 320 tile of dW (a wave: 96 x 80 = 6 x 5 blocks, 120 accumulator registers); waves 0-2 stage dY, waves 3-7 stage X (wave-uniform:
+// operand base and stride sit in scalar registers, a thread keeps one 32-bit offset).
+// Round 6 (tools/probes/wgrad_probe.hip, profiles/round6_wgrad16.md; 2.29 -> 1.18 ms on the first point-MLP layer):
+//  * staging is branch-free: the slab's whole blocks run a body without row tests, columns past an operand's edge are staged as they
+//    come (they only reach outputs that are never written), the bias column is one select per value;
+//  * loads run TWO blocks ahead: a half task of block b + 1 is converted between the MFMAs of block b and its registers are refilled at
+//    once with block b + 2, so every load has a whole iteration to land with the 32 staging registers of before;
+//  * the iteration is 18 groups of five independent MFMAs (one product kind of one row of blocks) with the eight staging pieces placed
+//    between them behind scheduling fences: a wave's vector work runs under its own MFMAs (the two waves of a SIMD leave every barrier in
+//    phase; unfenced, both convert at the same time and the matrix pipe idles);
+//  * LDS image of an operand half: blocks of 16 columns, inside a block [row octet g][column ^ g] 16-byte entries, so that lane (nl, g)
+//    of an operand read takes entry 16 g + (nl ^ g) and every 16-lane group of a ds_read_b128 covers all 64 banks (the plain
+//    [column][octet] order is two-way conflicted on gfx950's lane groups).
+// LDS is double buffered (131 KB), one barrier per block.  Row slabs meet in dW with fp32 atomics, as in the fp32-pipe kernel.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float wf32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
+typedef float wf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
 constexpr int kW16Rows = 32, kW16N = 192, kW16K = 320, kW16Threads = 512;
 constexpr int kW16QuadsA = kW16N / 4, kW16Quads = (kW16N + kW16K) / 4;                 // 48 + 80 column quads
 static_assert(kW16Quads * (kW16Rows / 8) == kW16Threads, "one staging task per thread");
-constexpr int kW16PlaneA = kW16N * kW16Rows / 2, kW16PlaneB = kW16K * kW16Rows / 2;    // floats per (operand, half) plane: [column][32 rows] bf16
+static_assert(kW16QuadsA * 4 % 64 == 0, "whole waves stage dY");
+static_assert(kW16N % 16 == 0 && kW16K % 16 == 0, "16-column blocks");
+constexpr int kW16PlaneA = kW16N * kW16Rows / 2, kW16PlaneB = kW16K * kW16Rows / 2;    // floats per (operand, half) plane
 constexpr int kW16Buf = 2 * (kW16PlaneA + kW16PlaneB);                                // floats per buffer: A hi | A lo | B hi | B lo
+template <bool B> struct W16Flag { static constexpr bool value = B; };
 
+// rows 2 rp, 2 rp + 1 (rp = 0, 1) of a half task, column i of the quad: hi / lo pairs to the two planes
+template <bool RELU, bool FULL>
+__device__ __forceinline__ void w16_piece(const wf32x4 (&st)[4], int i, float* dst, int slot, int plane_floats, float floor, bool isone, int rows_left) {
+    unsigned h[2], l[2];
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {
+        float v0 = st[2 * rp][i], v1 = st[2 * rp + 1][i];
+        if (RELU) { v0 = fmaxf(v0, floor); v1 = fmaxf(v1, floor); }                   // floor = 0 for X, -inf for dY
+        v0 = isone ? 1.0f : v0;                                                        // the bias column
+        v1 = isone ? 1.0f : v1;
+        if (!FULL) { if (2 * rp >= rows_left) v0 = 0.0f; if (2 * rp + 1 >= rows_left) v1 = 0.0f; }
+        // both halves rounded to nearest: a truncated hi would leave residuals of x's own sign, and the dropped lo lo products a bias
+        const bf16x2 hp = __builtin_convertvector(wf32x2{v0, v1}, bf16x2);
+        h[rp] = __builtin_bit_cast(unsigned, hp);
+        const float r0 = v0 - __uint_as_float(h[rp] << 16), r1 = v1 - __uint_as_float(h[rp] & 0xffff0000u);      // exact
+        const bf16x2 lp = __builtin_convertvector(wf32x2{r0, r1}, bf16x2);
+        l[rp] = __builtin_bit_cast(unsigned, lp);
+    }
+    float* d = dst + (slot ^ (4 * i));
+    *reinterpret_cast<wu32x2*>(d) = wu32x2{h[0], h[1]};
+    *reinterpret_cast<wu32x2*>(d + plane_floats) = wu32x2{l[0], l[1]};
+}
+
+template <bool RELU>
 __global__ void __launch_bounds__(kW16Threads) wgrad16_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, long M, int N,
-                                                              int K, int relu_x, long slab_rows, float* __restrict__ dW, int lddw, float* __restrict__ db) {
+                                                              int K, long slab_rows, float* __restrict__ dW, int lddw, float* __restrict__ db) {
     extern __shared__ __attribute__((aligned(16))) float lds[];                       // [2][kW16Buf]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 2, wk = wave & 3;                                          // the wave's 96 x 80 corner of the tile
     const int n0 = blockIdx.x * kW16N, k0 = blockIdx.y * kW16K;
     const int Kb = db ? K + 1 : K;
     const long m_begin = (long)blockIdx.z * slab_rows;
     const long m_end = m_begin + slab_rows < M ? m_begin + slab_rows : M;
     // staging task: column quad q of [dY's 48 | X's 80], row octet o of the 32-row block
+    const bool isA = wave < kW16QuadsA * 4 / 64;
     const int q = tid >> 2, o = tid & 3;
-    const bool isA = q < kW16QuadsA;
     const int c = isA ? 4 * q : 4 * (q - kW16QuadsA);                                 // first column inside the operand's tile
     const float* src = isA ? dY : X;
     const int ld = isA ? ldy : ldx, col0 = isA ? n0 + c : k0 + c;
     const int colc = col0 < ld - 3 ? col0 : 0;                                         // clamped: always a readable float4
-    wf32x4 stage[8];
-    auto fetch = [&](long m) {
+    bool isone[4];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const long row = m + 8 * o + r < m_end ? m + 8 * o + r : m_end - 1;
-            stage[r] = *reinterpret_cast<const wf32x4*>(src + row * ld + colc);
+    for (int i = 0; i < 4; ++i) isone[i] = !isA && db && col0 + i == K;
+    const unsigned voff = 4u * (unsigned)(8 * o * ld + colc);                          // bytes, inside a block
+    float* plane0 = lds + (isA ? 0 : 2 * kW16PlaneA);
+    const int slot0 = (c >> 4) * 256 + 64 * o + 4 * (c & 15) + 4 * o;                  // entry 16 o + ((c & 15) ^ o) of block c / 16 [xor 4 i per column]
+    const int plane_floats = isA ? kW16PlaneA : kW16PlaneB;
+    const float floor = isA ? -__builtin_inff() : 0.0f;
+    wf32x4 st[2][4];                                                                   // [half task][row]
+    auto load_half = [&](int hf, long m0, bool full) {
+        const char* blk = reinterpret_cast<const char*>(src + m0 * ld);
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[hf][r] = *reinterpret_cast<const wf32x4*>(blk + (voff + 4u * (unsigned)((4 * hf + r) * ld)));
+        } else {
+            const int left = (int)(m_end - m0) - 1;                                    // last row of the slab's partial block
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 8 * o + 4 * hf + r < left ? 8 * o + 4 * hf + r : left;
+                st[hf][r] = *reinterpret_cast<const wf32x4*>(blk + 4u * (unsigned)(row * ld + colc));
+            }
         }
     };
-    auto commit = [&](int buf, long m) {
-        float* plane = lds + buf * kW16Buf + (isA ? 0 : 2 * kW16PlaneA);
-        const int plane_floats = isA ? kW16PlaneA : kW16PlaneB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int col = col0 + i;
-            unsigned hi[8], lo[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float v = stage[r][i];
-                const bool in_rows = m + 8 * o + r < m_end;
-                if (isA) { if (!in_rows || col0 >= ld - 3 || col >= N) v = 0.0f; }
-                else if (col >= K) v = (col == K && db && in_rows) ? 1.0f : 0.0f;     // the bias column, then nothing
-                else if (!in_rows || col0 >= ld - 3) v = 0.0f;
-                else if (relu_x) v = fmaxf(v, 0.0f);
-                // both halves rounded to nearest: a truncated hi would leave residuals of x's own sign, and the dropped lo lo products a bias
-                hi[r] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
-                const float res = v - __uint_as_float(hi[r] << 16);                    // exact
-                lo[r] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)res);
-            }
-            const wu32x4 h4 = {hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16), hi[4] | (hi[5] << 16), hi[6] | (hi[7] << 16)};
-            const wu32x4 l4 = {lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16)};
-            float* dst = plane + ((c + i) * kW16Rows + 8 * o) / 2;                     // [column][32 rows] bf16: 16 floats per column
-            *reinterpret_cast<wu32x4*>(dst) = h4;
-            *reinterpret_cast<wu32x4*>(dst + plane_floats) = l4;
-        }
+    auto piece = [&](int hf, int i, int buf, long m0, bool full) {
+        float* dst = plane0 + buf * kW16Buf + 2 * hf;                                  // rows 4 hf .. of the octet: 8 bytes in
+        if (full) w16_piece<RELU, true>(st[hf], i, dst, slot0, plane_floats, floor, isone[i], 4);
+        else w16_piece<RELU, false>(st[hf], i, dst, slot0, plane_floats, floor, isone[i], (int)(m_end - m0) - (8 * o + 4 * hf));
     };
     wf32x4 acc[6][5];
 #pragma unroll
@@ -251,35 +284,60 @@ __global__ void __launch_bounds__(kW16Threads) wgrad16_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[i][j] = wf32x4{0.f, 0.f, 0.f, 0.f};
     const int nl = lane & 15, g = lane >> 4;
-    if (m_begin < m_end) { fetch(m_begin); commit(0, m_begin); }
+    if (m_begin < m_end) {
+        load_half(0, m_begin, false); load_half(1, m_begin, false);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { piece(0, i, 0, m_begin, false); piece(1, i, 0, m_begin, false); }
+        if (m_begin + kW16Rows < m_end) { load_half(0, m_begin + kW16Rows, false); load_half(1, m_begin + kW16Rows, false); }
+    }
     __syncthreads();
     int buf = 0;
-    for (long m = m_begin; m < m_end; m += kW16Rows) {
-        const bool more = m + kW16Rows < m_end;
-        if (more) fetch(m + kW16Rows);
-        const float* pa = lds + buf * kW16Buf + ((wn * 96 + nl) * kW16Rows + 8 * g) / 2;
-        const float* pb = lds + buf * kW16Buf + 2 * kW16PlaneA + ((wk * 80 + nl) * kW16Rows + 8 * g) / 2;
+    const int a_off = wn * 6 * 256 + 64 * g + 4 * (nl ^ g), b_off = 2 * kW16PlaneA + wk * 5 * 256 + 64 * g + 4 * (nl ^ g);
+    // one iteration: the MFMAs of block m out of buffer `buf`; block m + 1 staged into the other buffer; the loads of block m + 2
+    auto iteration = [&](long m, auto whole) {
+        constexpr bool kWhole = decltype(whole)::value;
+        const long m1 = m + kW16Rows, m2 = m + 2 * kW16Rows;
+        const bool has1 = kWhole || m1 < m_end, full1 = kWhole || m1 + kW16Rows <= m_end, has2 = kWhole || m2 < m_end, full2 = kWhole || m2 + kW16Rows <= m_end;
+        const float* pa = lds + buf * kW16Buf + a_off;
+        const float* pb = lds + buf * kW16Buf + b_off;
         bf16x8 bh[5], bl[5];
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pb + j * 16 * kW16Rows / 2));
-            bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pb + kW16PlaneB + j * 16 * kW16Rows / 2));
+            bh[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pb + j * 256));
+            bl[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pb + kW16PlaneB + j * 256));
         }
+        bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pa));
+        bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pa + kW16PlaneA));
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pa + i * 16 * kW16Rows / 2));
-            const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pa + kW16PlaneA + i * 16 * kW16Rows / 2));
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+            bf16x8 ahn = ah, aln = al;
+            if (i + 1 < 6) {
+                ahn = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pa + (i + 1) * 256));
+                aln = __builtin_bit_cast(bf16x8, *reinterpret_cast<const wf32x4*>(pa + kW16PlaneA + (i + 1) * 256));
             }
+#pragma unroll
+            for (int kind = 0; kind < 3; ++kind) {                                     // hi hi, hi lo, lo hi: acc[i][j] takes them in this order
+                const int grp = 3 * i + kind;                                          // 0 .. 17
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kind == 2 ? al : ah, kind == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+                if (kWhole) __builtin_amdgcn_sched_barrier(0);
+                // staging pieces: half task 0 behind groups 1-4, its reload behind 4; half task 1 behind 9-12, its reload behind 12
+                const int hf = grp < 8 ? 0 : 1, pi = grp - (grp < 8 ? 1 : 9);
+                if (pi >= 0 && pi < 4) {
+                    if (has1) piece(hf, pi, buf ^ 1, m1, full1);
+                    if (pi == 3 && has2) load_half(hf, m2, full2);
+                    if (kWhole) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            ah = ahn; al = aln;
         }
-        if (more) commit(buf ^ 1, m + kW16Rows);
         __syncthreads();
         buf ^= 1;
-    }
+    };
+    long m = m_begin;
+    for (; m + 3 * kW16Rows <= m_end; m += kW16Rows) iteration(m, W16Flag<true>{});
+    for (; m < m_end; m += kW16Rows) iteration(m, W16Flag<false>{});
     // lane (nl, g) holds, of block (i, j): dW rows n = 16 i + 4 g + r (r = 0..3), column k = 16 j + nl
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -306,18 +364,20 @@ int launch_wgrad16(const float* dY, int ldy, const float* X, int ldx, long M, in
     slab = (slab + kW16Rows - 1) / kW16Rows * kW16Rows;
     const unsigned gz = car_div_up(M, slab);
     CAR_REQUIRE(gz <= 65535, "car_linear_wgrad: too many row slabs");
+    CAR_REQUIRE((long)kW16Rows * (ldy > ldx ? ldy : ldx) < (1l << 29), "car_linear_wgrad: row stride too large for the 32-bit block offsets");
     const size_t lds_bytes = (size_t)2 * kW16Buf * sizeof(float);
-    static bool reserved[64] = {};
+    const bool relu = (flags & CAR_LIN_RELU_IN) != 0;
+    auto kern = relu ? wgrad16_kernel<true> : wgrad16_kernel<false>;
+    static bool reserved[2][64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !reserved[dev]) {
-        hipError_t e1 = hipFuncSetAttribute((const void*)wgrad16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (dev < 0 || dev >= 64 || !reserved[relu][dev]) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e1 != hipSuccess) { car_set_error("car_linear_wgrad: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e1)); return CAR_E_LAUNCH; }
-        if (dev >= 0 && dev < 64) reserved[dev] = true;
+        if (dev >= 0 && dev < 64) reserved[relu][dev] = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL(wgrad16_kernel, dim3(gx, gy, gz), dim3(kW16Threads), lds_bytes, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K,
-                       (flags & CAR_LIN_RELU_IN) ? 1 : 0, slab, dW, lddw, db);
+    hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(kW16Threads), lds_bytes, (hipStream_t)stream, dY, ldy, X, ldx, M, N, K, slab, dW, lddw, db);
     CAR_CHECK_LAUNCH("car_linear_wgrad");
     return CAR_OK;
 }
