@@ -96,6 +96,7 @@ SIGNATURES = {
     "car_linear_x3_packed_floats": (c_size_t, [c_int, c_int]),
     "car_linear_x3_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "car_linear_x3": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, c_long, c_int, _P]),
+    "car_linear_x3_masked": (c_int, [_P, c_int, _P, _P, c_int, c_int, _P, c_int, c_long, c_int, _P, c_int, _P]),
     "car_chain_pack": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "car_ray_mid": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, _P, c_long, _P]),
     "car_ray_tail": (c_int, [_P, _P, _P, c_int, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P]),

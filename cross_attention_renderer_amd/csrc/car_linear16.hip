@@ -45,6 +45,8 @@ struct LinArgs {
     // KQ (car_key_query_logits): the layer is key_map (relu behind it); its 128 outputs stay in the accumulators and run on through
     // key_map_2, while query_embed / query_embed_2 run on the row's 16-float geometric query g; out come qry [M,128] and logit [M]
     const float* g; const float* tail; const float* tail_bias; float* qry; float* logit;
+    // car_linear_x3_masked (the data gradient of a layer that sits behind a ReLU): result columns whose activation is not positive are zero
+    const float* mask; int ldm;
 };
 
 template <int NT, bool GATHER = false, bool KQ = false>
@@ -268,12 +270,17 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
     scale_acc<NT>(acc, dW * pinv);
     const bool relu_out = (a.flags & CAR_LIN_RELU_OUT) != 0, accum = (a.flags & CAR_LIN_ACCUM) != 0;
     float* yrow = a.Y + row * a.ldy + 16 * tile0 + 4 * q4;
+    const float* mrow = a.mask ? a.mask + row * a.ldm + 16 * tile0 + 4 * q4 : nullptr;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         float4* dst = reinterpret_cast<float4*>(yrow + 16 * t);
         float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
         if (accum) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         if (relu_out) v = make_float4(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f), fmaxf(v.w, 0.0f));
+        if (mrow) {                                                    // car_relu_mask's rule: keep where the activation is > 0
+            const float4 k = *reinterpret_cast<const float4*>(mrow + 16 * t);
+            v = make_float4(k.x > 0.0f ? v.x : 0.0f, k.y > 0.0f ? v.y : 0.0f, k.z > 0.0f ? v.z : 0.0f, k.w > 0.0f ? v.w : 0.0f);
+        }
         *dst = v;
     }
 }
@@ -356,8 +363,26 @@ extern "C" int car_linear_x3_pack(const float* W, int ldw, int K, int N, float* 
     return CAR_OK;
 }
 
+namespace {
+int linear_x3(const float* X, int ldx, const float* packed, const float* bias, int K, int N, float* Y, int ldy, long M, int flags, const float* act,
+              int lda, void* stream);
+}
 extern "C" int car_linear_x3(const float* X, int ldx, const float* packed, const float* bias, int K, int N, float* Y, int ldy, long M, int flags,
                              void* stream) {
+    return linear_x3(X, ldx, packed, bias, K, N, Y, ldy, M, flags, nullptr, 0, stream);
+}
+// car_linear_x3 with car_relu_mask applied to the result as it is stored: Y[m][n] = act[m][n] > 0 ? (X W^T + bias (+ Y))[m][n] : 0 — the data
+// gradient dX = dY W of a layer whose input went through a ReLU (torch autograd's threshold_backward over models.py:333-341, 487-491, 529),
+// without the separate pass over dX and the activation.  Bit-identical to car_linear_x3 followed by car_relu_mask.
+extern "C" int car_linear_x3_masked(const float* X, int ldx, const float* packed, const float* bias, int K, int N, float* Y, int ldy, long M, int flags,
+                                    const float* act, int lda, void* stream) {
+    CAR_REQUIRE(act && lda >= N && lda % 4 == 0 && ((uintptr_t)act & 15) == 0,
+                "car_linear_x3_masked: act must be 16-byte aligned with a row stride (%d) that is a multiple of 4 and holds N = %d", lda, N);
+    return linear_x3(X, ldx, packed, bias, K, N, Y, ldy, M, flags, act, lda, stream);
+}
+namespace {
+int linear_x3(const float* X, int ldx, const float* packed, const float* bias, int K, int N, float* Y, int ldy, long M, int flags, const float* act,
+              int lda, void* stream) {
     CAR_REQUIRE(X && packed && Y && M > 0 && K > 0 && N > 0, "car_linear_x3: bad arguments");
     CAR_REQUIRE(N % 32 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= ((K + 3) & ~3) && ldy >= N,
                 "car_linear_x3: N = %d must be a multiple of 32, ldx = %d / ldy = %d multiples of 4 that hold a row", N, ldx, ldy);
@@ -367,12 +392,14 @@ extern "C" int car_linear_x3(const float* X, int ldx, const float* packed, const
     a.X = X; a.ldx = ldx; a.Wp = packed; a.tiles_total = tiles; a.bias = bias;
     a.down = packed + (size_t)ksteps * tiles * kTile + 1;
     a.K = K; a.chunks = ksteps; a.Y = Y; a.ldy = ldy; a.M = M; a.flags = flags;
+    a.mask = act; a.ldm = lda;
     hipStream_t st = (hipStream_t)stream;
     if (tiles % 18 == 0) return launch16<18>(a, tiles / 18, st);
     if (tiles % 8 == 0) return launch16<8>(a, tiles / 8, st);
     if (tiles % 4 == 0) return launch16<4>(a, tiles / 4, st);
     return launch16<2>(a, tiles / 2, st);
 }
+}  // namespace
 
 // car_lattice_encode_rows followed by car_linear_x3 in ONE kernel (the three-view exchange, models.py:345-475 — engine._encode_three_views):
 // Y[rows, N] = act(relu(rows of the merged lattice + point term) W^T + bias).  The K = 576-wide first-layer rows are never written: every

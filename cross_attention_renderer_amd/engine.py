@@ -675,20 +675,31 @@ class RenderEngine:
             return True
         raise RuntimeError(f"{what} failed ({rc}): {msg}")
 
-    def linear(self, x: Tensor, ldx: int, layer: PackedLinear, y: Tensor, ldy: int, M: int, flags: int = 0):
+    def linear(self, x: Tensor, ldx: int, layer: PackedLinear, y: Tensor, ldy: int, M: int, flags: int = 0, mask=None):
+        """``mask = (act, lda)``: the result is zeroed where ``act <= 0`` (the backward of a ReLU in front of the layer whose data gradient this
+        is) — in the split-fp16 kernel's store (car_linear_x3_masked), or by car_relu_mask behind the fp32-pipe kernel."""
         # linear_flags (the NO_GLDS A/B knob of car_linear) selects the fp32-pipe kernel for every layer: the split-fp16 kernel has no such
         # variant, and an A/B run must not change arithmetic on some layers only
         if (self.linear_x3 and not self.linear_flags and layer.x3 is not None and ldx % 4 == 0 and ldy % 4 == 0 and x.data_ptr() % 16 == 0
                 and y.data_ptr() % 16 == 0 and M >= self.linear_x3_min_rows):
             tiles, bias = layer.x3
-            rc = self.lib.car_linear_x3(_ptr(x), ldx, _ptr(tiles), _ptr(bias), layer.K, layer.N, _ptr(y), ldy, M, flags, _stream())
+            if mask is not None and mask[1] % 4 == 0 and mask[0].data_ptr() % 16 == 0:
+                rc = self.lib.car_linear_x3_masked(_ptr(x), ldx, _ptr(tiles), _ptr(bias), layer.K, layer.N, _ptr(y), ldy, M, flags, _ptr(mask[0]),
+                                                   mask[1], _stream())
+                mask = None if rc == 0 else mask
+            else:
+                rc = self.lib.car_linear_x3(_ptr(x), ldx, _ptr(tiles), _ptr(bias), layer.K, layer.N, _ptr(y), ldy, M, flags, _stream())
             if not self._lds_refused(rc, "car_linear_x3"):
+                if mask is not None:
+                    _lib.check(self.lib.car_relu_mask(_ptr(y), ldy, _ptr(mask[0]), mask[1], M, layer.N, _stream()), "car_relu_mask")
                 return
             # the split-fp16 kernel's 72 KB weight double buffer was refused: the same layer on the fp32 matrix pipe from here on — another
             # HIP kernel of the same library, never a host path
             self.linear_x3 = False
         _lib.check(self.lib.car_linear(_ptr(x), ldx, _ptr(layer.packed), layer.K, layer.N, _ptr(y), ldy, M,
                                        flags | self.linear_flags, _stream()), "car_linear")
+        if mask is not None:
+            _lib.check(self.lib.car_relu_mask(_ptr(y), ldy, _ptr(mask[0]), mask[1], M, layer.N, _stream()), "car_relu_mask")
 
     def gather(self, maps: List[Tensor], grid: Tensor, pts: int, mode: int, place: int, V: int, out: Tensor,
                ld_out: int, col_out: int, run: int = 1):

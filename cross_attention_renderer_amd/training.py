@@ -146,7 +146,8 @@ class _RenderTrain(torch.autograd.Function):
         if mode == "concat2":
             grid_in = torch.empty(n, R, P, V, 2, **f32)
             ld1 = _round_up(C + 3, 32)
-            x1 = torch.zeros(S * V, ld1, **f32)
+            x1 = torch.empty(S * V, ld1, **f32)                   # columns [0, C + 3) are written below; only the row padding is zeroed
+            x1[:, C + 3:].zero_()
             _check(lib.car_sample_setup(_ptr(poses), _ptr(rays), _ptr(steps), b, V, R, P, H, W, nos, _ptr(pixel_val), _ptr(pt), _ptr(g), _ptr(grid_in),
                                         _ptr(x1), ld1, C, None, st), "car_sample_setup")
             # a7 / a10: the two gathers, literal
@@ -275,7 +276,14 @@ class _RenderTrain(torch.autograd.Function):
             raise RuntimeError(f"render_train: parameters were modified in place between forward and backward ({stale[:3]} ...): the saved "
                                "activations no longer belong to them")
         with torch.cuda.device(dev):
-            grads: Dict[str, Tensor] = {k: torch.zeros_like(v, dtype=torch.float32) for k, v in par.items()}
+            # one zero fill for all parameter gradients (views of a flat buffer, 16-byte aligned), not one per tensor
+            sizes = {k: v.numel() for k, v in par.items()}
+            flat = torch.zeros(sum(_round_up(n, 4) for n in sizes.values()), **f32)
+            grads: Dict[str, Tensor] = {}
+            at = 0
+            for k, v in par.items():
+                grads[k] = flat[at:at + sizes[k]].view(v.shape)
+                at += _round_up(sizes[k], 4)
 
             def W(name):
                 return par[name + ".weight"]
@@ -286,13 +294,14 @@ class _RenderTrain(torch.autograd.Function):
                 K = Kfull if K is None else K
                 ops.wgrad(dy, ldy, x, ldx, M, N, K, w.view(N, Kfull)[:, col0:], Kfull, grads[name + ".bias"] if bias else None, relu_x)
 
-            def dx(name, dy, ldy, out, ldo, M, flags=0, wt=None, cols=None):
+            def dx(name, dy, ldy, out, ldo, M, flags=0, wt=None, cols=None, relu=None):
                 # cols: only the first `cols` input columns get a gradient (the rest — point coordinates — never need one): the transposed
                 # layer then has a multiple of 32 outputs and runs on the split-fp16 path (engine.linear)
+                # relu = (act, lda): the layer's input was relu(act) — the gradient is zeroed where act <= 0 as it is stored
                 w = W(name) if wt is None else wt
                 if cols is not None:
                     w, name = w.reshape(w.shape[0], -1)[:, :cols], f"{name}[:, :{cols}]"
-                eng.linear(dy, ldy, ops.transposed(name, w), out, ldo, M, flags)
+                eng.linear(dy, ldy, ops.transposed(name, w), out, ldo, M, flags, mask=relu)
 
             # ---- a18 / a17: white background, decoder
             d_rgb = torch.zeros(b, R, 3, **f32) if d_rgb is None else d_rgb.detach().reshape(b, R, 3).float().contiguous()
@@ -300,8 +309,7 @@ class _RenderTrain(torch.autograd.Function):
             ops.scale_rows(d_out3, 4, d_rgb, 3, sv["valid"], 1, 1.0, bR, 3)
             wgrad("phi.lin_out", d_out3, 4, sv["x3"], hid, bR, relu_x=True)
             d_x = torch.empty(bR, hid, **f32)
-            dx("phi.lin_out", d_out3, 4, d_x, hid, bR)
-            ops.relu_mask(d_x, hid, sv["x3"], hid, bR, hid)
+            dx("phi.lin_out", d_out3, 4, d_x, hid, bR, relu=(sv["x3"], hid))
             d_zrep = torch.zeros(bR, V * Dl, **f32)
             d_net = torch.empty(bR, hid, **f32)
             tmp = torch.empty(bR, hid, **f32)
@@ -309,11 +317,9 @@ class _RenderTrain(torch.autograd.Function):
                 fc0, fc1, lz = f"phi.blocks.{i}.fc_0", f"phi.blocks.{i}.fc_1", f"phi.lin_z.{i}"
                 xa, net = sv["xas"][i], sv["nets"][i]
                 wgrad(fc1, d_x, hid, net, hid, bR, relu_x=True)
-                dx(fc1, d_x, hid, d_net, hid, bR)
-                ops.relu_mask(d_net, hid, net, hid, bR, hid)
+                dx(fc1, d_x, hid, d_net, hid, bR, relu=(net, hid))
                 wgrad(fc0, d_net, hid, xa, hid, bR, relu_x=True)
-                dx(fc0, d_net, hid, tmp, hid, bR)
-                ops.relu_mask(tmp, hid, xa, hid, bR, hid)
+                dx(fc0, d_net, hid, tmp, hid, bR, relu=(xa, hid))
                 ops.add(d_x, hid, d_x, hid, 1.0, tmp, hid, 1.0, bR, hid)                             # d xa = d x + (d net Wfc0) [xa > 0]
                 wgrad(lz, d_x, hid, sv["zrep"], V * Dl, bR)
                 dx(lz, d_x, hid, d_zrep, V * Dl, bR, ACCUM)
@@ -344,8 +350,7 @@ class _RenderTrain(torch.autograd.Function):
                 ops.scale_rows(d_q, 128, sv["key2"], 128, dlogit, 1, 1.0 / 16.0, S, 128)
                 wgrad("query_repeat_embed_2", d_key, 128, sv["k1r"], 128, S)
                 d_k1r = torch.empty(S, 128, **f32)
-                dx("query_repeat_embed_2", d_key, 128, d_k1r, 128, S)
-                ops.relu_mask(d_k1r, 128, sv["k1r"], 128, S, 128)
+                dx("query_repeat_embed_2", d_key, 128, d_k1r, 128, S, relu=(sv["k1r"], 128))
                 wr = W("query_repeat_embed").reshape(128, -1)
                 wgrad("query_repeat_embed", d_k1r, 128, sv["g"], 16, S, col0=128, K=16)              # local_coords half + bias
                 d_uh = torch.empty(bR, 128, **f32)
@@ -367,13 +372,11 @@ class _RenderTrain(torch.autograd.Function):
             # ---- a12, a13
             wgrad("key_map_2", d_key, 128, sv["k1"], 128, S)
             d_k1 = torch.empty(S, 128, **f32)
-            dx("key_map_2", d_key, 128, d_k1, 128, S)
-            ops.relu_mask(d_k1, 128, sv["k1"], 128, S, 128)
+            dx("key_map_2", d_key, 128, d_k1, 128, S, relu=(sv["k1"], 128))
             wgrad("key_map", d_k1, 128, sv["e"], Ce, S)
             dx("key_map", d_k1, 128, d_e, Ce, S, ACCUM)
             wgrad("query_embed_2", d_q, 128, sv["q1"], 128, S)
-            dx("query_embed_2", d_q, 128, d_k1, 128, S)                                               # d q1 (buffer reused)
-            ops.relu_mask(d_k1, 128, sv["q1"], 128, S, 128)
+            dx("query_embed_2", d_q, 128, d_k1, 128, S, relu=(sv["q1"], 128))                        # d q1 (buffer reused)
             wgrad("query_embed", d_k1, 128, sv["g"], 16, S)
             dz = [None] * ctx.n_levels
             need = list(ctx.needs_input_grad[3:3 + ctx.n_levels])
@@ -383,8 +386,7 @@ class _RenderTrain(torch.autograd.Function):
                 # ---- a11
                 wgrad("query_encode_latent_2", d_e, C // 2, sv["h1"], C, S * V)
                 d_h1 = torch.empty(S * V, C, **f32)
-                dx("query_encode_latent_2", d_e, C // 2, d_h1, C, S * V)
-                ops.relu_mask(d_h1, C, sv["h1"], C, S * V, C)
+                dx("query_encode_latent_2", d_e, C // 2, d_h1, C, S * V, relu=(sv["h1"], C))
                 wgrad("query_encode_latent", d_h1, C, sv["x1"], ld1, S * V)
                 if ctx.need_dz:                               # the pyramid asked for a gradient (z from get_z under autograd, or a leaf)
                     d_x1 = torch.empty(S * V, ld1, **f32)
@@ -395,8 +397,7 @@ class _RenderTrain(torch.autograd.Function):
                 d_enc = d_e.view(S, C // 2, 3).permute(0, 2, 1).contiguous().view(S * 3, C // 2)
                 wgrad("query_encode_latent_2", d_enc, C // 2, sv["h1"], C, S * 3)
                 d_h1 = torch.empty(S * 3, C, **f32)
-                dx("query_encode_latent_2", d_enc, C // 2, d_h1, C, S * 3)
-                ops.relu_mask(d_h1, C, sv["h1"], C, S * 3, C)
+                dx("query_encode_latent_2", d_enc, C // 2, d_h1, C, S * 3, relu=(sv["h1"], C))
                 wgrad("query_encode_latent", d_h1, C, sv["x1"], ld1, S * 3)
                 if ctx.need_dz:
                     d_x3 = torch.empty(S * 3, ld1, **f32)

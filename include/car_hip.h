@@ -215,6 +215,12 @@ size_t car_linear_x3_packed_floats(int K, int N);
 int car_linear_x3_pack(const float* W, int ldw, int K, int N, float* packed, void* stream);
 int car_linear_x3(const float* X, int ldx, const float* packed, const float* bias, int K, int N, float* Y, int ldy, long M, int flags,
                   void* stream);
+/* car_linear_x3 with car_relu_mask (below) applied while the result is stored: Y[m][n] = act[m][n] > 0 ? (X W^T + bias (+ Y))[m][n] : 0.
+ * The backward's data gradient dX = dY W of a layer whose input went through a ReLU (what torch autograd does for F.relu in front of the
+ * convolutions of models.py:333-341, 487-491, 529) without a second pass over dX and the activation; bit-identical to the two calls.
+ * act [M, N] with row stride lda (a multiple of 4, >= N), 16-byte aligned. */
+int car_linear_x3_masked(const float* X, int ldx, const float* packed, const float* bias, int K, int N, float* Y, int ldy, long M, int flags,
+                         const float* act, int lda, void* stream);
 
 /* ---- a12 + a13 + the logits of a14 for the stage route's variants (n_view 1 / 3, no_latent_concat): key = key_map_2(relu(key_map(e))),
  * qry = query_embed_2(relu(query_embed(g))), logit = <key, qry> / 16 (models.py:487-491, 529, 533) in ONE kernel — the gather-free instance of

@@ -128,6 +128,37 @@ def test_split_fp16_linear_matches_torch(M, K, N, flags):
     assert lib.car_linear_x3(_ptr(Xd), ldx, _ptr(tiles), _ptr(bdev), K, N - 1, _ptr(Yd), ldy, M, 0, st) != 0
 
 
+@pytest.mark.parametrize("M,K,N,flags", [(4100, 288, 576, 0), (1000, 128, 128, 4), (333, 576, 64, 0), (777, 64, 32, 2)])
+def test_split_fp16_linear_with_the_relu_mask_in_its_store(M, K, N, flags):
+    """car_linear_x3_masked = car_linear_x3 followed by car_relu_mask, bit for bit (the backward's data gradient of a layer behind a ReLU),
+    for every tile count of the kernel, with ACCUM and RELU_OUT, a strided activation, and -0.0 / NaN activations (not > 0: zeroed)."""
+    from cross_attention_renderer_amd.engine import PackedLinear
+    lib = _lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + K + N)
+    ldx, ldy, lda = (K + 3) // 4 * 4, N + 4, N + 8
+    X = torch.randn(M, ldx, generator=g).to(dev)
+    act = torch.randn(M, lda, generator=g)
+    act[::7, ::3] = -0.0
+    act[3::11, 1::5] = float("nan")
+    act = act.to(dev)
+    Y0 = torch.randn(M, ldy, generator=g).to(dev)
+    layer = PackedLinear(torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), dev)
+    tiles, bdev = layer.x3
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    want, got = Y0.clone(), Y0.clone()
+    assert lib.car_linear_x3(_ptr(X), ldx, _ptr(tiles), _ptr(bdev), K, N, _ptr(want), ldy, M, flags, st) == 0, lib.car_last_error()
+    assert lib.car_relu_mask(_ptr(want), ldy, _ptr(act), lda, M, N, st) == 0
+    assert lib.car_linear_x3_masked(_ptr(X), ldx, _ptr(tiles), _ptr(bdev), K, N, _ptr(got), ldy, M, flags, _ptr(act), lda, st) == 0, lib.car_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert (got[:, :N] == 0).float().mean().item() > 0.4                                   # the mask did something
+    # refused: no activation, a row stride that does not hold a row or is not a multiple of 4
+    assert lib.car_linear_x3_masked(_ptr(X), ldx, _ptr(tiles), _ptr(bdev), K, N, _ptr(got), ldy, M, flags, None, lda, st) != 0
+    assert lib.car_linear_x3_masked(_ptr(X), ldx, _ptr(tiles), _ptr(bdev), K, N, _ptr(got), ldy, M, flags, _ptr(act), N - 4, st) != 0
+    assert lib.car_linear_x3_masked(_ptr(X), ldx, _ptr(tiles), _ptr(bdev), K, N, _ptr(got), ldy, M, flags, _ptr(act), N + 2, st) != 0
+
+
 # ----------------------------------------------------------------------------------------------------------
 # stage kernels
 # ----------------------------------------------------------------------------------------------------------
