@@ -120,6 +120,8 @@ SIGNATURES = {
     "car_linear_wgrad": (c_int, [_P, c_int, _P, c_int, c_long, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "car_attend_backward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "car_gather_bilinear_backward": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, c_long, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "car_scatter_workspace_bytes": (c_size_t, [_P, _P, c_int, c_int, c_long, c_int]),
+    "car_gather_bilinear_backward_binned": (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_long, c_int, _P, c_int, c_int, _P, c_size_t, _P]),
     "car_relu_mask": (c_int, [_P, c_int, _P, c_int, c_long, c_int, _P]),
     "car_scale_rows": (c_int, [_P, c_int, _P, c_int, _P, c_long, c_float, c_long, c_int, c_int, _P]),
     "car_add": (c_int, [_P, c_int, _P, c_int, c_float, _P, c_int, c_float, c_long, c_int, _P]),

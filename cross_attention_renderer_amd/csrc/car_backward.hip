@@ -157,6 +157,9 @@ int launch_wgrad_tile(const float* dY, int ldy, const float* X, int ldx, long M,
     long want = 512 / ((long)gx * gy);                                 // ~2 workgroups per CU
     if (want < 1) want = 1;
     long slab = (M + want - 1) / want;
+    // a workgroup adds its whole tile to dW with atomics whatever its slab: over few rows (the per-ray layers: 2304 rows a step) slabs of one
+    // 16-row block made a launch 60 000 atomics per 16 rows — 72-141 us for a 0.8 GFLOP product; four blocks per workgroup at least
+    if (slab < 4 * kWtRows) slab = 4 * kWtRows;
     slab = (slab + kWtRows - 1) / kWtRows * kWtRows;
     const unsigned gz = car_div_up(M, slab);
     CAR_REQUIRE(gz <= 65535, "car_linear_wgrad: too many row slabs");
@@ -519,6 +522,21 @@ __global__ void relu_mask_kernel(float* __restrict__ grad, int ldg, const float*
 // out[m][:] (+)= scale * s[m / group] * x[m][:]
 __global__ void scale_rows_kernel(float* __restrict__ out, int ldo, const float* __restrict__ x, int ldx, const float* __restrict__ s, long group,
                                   float scale, long M, int N, int accumulate) {
+    if (((N | ldo | ldx) & 3) == 0 && (((uintptr_t)out | (uintptr_t)x) & 15) == 0) {       // whole float4s (the 128-wide key / query gradients)
+        const int nq = N / 4;
+        const long total4 = M * nq;
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (long)gridDim.x * blockDim.x) {
+            const long m = idx / nq;
+            const int n = 4 * (int)(idx % nq);
+            const float f = scale * s[m / group];
+            const float4 v = *reinterpret_cast<const float4*>(x + m * ldx + n);
+            float4* o = reinterpret_cast<float4*>(out + m * ldo + n);
+            float4 r = make_float4(f * v.x, f * v.y, f * v.z, f * v.w);
+            if (accumulate) { const float4 p = *o; r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; }
+            *o = r;
+        }
+        return;
+    }
     const long total = M * N;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long m = idx / N;

@@ -56,12 +56,17 @@ __global__ void __launch_bounds__(kThreads) linear16_kernel(const LinArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s = lane & 15, q4 = lane >> 4;
-    // the column groups of a block of rows are neighbours in launch order: they read the same rows of X at about the same time (L2)
+    // the column groups of a block of rows read the same rows of X: they sit on ONE XCD (workgroup b runs on XCD b % 8) in consecutive
+    // slots, so the second reader finds the rows in that XCD's L2 — as neighbours in launch order (rounds 4-6) they were on different
+    // XCDs and a 576-wide layer fetched X twice from the fabric (HBM-bound at 1.3-1.5 ms per 589 824 x 576 x 576 layer)
     const int groups = a.tiles_total / NT;
-    const long row = (long)(blockIdx.x / groups) * kGroupRows + wave * kRows + s;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long rblock = (long)(slot / groups) * 8 + xcd;
+    if (rblock * kGroupRows >= a.M) return;                            // the grid is padded to whole rounds of eight row blocks
+    const long row = rblock * kGroupRows + wave * kRows + s;
     const long lrow = row < a.M ? row : a.M - 1;
     const float* xrow = a.X + lrow * a.ldx;
-    const int tile0 = (blockIdx.x % groups) * NT;
+    const int tile0 = (slot % groups) * NT;
     const bool relu_in = (a.flags & CAR_LIN_RELU_IN) != 0;
     const int K = a.K;
 
@@ -340,7 +345,7 @@ int launch16(const LinArgs& a, int groups, hipStream_t st) {
         if (dev >= 0 && dev < 64) reserved[dev] = true;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((linear16_kernel<NT, GATHER, KQ>), dim3((unsigned)(car_div_up(a.M, kGroupRows) * groups)), dim3(kThreads), lds_bytes, st, a);
+    hipLaunchKernelGGL((linear16_kernel<NT, GATHER, KQ>), dim3((unsigned)(car_div_up(car_div_up(a.M, kGroupRows), 8) * 8 * groups)), dim3(kThreads), lds_bytes, st, a);
     CAR_CHECK_LAUNCH("car_linear_x3");
     return CAR_OK;
 }

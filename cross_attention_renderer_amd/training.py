@@ -86,6 +86,25 @@ class _Ops:
         _check(self.lib.car_gather_bilinear_backward(ptrs, cs, hs, ws, L, dmaps[0].shape[0], _ptr(grid), pts, mode, place, V, _ptr(dout), ld_out,
                                                      col_out, _stream()), "car_gather_bilinear_backward")
 
+    def gather_backward_binned(self, maps: List[Tensor], gathers, pts: int, V: int, dout: Tensor, ld_out: int, col_out: int) -> List[Tensor]:
+        """The gradient of the gathered rows `dout` with respect to `maps` for all `gathers` [(grid, padding mode, placement)] at once, every
+        texel written exactly once (csrc/car_scatter.hip: taps binned by texel, no floating-point atomics, no zero fill)."""
+        L, G = len(maps), len(gathers)
+        dmaps = [torch.empty_like(m) for m in maps]
+        ptrs = (ctypes.c_void_p * L)(*[m.data_ptr() for m in dmaps])
+        cs = (ctypes.c_int * L)(*[m.shape[3] for m in maps])
+        hs = (ctypes.c_int * L)(*[m.shape[1] for m in maps])
+        ws = (ctypes.c_int * L)(*[m.shape[2] for m in maps])
+        grids = (ctypes.c_void_p * G)(*[g[0].data_ptr() for g in gathers])
+        modes = (ctypes.c_int * G)(*[g[1] for g in gathers])
+        places = (ctypes.c_int * G)(*[g[2] for g in gathers])
+        n_maps = maps[0].shape[0]
+        nbytes = self.lib.car_scatter_workspace_bytes(hs, ws, L, n_maps, pts, G)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=dout.device)
+        _check(self.lib.car_gather_bilinear_backward_binned(ptrs, cs, hs, ws, L, n_maps, grids, modes, places, G, pts, V, _ptr(dout), ld_out, col_out,
+                                                            _ptr(work), nbytes, _stream()), "car_gather_bilinear_backward_binned")
+        return dmaps
+
 
 # parameters the path reads, in the order their gradients are returned
 def _mode(m) -> str:
@@ -423,10 +442,14 @@ class _RenderTrain(torch.autograd.Function):
             elif ctx.need_dz:
                 d_gather = (d_e, Ce, [(sv["pixel_val"], 0, PLACE_PLAIN)])
             if d_gather is not None:
-                # ---- a7 / a10: scatter into the pyramid
-                dmaps = [torch.zeros_like(t) for t in ctx.maps]
-                for grid, pad_mode, place in d_gather[2]:
-                    ops.gather_backward(dmaps, grid, R * P, pad_mode, place, V, d_gather[0], d_gather[1], 0)
+                # ---- a7 / a10: the gathered rows' gradient into the pyramid — taps binned by texel, every texel written once
+                # (engine.scatter_atomics = True: the fp32-atomic scatter, one launch per gather into zeroed maps; A/B and tests)
+                if getattr(eng, "scatter_atomics", False):
+                    dmaps = [torch.zeros_like(t) for t in ctx.maps]
+                    for grid, pad_mode, place in d_gather[2]:
+                        ops.gather_backward(dmaps, grid, R * P, pad_mode, place, V, d_gather[0], d_gather[1], 0)
+                else:
+                    dmaps = ops.gather_backward_binned(ctx.maps, d_gather[2], R * P, V, d_gather[0], d_gather[1], 0)
                 dz = [(t.permute(0, 3, 1, 2) if cl else t.permute(0, 3, 1, 2).contiguous().to(dt)) if nd else None
                       for t, dt, nd, cl in zip(dmaps, ctx.z_dtypes, need, ctx.z_channel_last)]
         out = [None, None, None] + dz + [grads[k].view_as(par[k]).to(par[k].dtype) for k in _param_names(m)]

@@ -326,6 +326,11 @@ int car_finalize(const float* rays, const float* rgb_in, int ld_in, int b, int V
  *                     pt [b*V,R,P,3] and poses): gradient of depth_ray.  dval [b*V,R,P,D] (+)= w_s dz, dlogit [b*V,R,P].
  *  car_gather_bilinear_backward   grid_sample backward w.r.t. the maps: dmaps[l] [n_maps,Hl,Wl,Cl] += tap weight x the gradient of
  *                     the gathered row (same arguments and row placement as car_gather_bilinear; fp32 atomics).
+ *  car_gather_bilinear_backward_binned   the same gradient without floating-point atomics (csrc/car_scatter.hip): the taps of n_gathers
+ *                     gathers (grids[j] [n_maps, pts, 2], padding modes[j], placements[j]; all reading dout) are binned by texel — a counting
+ *                     sort on (row, weight) records in `workspace` (car_scatter_workspace_bytes) — and every texel of every level is then
+ *                     WRITTEN once (dmaps = the gradient, not +=; no zero fill beforehand).  The sum runs over the same terms as the atomic
+ *                     form's, in the order the records landed.
  *  car_relu_mask      grad[m][n] = act[m][n] > 0 ? grad[m][n] : 0
  *  car_scale_rows     out[m][:] (+)= scale * s[m / group] * x[m][:]        (logit gradients to keys / queries, valid mask)
  *  car_add            out = alpha a + beta b (b may be NULL)
@@ -338,6 +343,11 @@ int car_attend_backward(const float* w, const float* val, int D, int b, int V, i
 int car_gather_bilinear_backward(float* const* dmaps, const int* level_c, const int* level_h, const int* level_w, int n_levels,
                                  int n_maps, const float* grid, long pts, int mode, int place, int V, const float* dout, int ld_out,
                                  int col_out, void* stream);
+size_t car_scatter_workspace_bytes(const int* level_h, const int* level_w, int n_levels, int n_maps, long pts, int n_gathers);
+int car_gather_bilinear_backward_binned(float* const* dmaps, const int* level_c, const int* level_h, const int* level_w, int n_levels,
+                                        int n_maps, const float* const* grids, const int* modes, const int* places, int n_gathers,
+                                        long pts, int V, const float* dout, int ld_out, int col_out, void* workspace,
+                                        size_t workspace_bytes, void* stream);
 int car_relu_mask(float* grad, int ldg, const float* act, int lda, long M, int N, void* stream);
 int car_scale_rows(float* out, int ldo, const float* x, int ldx, const float* s, long group, float scale, long M, int N, int accumulate,
                    void* stream);

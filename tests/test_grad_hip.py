@@ -144,6 +144,59 @@ def test_gather_backward_is_the_adjoint_of_the_gather():
             assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs)), (mode, place, lhs, rhs)
 
 
+def test_binned_scatter_equals_the_atomic_scatter():
+    """car_gather_bilinear_backward_binned (taps binned by texel, every texel written once) against car_gather_bilinear_backward (fp32
+    atomics into zeroed maps), launch for launch summed: one and two gathers with different grids, padding modes and placements reading
+    one dout; coordinates inside, on the edge of and far outside the maps, points piled on one texel; channel counts of 1, 3 and 64 float4s
+    per texel; maps the binned form must overwrite (NaN before the call)."""
+    from cross_attention_renderer_amd.engine import PLACE_OTHER2, PLACE_OWN, PLACE_PLAIN
+    lib, dev = _lib(), torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    for (n_maps, pts, V, shapes) in ((4, 300, 2, ((5, 8), (9, 12), (17, 4))), (2, 5000, 2, ((32, 256), (16, 256), (64, 64))), (3, 77, 1, ((7, 4),))):
+        maps = [torch.randn(n_maps, h, h + 1, cch, generator=g).to(dev) for h, cch in shapes]
+        C = sum(t.shape[3] for t in maps)
+        L = len(maps)
+        cs = (ctypes.c_int * L)(*[t.shape[3] for t in maps])
+        hs = (ctypes.c_int * L)(*[t.shape[1] for t in maps])
+        ws = (ctypes.c_int * L)(*[t.shape[2] for t in maps])
+        grids = []
+        for k in range(2):
+            grid = (torch.rand(n_maps, pts, 2, generator=g) * 3 - 1.5)
+            grid[0, 0] = torch.tensor([1e10, -1e10])
+            grid[-1, 1] = torch.tensor([-1.0, 1.0])
+            grid[0, 10:60] = torch.tensor([0.123, -0.4])                          # fifty points on one texel
+            grids.append(grid.to(dev))
+        combos = [[(grids[0], 0, PLACE_PLAIN)], [(grids[1], 1, PLACE_PLAIN)]]
+        if V == 2:
+            combos += [[(grids[0], 0, PLACE_OWN), (grids[1], 1, PLACE_OTHER2)], [(grids[1], 1, PLACE_OWN)]]
+        for gathers in combos:
+            rows = n_maps * pts * (1 if gathers[0][2] == PLACE_PLAIN else V)
+            ld = C + 8
+            dout = torch.randn(rows, ld, generator=g).to(dev)
+            want = [torch.zeros_like(t) for t in maps]
+            dptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in want])
+            for grid, mode, place in gathers:
+                assert lib.car_gather_bilinear_backward(dptrs, cs, hs, ws, L, n_maps, _ptr(grid), pts, mode, place, V, _ptr(dout), ld, 4, _stream()) == 0
+            got = [torch.full_like(t, float("nan")) for t in maps]
+            gptrs = (ctypes.c_void_p * L)(*[t.data_ptr() for t in got])
+            G = len(gathers)
+            gr = (ctypes.c_void_p * G)(*[x[0].data_ptr() for x in gathers])
+            mo = (ctypes.c_int * G)(*[x[1] for x in gathers])
+            pl = (ctypes.c_int * G)(*[x[2] for x in gathers])
+            nbytes = lib.car_scatter_workspace_bytes(hs, ws, L, n_maps, pts, G)
+            assert nbytes > 0
+            work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rc = lib.car_gather_bilinear_backward_binned(gptrs, cs, hs, ws, L, n_maps, gr, mo, pl, G, pts, V, _ptr(dout), ld, 4, _ptr(work), nbytes, _stream())
+            assert rc == 0, lib.car_last_error()
+            torch.cuda.synchronize()
+            for a, b_ in zip(got, want):
+                assert torch.isfinite(a).all()
+                assert (a - b_).abs().max().item() <= 2e-5 * max(1.0, b_.abs().max().item()), (n_maps, pts, len(gathers))
+            # a workspace one byte short is refused
+            assert lib.car_gather_bilinear_backward_binned(gptrs, cs, hs, ws, L, n_maps, gr, mo, pl, G, pts, V, _ptr(dout), ld, 4, _ptr(work), nbytes - 1,
+                                                           _stream()) != 0
+
+
 def test_a_gradient_step_lowers_the_image_loss_by_the_predicted_amount():
     """The reference's training step (training.py:92-136) with render_train in the place of model(model_input): L1 image loss on
     192 random rays of two synthetic scenes, backward through the HIP kernels, one plain gradient step on the renderer's parameters AND
