@@ -587,7 +587,9 @@ extern "C" int car_linear_wgrad(const float* dY, int ldy, const float* X, int ld
     CAR_REQUIRE((((uintptr_t)dY | (uintptr_t)X) & 15) == 0, "car_linear_wgrad: dY and X must be 16-byte aligned (a column-offset view? copy it first)");
     // wide layers over many rows: the bf16 x 3 kernel (CAR_WGRAD_FP32 in flags keeps them on the fp32 pipe: A/B and tests); wide layers
     // otherwise: the fp32 pipe's 192 x 320 workgroup tile; everything else its 128 x 128 one
-    if ((N > 128 || K + (db ? 1 : 0) > 128) && M >= 4096 && !(flags & CAR_WGRAD_FP32))
+    // (round 6: also the 128 x 16 layers over every sample (query_embed) — a sparsely filled 192 x 320 tile on the bf16 pipe still beats the fp32
+    // pipe's 128 x 128 tile, 100 against 203 us over 294 912 rows)
+    if ((N > 128 || K + (db ? 1 : 0) > 128 || (long)N * K >= 32 * 32) && M >= 2048 && !(flags & CAR_WGRAD_FP32))
         return launch_wgrad16(dY, ldy, X, ldx, M, N, K, flags, dW, lddw, db, stream);
     if (N > 128 || K + (db ? 1 : 0) > 128) return launch_wgrad_tile<3, 5>(dY, ldy, X, ldx, M, N, K, flags, dW, lddw, db, stream);
     return launch_wgrad_tile<2, 2>(dY, ldy, X, ldx, M, N, K, flags, dW, lddw, db, stream);

@@ -317,10 +317,11 @@ int car_finalize(const float* rays, const float* rgb_in, int ld_in, int b, int V
  * linear layer, dX = dY W, is car_linear with the transposed weight packed by car_linear_pack.
  *
  *  car_linear_wgrad   dW[N, K] += dY[M, N]^T X[M, K]  and, with db != NULL, db[N] += column sums of dY (fp32 atomics into dW / db:
- *                     zero them first).  Wide layers (N or K above 128) over >= 4096 rows run on the bf16 matrix pipe as three
- *                     products of bf16 hi / lo halves of both operands (fp32 accumulate; bf16 keeps fp32's exponent, so no scale
- *                     is involved; error ~2^-17 per term, rounding-like); the rest — and everything with CAR_WGRAD_FP32 — on the
- *                     fp32 matrix pipe.  flags: CAR_LIN_RELU_IN = X is used as relu(X).
+ *                     zero them first).  Layers over >= 2048 rows with N K >= 1024 run on the bf16 matrix pipe as three products of
+ *                     bf16 hi / lo halves of both operands (fp32 accumulate; bf16 keeps fp32's exponent, so no scale is involved;
+ *                     error ~2^-17 per term, rounding-like); the rest — and everything with CAR_WGRAD_FP32 — on the fp32 matrix
+ *                     pipe.  flags: CAR_LIN_RELU_IN = X is used as relu(X).  Columns of dY / X beyond N / K (row padding) may hold
+ *                     anything, NaN included: they only meet entries of dW that are never written.
  *  car_attend_backward   one attention round (models.py:532-541 / 555-565, depth read-out 577-590).  w [b*V,R,P] the round's
  *                     softmax weights, val [b*V,R,P,D]; dz [b,R,ld_dz]: gradient of sum_s w_s val_s; ddepth [b,R] (optional, with
  *                     pt [b*V,R,P,3] and poses): gradient of depth_ray.  dval [b*V,R,P,D] (+)= w_s dz, dlogit [b*V,R,P].
