@@ -13,7 +13,7 @@
 // pipe); a layer's weights carry a power of two chosen at pack time from its largest weight, its input vector one chosen per ray
 // from the vector's largest magnitude, both undone exactly on the accumulators — which therefore also take the residual sums
 // (x += ...) in true fp32.  A workgroup = 4 waves = 128 rays at one wave per SIMD (z, x and the residual branch need ~300
-// registers); the weight chunks of all layers (K = 32 each) stream L2 -> LDS by LDS-DMA, double buffered across layer boundaries, in
+// registers); the weight chunks of all layers (K = 32 each) stream L2 -> LDS by LDS-DMA through a ring of three buffers (two chunks ahead of the products, across layer boundaries), in
 // the order a host-built table lists them.
 // lin_z_i sees [z, z] (the per-view replication of models.py:565, 605-606): its two 288-column halves are added once at pack time.
 #include "car_common.h"
@@ -51,15 +51,17 @@ struct ChainArgs {
     float zscale;                                  // tail: V
 };
 
+constexpr int kRing = 3;                           // weight buffers: the chunk being multiplied and the two behind it
 struct Stream {
     const ChainArgs& a;
     float* lds;
     int g;
+    __device__ __forceinline__ float* buffer(int gi) const { return lds + (gi % kRing) * kBufFloats; }
     __device__ __forceinline__ void issue(int gi, int tid, int wave) const {
         if (gi >= a.n_chunks) return;
         const Chunk c = a.chunk[gi];
         const float* src = a.arena + c.off;
-        float* dst = lds + (gi & 1) * kBufFloats;
+        float* dst = buffer(gi);
         for (int t = 0; t < c.nt; ++t) {
             const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(dst + 4 * (t * 256 + wave * 64)));
             const float* gsrc = src + 4 * (t * 256 + tid);
@@ -68,10 +70,22 @@ struct Stream {
                          : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
         }
     }
-    __device__ __forceinline__ void sync() const {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // chunk gi has landed, in every wave's view: this wave's pieces of it are older than the one chunk issued behind it (gi + 1: a chunk is
+    // nt loads per thread, nt in {1, 4, 9}), which may stay in flight.  Loads the compiler issued in between (a layer's input rows) only
+    // make the count stricter; its own waits never know of these loads and are stricter for that
+    __device__ __forceinline__ void landed(int gi) const {
+        const int n = __builtin_amdgcn_readfirstlane(gi + 1 < a.n_chunks ? a.chunk[gi + 1].nt : 0);
+        switch (n) {
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
         __syncthreads();
     }
+    // end of chunk g's products: chunk g + 1 must be in LDS (chunk g + 2, issued at the start of this step, may still fly), and every wave
+    // is done with chunk g's buffer — which chunk g + 3 overwrites, issued at the start of the next step
+    __device__ __forceinline__ void sync() const { landed(g + 1); }
 };
 
 #include "car_split.h"
@@ -88,16 +102,26 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[NT], const float* wl, co
     half8 bhi[2], blo[2];
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) split8(x8[kg], p, bhi[kg], blo[kg]);
+    // one wave per SIMD: nobody else hides an LDS round trip, so the A operands of step (t, kg) + 1 are read BEFORE the three products of
+    // step (t, kg) are issued (the compiler, left alone, reads them into the same two registers right in front of their first use and
+    // waits: ~100 cycles exposed per 96 cycles of MFMA — the chains ran at a third of their matrix time)
+    auto read = [&](int i, half8& ah, half8& al) {
+        const int t = i >> 1, kg = i & 1;
+        ah = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wl + t * kTileFloats + ((kg * 2 + 0) * 64) * 4));
+        al = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wl + t * kTileFloats + ((kg * 2 + 1) * 64) * 4));
+    };
+    half8 ah[2], al[2];
+    read(0, ah[0], al[0]);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-            const half8 ah = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wl + t * kTileFloats + ((kg * 2 + 0) * 64) * 4));
-            const half8 al = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wl + t * kTileFloats + ((kg * 2 + 1) * 64) * 4));
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[kg], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[kg], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[kg], acc[t], 0, 0, 0);
-        }
+    for (int i = 0; i < 2 * NT; ++i) {
+        const int t = i >> 1, kg = i & 1, cur = i & 1;
+        if (i + 1 < 2 * NT) read(i + 1, ah[cur ^ 1], al[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bhi[kg], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], blo[kg], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bhi[kg], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // acc += W x for a layer whose input rows come from global memory (standard K order: K step ks takes k = 16 ks + 8 h + e).  The row's
@@ -137,9 +161,9 @@ __device__ __forceinline__ void layer_global(f32x16 (&acc)[NT], const float* xro
     float cur[2][8], nxt[2][8];
     load(0, cur);
     for (int c = 0; c < chunks; ++c) {
-        st.issue(st.g + 1, tid, wave);
+        st.issue(st.g + 2, tid, wave);
         if (c + 1 < chunks) load(c + 1, nxt);
-        mma_chunk<NT>(acc, st.lds + (st.g & 1) * kBufFloats + 4 * lane, cur, p);
+        mma_chunk<NT>(acc, st.buffer(st.g) + 4 * lane, cur, p);
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
@@ -164,13 +188,13 @@ __device__ __forceinline__ void layer_chained(f32x16 (&acc)[NT], const f32x16 (&
     scale<NT>(acc, p / dW);
 #pragma unroll
     for (int T = 0; T < NSRC; ++T) {
-        st.issue(st.g + 1, tid, wave);
+        st.issue(st.g + 2, tid, wave);
         float x8[2][8];
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
             for (int e = 0; e < 8; ++e) x8[kg][e] = RELU ? fmaxf(src[T][8 * kg + e], 0.0f) : src[T][8 * kg + e];
-        mma_chunk<NT>(acc, st.lds + (st.g & 1) * kBufFloats + 4 * lane, x8, p);
+        mma_chunk<NT>(acc, st.buffer(st.g) + 4 * lane, x8, p);
         st.sync();
         ++st.g;
     }
@@ -211,7 +235,8 @@ __global__ void __launch_bounds__(256, 1) ray_mid_kernel(const ChainArgs a) {
     auto dW = [&](int i) { return a.scale[kMaxLayers + a.layer[i]]; };
     Stream st{a, lds, 0};
     st.issue(0, tid, wave);
-    st.sync();
+    st.issue(1, tid, wave);
+    st.landed(0);
     f32x16 z1[9];
     zero<9>(z1);
     add_bias<9>(z1, a.bias, h);
@@ -237,7 +262,8 @@ __global__ void __launch_bounds__(256, 1) ray_tail_kernel(const ChainArgs a) {
     auto dW = [&](int i) { return a.scale[kMaxLayers + a.layer[i]]; };
     Stream st{a, lds, 0};
     st.issue(0, tid, wave);
-    st.sync();
+    st.issue(1, tid, wave);
+    st.landed(0);
     // z = (Wv ebar2 + bv) + V z1   (models.py:561-565: "+ z_local" in every view, then the sum over the views)
     f32x16 z[9];
 #pragma unroll
@@ -350,7 +376,7 @@ int launch_chain(bool tail, const float* arena, const unsigned* offs, const int*
     for (int i = 0; i < n_chunks; ++i) { a.chunk[i].off = offs[i]; a.chunk[i].nt = nts[i]; }
     a.x0 = x0; a.ld0 = ld0; a.x1 = x1; a.ld1 = ld1; a.z1_in = z1_in; a.out0 = out0; a.out1 = out1; a.rays = (const CarRay*)rays;
     a.M = M; a.V = V; a.R = R; a.zscale = zscale;
-    const size_t lds_bytes = 2 * kBufFloats * sizeof(float);
+    const size_t lds_bytes = (size_t)kRing * kBufFloats * sizeof(float);
     auto kern = tail ? ray_tail_kernel : ray_mid_kernel;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) { car_set_error("car_ray_chain: cannot reserve LDS: %s", hipGetErrorString(e)); return CAR_E_LAUNCH; }
