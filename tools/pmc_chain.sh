@@ -14,9 +14,9 @@ import sqlite3, glob
 for d in sorted(glob.glob('gpurun_out/pmc_chain/*/p_results.db')):
     c = sqlite3.connect(d).cursor()
     print(d)
-    for r in c.execute("select substr(kernel_name, 1, 44), counter_name, count(*), avg(value) from counters_collection where kernel_name like '%ray_tail%' or kernel_name like '%ray_mid%' group by 1, 2"):
+    for r in c.execute("select substr(kernel_name, 1, 44), counter_name, count(*), avg(value) from counters_collection where kernel_name like '%ray_tail%' or kernel_name like '%ray_mid%' or kernel_name like '%round2%' or kernel_name like '%attend%' group by 1, 2"):
         print("   %-46s %-28s n=%d avg=%.4g" % r)
-    for r in c.execute("select substr(name,1,44), count(*), avg(duration) from kernels where name like '%ray_tail%' or name like '%ray_mid%' group by 1"):
+    for r in c.execute("select substr(name,1,44), count(*), avg(duration) from kernels where name like '%ray_tail%' or name like '%ray_mid%' or name like '%round2%' or name like '%attend%' group by 1"):
         print("   %-46s n=%d avg %.1f us" % (r[0], r[1], r[2] / 1e3))
 PY
 find $OUT -name "*.db" -size +3M -delete
