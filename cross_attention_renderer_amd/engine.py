@@ -84,7 +84,7 @@ class RenderEngine:
         self._steps: Dict[tuple, Tensor] = {}
         self.linear_flags = 0          # tests may set NO_GLDS for A/B
         self.linear_x3 = True          # stage entries: wide layers on the split-fp16 path (car_linear_x3); False = all on the fp32 pipe
-        self.linear_x3_min_rows = 4096 # below this many rows a launch is latency bound either way
+        self.linear_x3_min_rows = 2048 # below this many rows a launch is latency bound either way (a training step has 2304 rays: 16.2 -> 15.8 ms)
         self.pose_records = None       # tests: (b*V, 96) CarPose records to use instead of the host pose algebra
         # "host": the reference's torch.inverse on the CPU wherever the cameras live (strict parity; cameras on the GPU cost one small
         # download per new pose); "device": car_pose_setup when the cameras are on the GPU (no host round trip, budgeted parity)
