@@ -66,6 +66,23 @@ def test_round6_entries_validate_their_arguments(lib):
     assert lib.car_attend_parts(None, None, 4, 576, 1, 2, 8, 8, None, None, 576, 1, None, None, None, None, None) == -1
 
 
+def test_round6_training_entries_validate_their_arguments(lib):
+    """The backward entries added in round 6 (second session): the binned scatter's workspace size without a GPU, codes on bad arguments."""
+    import ctypes
+    hs, ws = (ctypes.c_int * 3)(256, 128, 64), (ctypes.c_int * 3)(256, 128, 64)
+    texels = 256 * 256 + 128 * 128 + 64 * 64
+    n_maps, pts, gathers = 24, 12288, 2
+    n = n_maps * texels + 1
+    blocks = (n + 1023) // 1024
+    want = ((2 * n + blocks + 4) * 4 + 15) // 16 * 16 + gathers * n_maps * pts * 3 * 4 * 8       # counters | start | block sums, then 8-byte records
+    assert lib.car_scatter_workspace_bytes(hs, ws, 3, n_maps, pts, gathers) == want
+    assert lib.car_scatter_workspace_bytes(None, ws, 3, n_maps, pts, gathers) == 0 and lib.car_scatter_workspace_bytes(hs, ws, 5, n_maps, pts, gathers) == 0
+    assert lib.car_gather_bilinear_backward_binned(None, None, hs, ws, 3, n_maps, None, None, None, gathers, pts, 2, None, 608, 0, None, 0, None) == -1
+    assert b"null pointer" in lib.car_last_error()
+    assert lib.car_linear_x3_masked(None, 4, None, None, 4, 32, None, 32, 8, 0, None, 32, None) == -1
+    assert b"act" in lib.car_last_error()
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "cross_attention_renderer_amd")
     for dirpath, _, files in os.walk(pkg):
