@@ -39,12 +39,15 @@ constexpr size_t kLdsBytesG = (size_t)(kLdsBiasG + kBiasFloatsG) * sizeof(float)
 
 // acc = W1 x16 + b1 for the wave's 32 samples (K = 16, one v_mfma_f32_32x32x16_f16 step, fp16 hi / lo operand halves), times `up`:
 // lane (s, h) register 4 g' + r of tile t = channel 32 t + 8 g' + 4 h + r
+template <bool ZERO = false>
 __device__ __forceinline__ void first_layer(const half8& ghi, const half8& glo, const float* lw1, const float* lb1, float up, int lane, int h,
                                             f32x16 (&ug)[kNT]) {
 #pragma unroll
     for (int t = 0; t < kNT; ++t) {
+        // ZERO: the products alone, from a zero accumulator (the matrix instruction takes the constant: no 64 register writes, no 64 multiplies
+        // by `up`); the caller adds the bias after undoing the scale
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ug[t][r] = lb1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h] * up;
+        for (int r = 0; r < 16; ++r) ug[t][r] = ZERO ? 0.0f : lb1[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h] * up;
         const float* w1 = lw1 + t * 512 + 4 * lane;
         const half8 ah = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1));
         const half8 al = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(w1 + 256));
@@ -55,12 +58,13 @@ __device__ __forceinline__ void first_layer(const half8& ghi, const half8& glo, 
 }
 // acc = W2 x + b2 with x in the accumulator layout above (its registers are the B operands: K step (source tile c, group kg) takes
 // registers 8 kg .. 8 kg + 7 of x's tile c), times xp / down2
+template <bool ZERO = false>
 __device__ __forceinline__ void second_layer(const f32x16 (&x)[kNT], float xp, const float* lw2, const float* lb2, float up2, int lane, int h,
                                              f32x16 (&acc)[kNT]) {
 #pragma unroll
     for (int t = 0; t < kNT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = lb2[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h] * up2;
+        for (int r = 0; r < 16; ++r) acc[t][r] = ZERO ? 0.0f : lb2[32 * t + (r & 3) + 8 * (r >> 2) + 4 * h] * up2;
 #pragma unroll
     for (int c = 0; c < kChunks; ++c) {
         half8 bhi[2], blo[2];
@@ -72,16 +76,24 @@ __device__ __forceinline__ void second_layer(const f32x16 (&x)[kNT], float xp, c
             split8(x8, xp, bhi[kg], blo[kg]);
         }
         const float* wl = lw2 + c * kNT * kTile + 4 * lane;
+        // the A operands of step (t, kg) + 1 are read before the three products of step (t, kg) are issued (car_raychain.hip::mma_chunk)
+        auto read = [&](int i, half8& ah, half8& al) {
+            const int t = i >> 1, kg = i & 1;
+            ah = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wl + t * kTile + ((kg * 2 + 0) * 64) * 4));
+            al = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wl + t * kTile + ((kg * 2 + 1) * 64) * 4));
+        };
+        half8 ah[2], al[2];
+        read(0, ah[0], al[0]);
 #pragma unroll
-        for (int t = 0; t < kNT; ++t)
-#pragma unroll
-            for (int kg = 0; kg < 2; ++kg) {
-                const half8 ah = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wl + t * kTile + ((kg * 2 + 0) * 64) * 4));
-                const half8 al = __builtin_bit_cast(half8, *reinterpret_cast<const float4*>(wl + t * kTile + ((kg * 2 + 1) * 64) * 4));
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[kg], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[kg], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[kg], acc[t], 0, 0, 0);
-            }
+        for (int i = 0; i < 2 * kNT; ++i) {
+            const int t = i >> 1, kg = i & 1, cur = i & 1;
+            if (i + 1 < 2 * kNT) read(i + 1, ah[cur ^ 1], al[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bhi[kg], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], blo[kg], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bhi[kg], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -135,9 +147,10 @@ __global__ void __launch_bounds__(512) round2_kernel(const float* __restrict__ g
             pow2_scale(fmaxf(m, 1e-30f), gp, ginv);
             split8(gx, gp, ghi, glo);
         }
-        // ug = Wr1g g + br1; y = relu(ug + uh) in place
+        // ug = Wr1g g + br1; y = relu(ug + uh) in place.  G: the biases of all three layers are added AFTER the products, in true units (one
+        // fma each, where the product's scale is undone anyway), so the accumulators start from the matrix instruction's zero
         f32x16 ug[kNT];
-        first_layer(ghi, glo, lds + kLdsW1, lb, gp / down1, lane, h, ug);
+        first_layer<G>(ghi, glo, lds + kLdsW1, lb, gp / down1, lane, h, ug);
         const float undo1 = down1 * ginv;
         float xm = 0.0f;
 #pragma unroll
@@ -145,7 +158,11 @@ __global__ void __launch_bounds__(512) round2_kernel(const float* __restrict__ g
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const float4 u = *reinterpret_cast<const float4*>(uhrow + 32 * t + 8 * gq + 4 * h);
-                const float uu[4] = {u.x, u.y, u.z, u.w};
+                float uu[4] = {u.x, u.y, u.z, u.w};
+                if constexpr (G) {
+                    const float4 b = *reinterpret_cast<const float4*>(lb + 32 * t + 8 * gq + 4 * h);
+                    uu[0] += b.x; uu[1] += b.y; uu[2] += b.z; uu[3] += b.w;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float x = fmaxf(fmaf(ug[t][4 * gq + r], undo1, uu[r]), 0.0f);
@@ -158,19 +175,21 @@ __global__ void __launch_bounds__(512) round2_kernel(const float* __restrict__ g
             // x = relu(Wq1 g + bq1); t = M x + v; <q2, qry> = y^T t + u^T x + c
             const float downq = lb[4 * kD + 2];
             f32x16 xq[kNT];
-            first_layer(ghi, glo, lds + kLdsWq1, lb + 2 * kD, gp / downq, lane, h, xq);
+            first_layer<true>(ghi, glo, lds + kLdsWq1, lb + 2 * kD, gp / downq, lane, h, xq);
             const float undoq = downq * ginv;
             const float* lu = lb + 3 * kD;
+            const float* lq = lb + 2 * kD;
             float xqm = 0.0f, dot_u = 0.0f;
 #pragma unroll
             for (int t = 0; t < kNT; ++t)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const float4 u = *reinterpret_cast<const float4*>(lu + 32 * t + 8 * gq + 4 * h);
-                    const float uu[4] = {u.x, u.y, u.z, u.w};
+                    const float4 b = *reinterpret_cast<const float4*>(lq + 32 * t + 8 * gq + 4 * h);
+                    const float uu[4] = {u.x, u.y, u.z, u.w}, bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float x = fmaxf(xq[t][4 * gq + r] * undoq, 0.0f);
+                        const float x = fmaxf(fmaf(xq[t][4 * gq + r], undoq, bb[r]), 0.0f);
                         xq[t][4 * gq + r] = x;
                         xqm = fmaxf(xqm, x);
                         dot_u = fmaf(uu[r], x, dot_u);
@@ -180,12 +199,23 @@ __global__ void __launch_bounds__(512) round2_kernel(const float* __restrict__ g
             float xp, xinv;
             pow2_scale(fmaxf(xqm, 1e-30f), xp, xinv);
             f32x16 acc[kNT];
-            second_layer(xq, xp, lds, lb + kD, xp / down2, lane, h, acc);
+            second_layer<true>(xq, xp, lds, lb + kD, xp / down2, lane, h, acc);
+            // y^T (M x) in the product's units, y^T v in true ones
+            const float* lv = lb + kD;
+            float dot_v = 0.0f;
 #pragma unroll
             for (int t = 0; t < kNT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dot = fmaf(ug[t][r], acc[t][r], dot);
-            dot = fmaf(dot, down2 * xinv, dot_u);
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(lv + 32 * t + 8 * gq + 4 * h);
+                    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dot = fmaf(ug[t][4 * gq + r], acc[t][4 * gq + r], dot);
+                        dot_v = fmaf(ug[t][4 * gq + r], vv[r], dot_v);
+                    }
+                }
+            dot = fmaf(dot, down2 * xinv, dot_u + dot_v);
             dot += __shfl_xor(dot, 32, 64);
             dot += lb[4 * kD + 3];
         } else {
