@@ -63,8 +63,11 @@ def test_wgrad_kernel_matches_torch():
     g = torch.Generator().manual_seed(1)
     # (4099, 288, 576), (8221, 576, 579), (5000, 128, 576), (4100, 200, 100): wide layers over >= 4096 rows -> the bf16 x 3 kernel (ragged
     # tiles in both directions, the bias column at 579 = a tile's last live column); the rest: the fp32-pipe kernels
+    # (2304, ...): the per-ray layers of a training step; (2304 / 4099, 128, 16): a sparsely filled tile of the bf16 kernel (round 6: every layer
+    # over >= 2048 rows with N K >= 1024 takes it); (2047, ...) and (3000, 3, 128): just below either threshold, the fp32 pipe's kernels
     for M, N, K, relu in ((1000, 128, 16, False), (777, 3, 128, True), (4099, 288, 576, False), (513, 576, 579, False), (64, 128, 144, True),
-                          (8221, 576, 579, True), (5000, 128, 576, False), (4100, 200, 100, True)):
+                          (8221, 576, 579, True), (5000, 128, 576, False), (4100, 200, 100, True), (2304, 288, 576, False), (2304, 128, 16, True),
+                          (4099, 128, 16, False), (2304, 128, 128, True), (2047, 288, 576, False), (3000, 3, 128, False), (2048, 32, 32, True)):
         ldy, ldx = N + (4 - N % 4) % 4 + 4, K + (4 - K % 4) % 4
         dy = torch.randn(M, ldy, generator=g).to(dev)
         x = torch.randn(M, ldx, generator=g).to(dev)
