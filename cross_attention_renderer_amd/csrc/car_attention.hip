@@ -10,7 +10,9 @@
 namespace {
 
 constexpr int kMaxSamples = CAR_MAX_VIEWS * 256;
-constexpr int kMaxSeg = 14;                      // widest row of the streaming value reduction: 14 x 64 channels (864 = three views' 288: 13.5)
+constexpr int kWideSeg = 14;                     // widest row of the streaming value reduction: 14 x 64 channels (864 = three views' 288: 13.5)
+constexpr int kNarrowSeg = 9;                    // the two-view routes' rows: 576 channels.  The segment count is a template argument: the
+                                                 // partial sums of all kMaxSeg segments are registers (56 for 14, 36 for 9: a wave of occupancy)
 
 __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -25,7 +27,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // sum_j exp(logit_j - m_g) val_j with m_g the group's largest logit (written by the fused per-sample kernel, csrc/car_fused.hip); the value
 // reduction then runs over the V * ceil(P / tile_steps) groups with the weights exp(m_g - M) / L instead of over the V * P sample rows —
 // the same sum, 1 / tile_steps of the bytes.  The softmax weights themselves (w_out, depth, argmax) are computed exactly as without.
-template <bool PARTS>
+template <bool PARTS, int kMaxSeg>
 __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ qa, const float* __restrict__ qb, int dq,
                                                      const float* __restrict__ val, int D, int b, int V, int R, int P,
                                                      const float* __restrict__ zprev, float zprev_scale,
@@ -42,8 +44,36 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
     // sample s = v*P + p of this ray lives at row ((sc*V+v)*R + r)*P + p
     auto row_of = [&](int s) -> long { return ((long)(sc * V + s / P) * R + r) * P + (s % P); };
 
-    // 1. logits: 16 lanes per sample, float4 per lane per step
     const int sub = tid & 15, grp = tid >> 4;            // 16 groups of 16 lanes
+    // rows of the value reduction (step 3): the samples, or (PARTS) the step groups.  Their addresses do not depend on the softmax, so the
+    // rows of the first iteration are requested HERE, in front of the logits -> max -> sum chain, and land while it runs: a workgroup then
+    // has its 16 rows in flight for its whole life instead of the last third of it (the PARTS launch is ONE iteration per workgroup and ran
+    // at 4.3 TB/s, latency-bound on two dependent round trips to memory)
+    const int pgs = PARTS ? (P + tile_steps - 1) / tile_steps : 0;
+    const int NV = PARTS ? V * pgs : S;
+    auto vrow_of = [&](int i) -> long {
+        if constexpr (PARTS) return ((long)(sc * V + i / pgs) * R + r) * pgs + (i % pgs);
+        else return row_of(i);
+    };
+    const bool streaming = D % 4 == 0 && D >= 64 && D <= 64 * kMaxSeg;
+    const int nseg = (D + 63) / 64;
+    float4 part[kMaxSeg];
+    // (PARTS only: the 36 registers held across the softmax cost the sample-row instance a wave of occupancy — 3.27 -> 3.58 ms on the second
+    // round's 19 GB, which runs eight iterations per workgroup and is bandwidth-bound, not latency-bound)
+    if (PARTS && streaming) {
+        const float* rowp = val + vrow_of(grp < NV ? grp : NV - 1) * D + 4 * sub;
+#pragma unroll
+        for (int j = 0; j < kMaxSeg; ++j) {
+            part[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < nseg && 64 * j + 4 * sub < D) {
+                // streamed once per round (19 GB per frame): non-temporal, so the rows do not displace what the next kernel reads
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rowp + 64 * j));
+                part[j] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+            }
+        }
+    }
+    // 1. logits: 16 lanes per sample, float4 per lane per step
     if (qb == nullptr) {                                 // logits were computed upstream (car_fused_samples)
         for (int s = tid; s < S; s += 256) s_w[s] = qa[row_of(s)];
     } else
@@ -68,7 +98,6 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
     if (lane == 0) s_red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    const int pgs = PARTS ? (P + tile_steps - 1) / tile_steps : 0;
     if constexpr (PARTS) {                                  // exp(m_g - M) of every group, from the raw logits (before they are overwritten)
         for (int gi = tid; gi < V * pgs; gi += 256) {
             const int v = gi / pgs, p0 = (gi % pgs) * tile_steps;
@@ -91,23 +120,21 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
     }
     if constexpr (PARTS) { for (int gi = tid; gi < V * pgs; gi += 256) s_g[gi] = s_g[gi] / sum; }
     __syncthreads();
-    // rows of the value reduction and their weights: the samples, or (PARTS) the step groups
-    const int NV = PARTS ? V * pgs : S;
     const float* wv = PARTS ? s_g : s_w;
-    auto vrow_of = [&](int i) -> long {
-        if constexpr (PARTS) return ((long)(sc * V + i / pgs) * R + r) * pgs + (i % pgs);
-        else return row_of(i);
-    };
     // 3. z = sum_s w_s val[s] (+ scale * zprev), replicated `reps` times
-    if (D % 4 == 0 && D >= 64 && D <= 64 * kMaxSeg) {
+    if (streaming) {
         // Streaming form for wide rows: a 16-lane group reads a whole row as ceil(D/64) float4 loads (16 B per lane, the row's D*4
         // bytes contiguous; the lanes past the end of a last, partial segment sit out), the 16 groups of the workgroup take samples
         // s = 16 it + group; every load instruction moves up to 1 KB and 4 iterations are in flight.  Partial sums meet in LDS.
-        const int nseg = (D + 63) / 64;
-        float4 part[kMaxSeg];
+        if constexpr (PARTS) {   // the first iteration's rows were loaded in front of the softmax: w * x (what fmaf(w, x, 0) gave)
+            const float w = grp < NV ? wv[grp] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < kMaxSeg; ++j) part[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s0 = 0; s0 < NV; s0 += 16) {
+            for (int j = 0; j < kMaxSeg; ++j) { part[j].x *= w; part[j].y *= w; part[j].z *= w; part[j].w *= w; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kMaxSeg; ++j) part[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int s0 = PARTS ? 16 : 0; s0 < NV; s0 += 16) {
             const int sidx = s0 + grp;
             const bool on = sidx < NV;
             const float w = on ? wv[sidx] : 0.0f;
@@ -115,7 +142,6 @@ __global__ void __launch_bounds__(256) attend_kernel(const float* __restrict__ q
 #pragma unroll
             for (int j = 0; j < kMaxSeg; ++j) {
                 if (j < nseg && 64 * j + 4 * sub < D) {
-                    // streamed once per round (19 GB per frame): non-temporal, so the rows do not displace what the next kernel reads
                     typedef float f32x4 __attribute__((ext_vector_type(4)));
                     const f32x4 xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rowp + 64 * j));
                     const float4 x = make_float4(xv[0], xv[1], xv[2], xv[3]);
@@ -204,7 +230,8 @@ extern "C" int car_attend(const float* qa, const float* qb, int dq, const float*
     CAR_REQUIRE((!qb || (dq > 0 && dq % 4 == 0)) && D > 0 && reps >= 1 && ld_z >= reps * D, "car_attend: bad widths dq=%d D=%d", dq, D);
     CAR_REQUIRE(!pt || (poses && depth), "car_attend: pt needs poses and depth");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(attend_kernel<false>, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, qa, qb, dq, val,
+    auto kern = D <= 64 * kNarrowSeg ? attend_kernel<false, kNarrowSeg> : attend_kernel<false, kWideSeg>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, qa, qb, dq, val,
                        D, b, V, R, P, zprev, zprev_scale, w_out, z_out, ld_z, reps, pt, (const CarPose*)poses, depth,
                        w_argmax, 0);
     CAR_CHECK_LAUNCH("car_attend");
@@ -221,7 +248,8 @@ extern "C" int car_attend_parts(const float* logit, const float* part, int tile_
     CAR_REQUIRE(tile_steps >= 4 && D > 0 && reps >= 1 && ld_z >= reps * D, "car_attend_parts: bad widths D=%d tile_steps=%d", D, tile_steps);
     CAR_REQUIRE(!pt || (poses && depth), "car_attend_parts: pt needs poses and depth");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(attend_kernel<true>, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, logit, (const float*)nullptr, 0,
+    auto kern = D <= 64 * kNarrowSeg ? attend_kernel<true, kNarrowSeg> : attend_kernel<true, kWideSeg>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)b * R)), dim3(256), 0, (hipStream_t)stream, logit, (const float*)nullptr, 0,
                        part, D, b, V, R, P, (const float*)nullptr, 0.0f, w_out, z_out, ld_z, reps, pt, (const CarPose*)poses, depth, w_argmax,
                        tile_steps);
     CAR_CHECK_LAUNCH("car_attend_parts");
