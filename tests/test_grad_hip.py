@@ -240,6 +240,54 @@ def test_a_gradient_step_lowers_the_image_loss_by_the_predicted_amount():
     assert np.isfinite(loss1) and predicted / 1.5 <= drop <= predicted * 1.5, (loss0.item(), loss1, predicted)
 
 
+def test_round6_default_routes_agree_with_the_conservative_ones_at_a_training_steps_row_counts():
+    """At the row counts of the reference's training step (2304 rays: b x R = 2 x 1152 here; 147 456 sample-source rows) the default routes of
+    round 6 — weight gradients on the bf16 x 3 kernel from 2048 rows on, the split-fp16 layer kernel from 2048 rows on with the ReLU mask in
+    its store, the pyramid's gradient by binned taps — against the conservative ones (fp32-pipe weight gradients, the 4096-row threshold, the
+    fp32-atomic scatter): every gradient within 1e-3 of its tensor's largest entry (the fixtures' bound), the forward bit for bit where the
+    kernels are the same and to 2e-5 where the per-ray layers changed pipes."""
+    from cross_attention_renderer_amd import synthetic as S
+    from cross_attention_renderer_amd.models import CrossAttentionRenderer
+    from cross_attention_renderer_amd.training import render_train
+    dev = torch.device("cuda:0")
+    H, P, R = 64, 32, 1152
+    torch.manual_seed(0)
+    m = CrossAttentionRenderer(model="midas_vit", n_view=2, npoints=P, with_encoder=False).train()
+    S.perturb_parameters(m, seed=4)
+    m.H = m.W = H
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(7)
+    uv = S.pixel_grid(H, H)[torch.randperm(H * H, generator=g)[:R]].contiguous()
+    inp = to_device(S.stereo_scene(H, b=2, uv=uv, seed=5), dev, cameras_on_host=True)
+    base = [t.to(dev) for t in S.feature_maps(2, 2, H, seed=1)]
+    cot = torch.randn(2, 1, R, 3, generator=g).to(dev)
+
+    def run(conservative):
+        z = [t.clone().requires_grad_(True) for t in base]
+        m.zero_grad(set_to_none=True)
+        out = render_train(m, inp, z=z)                                               # the engine exists after the first call
+        eng = m._engine
+        eng.wgrad_fp32, eng.scatter_atomics, eng.linear_x3_min_rows = (True, True, 4096) if conservative else (False, False, 2048)
+        z = [t.clone().requires_grad_(True) for t in base]
+        m.zero_grad(set_to_none=True)
+        out = render_train(m, inp, z=z)
+        (out["rgb"] * cot).sum().backward()
+        grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        grads.update({f"z{i}": t.grad.clone() for i, t in enumerate(z)})
+        return out["rgb"].detach().clone(), grads
+    try:
+        rgb_a, ga = run(False)
+        rgb_b, gb = run(True)
+    finally:
+        m._engine.wgrad_fp32, m._engine.scatter_atomics, m._engine.linear_x3_min_rows = False, False, 2048
+    assert (rgb_a - rgb_b).abs().max().item() <= 2e-5 * max(1.0, rgb_b.abs().max().item())
+    assert ga.keys() == gb.keys() and len(ga) == 45
+    for k in ga:
+        scale = gb[k].abs().max().item()
+        assert torch.isfinite(ga[k]).all(), k
+        assert (ga[k] - gb[k]).abs().max().item() <= 1e-3 * max(scale, 1e-12), (k, (ga[k] - gb[k]).abs().max().item(), scale)
+
+
 def test_model_call_in_train_mode_carries_gradients_and_channel_last_levels_are_taken_as_they_lie():
     """The reference's training loop calls model(model_input) (training.py:92): on a module in train() mode under autograd that call IS
     render_train here; under no_grad() or in eval() mode it is the inference engine.  A pyramid level in torch.channels_last memory is used
